@@ -1,0 +1,306 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the reference retrieval hot path.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+See oracle/__init__.py for which parts are pinned by golden vectors.
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+__all__ = [
+    "matching_l2", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
+    "extract_ms_tail", "knn_flat_ip", "compute_ap2", "compute_map2", "compute_map_revisited",
+    "get_affinity", "get_laplacian", "diffusion_offline", "diffusion_online", "qge_small",
+    "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
+]
+
+
+# --------------------------------------------------------------------------- a1
+def matching_l2(K, gallery, queries):
+    """a1: src/utils/nnsearch.py:687-706 (matching_L2).
+
+    Rows of both matrices are divided by their L2 norm with NO eps (:693-698), then for every
+    query the distances ||q - G|| over gallery rows are fully argsorted ascending and the
+    first K kept (:699-703).  Arithmetic stays in the input dtype.  Timing is not restated.
+    """
+    gallery = np.asarray(gallery)
+    queries = np.asarray(queries)
+    gn = gallery / np.linalg.norm(gallery, axis=1)[:, None]
+    qn = queries / np.linalg.norm(queries, axis=1)[:, None]
+    out = np.zeros((qn.shape[0], K), dtype=np.int64)
+    for r in range(qn.shape[0]):
+        d = np.linalg.norm(qn[r, :] - gn, axis=1)
+        out[r, :] = np.argsort(d)[:K]
+    return out
+
+
+# --------------------------------------------------------------------------- a2
+def ip_rank(vecs, qvecs):
+    """a2: src/main_retrieve.py:175-176 -- scores = vecs.T @ qvecs ; ranks = argsort(-scores, 0).
+
+    vecs [D,N], qvecs [D,Q] (column per image).  Returns (ranks int64 [N,Q], scores [N,Q]).
+    """
+    scores = np.dot(vecs.T, qvecs)
+    return np.argsort(-scores, axis=0), scores
+
+
+# --------------------------------------------------------------------------- a3
+def qe_weights(k, w):
+    """src/utils/Reranking.py:197 -- ((k, k-1, ..., 1)/k) ** w, float64."""
+    return (np.arange(k, 0, -1) / k) ** w
+
+
+def feature_enhancement(k, ranks, vecs, w):
+    """a3: src/utils/Reranking.py:195-208 (identical copy at :288-301).
+
+    ranks [K_in,Q] int, vecs [D,N].  The expanded query is the weighted sum of the top-k
+    gallery columns (the original query is NOT added, :203 is commented out), divided by
+    (||.||_2 + 1e-6) (:204); all gallery columns are re-scored by inner product and fully
+    argsorted descending (:206-207).  The reference's it_times loop re-reads the input ranks
+    every pass, so any it_times >= 1 gives this single-pass result.
+    Returns (q_exp [D,Q] float64, ranks_aqe int64 [N,Q]).
+    """
+    wts = qe_weights(k, w).reshape(1, k, 1)
+    top = vecs[:, ranks[:k, :]]                       # [D,k,Q]
+    qx = (top * wts).sum(axis=1)                      # [D,Q], promotes to float64
+    qx = qx / (np.linalg.norm(qx, ord=2, axis=0, keepdims=True) + 1e-6)
+    scores = np.dot(vecs.T, qx)
+    return qx, np.argsort(-scores, axis=0)
+
+
+def qge1(ranks, qvec, vecs, K):
+    """src/utils/Reranking.py:287-306 -- k=3, w=4.0, one pass; K and qvec are unused there."""
+    return feature_enhancement(3, ranks, vecs, 4.0)[1]
+
+
+# --------------------------------------------------------------------------- a7 / a8
+def l2n(x, eps=1e-6):
+    """a7: src/layers/functional.py:129-130 -- x / (||x||_2 over dim 1 + eps), x [B,D,...]."""
+    x = np.asarray(x)
+    return x / (np.sqrt((x * x).sum(axis=1, keepdims=True)) + x.dtype.type(eps))
+
+
+def extract_ms_tail(per_scale, msp=1.0):
+    """a7: src/networks/imageretrievalnet.py:473-477 -- mean over scales of v**msp, **(1/msp),
+    then v / ||v|| (no eps).  per_scale [S,D]."""
+    v = np.zeros(per_scale.shape[1], dtype=per_scale.dtype)
+    for s in range(per_scale.shape[0]):
+        v = v + per_scale[s] ** msp
+    v = v / per_scale.shape[0]
+    v = v ** (1.0 / msp)
+    return v / np.linalg.norm(v)
+
+
+def whitenapply(X, m, P, dimensions=None):
+    """a8: src/utils/whiten.py:4-12 -- P[:dims] @ (X - m), columns / (||.|| + 1e-6)."""
+    if not dimensions:
+        dimensions = P.shape[0]
+    Y = np.dot(P[:dimensions, :], X - m)
+    return Y / (np.linalg.norm(Y, ord=2, axis=0, keepdims=True) + 1e-6)
+
+
+# --------------------------------------------------------------------------- a6
+def knn_flat_ip(database, queries, k):
+    """a6: src/utils/knn.py:8-40 -- contract of faiss.IndexFlatIP.search (third-party, absent):
+    exact top-k float32 inner products per query, descending.  Tie order unspecified in faiss;
+    here ties go to the lower index.  Returns (sims f32 [Q,k], ids int64 [Q,k])."""
+    db = np.ascontiguousarray(database, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    s = q @ db.T
+    order = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(s, order, axis=1), order.astype(np.int64)
+
+
+# --------------------------------------------------------------------------- a9
+def compute_ap2(pos, nres):
+    """a9: src/utils/evaluate2.py:4-33 -- trapezoid AP from zero-based positive positions."""
+    ap = 0.0
+    step = 1.0 / nres
+    for j in range(len(pos)):
+        r = pos[j]
+        p0 = 1.0 if r == 0 else float(j) / r
+        p1 = float(j + 1) / (r + 1)
+        ap += (p0 + p1) * step / 2.0
+    return ap
+
+
+def compute_map2(ranks, gnd):
+    """a9: src/utils/evaluate2.py:36-107.  ranks [K,Q]; gnd[i] has 'ok' and optional 'junk'.
+    Junk entries ranked before a positive shift that positive up.  Queries without positives
+    are excluded from the mean.  Returns (map, aps)."""
+    nq = len(gnd)
+    aps = np.zeros(nq)
+    total, nempty = 0.0, 0
+    for i in range(nq):
+        ok = np.array(gnd[i]["ok"])
+        if ok.shape[0] == 0:
+            aps[i] = float("nan")
+            nempty += 1
+            continue
+        junk_ids = np.array(gnd[i]["junk"]) if "junk" in gnd[i] else np.empty(0)
+        col = ranks[:, i]
+        pos = np.flatnonzero(np.isin(col, ok))
+        junk = np.flatnonzero(np.isin(col, junk_ids))
+        if len(junk):
+            shift = np.searchsorted(junk, pos)      # junk ranked strictly before each positive
+            pos = pos - shift
+        ap = compute_ap2(pos, len(ok))
+        total += ap
+        aps[i] = ap
+    return total / (nq - nempty), aps
+
+
+def compute_map_revisited(ranks, gnd):
+    """a9: src/utils/evaluate2.py:118-145 -- Easy / Medium / Hard splits of the revisited protocol.
+    Returns (mapE, mapM, mapH)."""
+    out = []
+    for ok_keys, junk_keys in ((("easy",), ("junk", "hard")),
+                               (("easy", "hard"), ("junk",)),
+                               (("hard",), ("junk", "easy"))):
+        g = [{"ok": np.concatenate([gnd[i][k] for k in ok_keys]),
+              "junk": np.concatenate([gnd[i][k] for k in junk_keys])} for i in range(len(gnd))]
+        out.append(compute_map2(ranks, g)[0])
+    return tuple(out)
+
+
+# --------------------------------------------------------------------------- a5
+def get_affinity(sims, ids, gamma=3):
+    """a5: src/utils/diffusion.py:101-116.  sims/ids [N,kd].  Negative sims are clipped to 0,
+    raised to gamma; (i, ids[i,j]) is kept iff i appears in the kd-list of ids[i,j] (mutual),
+    position 0 is always dropped (:108).  CSC float32 [N,N]."""
+    num = sims.shape[0]
+    s = np.where(sims < 0, 0, sims) ** gamma
+    rr, cc, vv = [], [], []
+    for i in range(num):
+        mutual = np.isin(ids[ids[i]], i).any(axis=1)
+        mutual[0] = False
+        if mutual.any():
+            rr.append(np.full(int(mutual.sum()), i, dtype=int))
+            cc.append(ids[i, mutual])
+            vv.append(s[i, mutual])
+    rr, cc, vv = map(np.concatenate, (rr, cc, vv))
+    return sp.csc_matrix((vv, (rr, cc)), shape=(num, num), dtype=np.float32)
+
+
+def get_laplacian(sims, ids, alpha=0.99):
+    """a5: src/utils/diffusion.py:87-98 -- I - alpha * D^-1/2 A D^-1/2 with deg = A@1 + 1e-12."""
+    aff = get_affinity(sims, ids)
+    num = aff.shape[0]
+    deg = aff @ np.ones(num) + 1e-12
+    dm = sp.dia_matrix((deg ** (-0.5), [0]), shape=(num, num), dtype=np.float32)
+    stoch = dm @ aff @ dm
+    eye = sp.dia_matrix((np.ones(num), [0]), shape=(num, num), dtype=np.float32)
+    return eye - alpha * stoch
+
+
+def diffusion_offline(features, n_trunc, kd=50, return_parts=False):
+    """a5: src/utils/diffusion.py:52-84 (N < 110000 branch) + :15-19.
+
+    kNN graph by exact inner product (faiss IndexFlatIP stand-in), Laplacian on the first kd
+    columns, then for every node a CG solve of lap[ids_i][:, ids_i] x = e0 with
+    rtol=1e-6 (legacy tol=1e-6, ||b|| = 1), at most 20 iterations, result ignored on
+    non-convergence like the reference (info is dropped).  CSR float32 [N,N]."""
+    n = len(features)
+    sims, ids = knn_flat_ip(features, features, n_trunc)
+    lap = sp.csr_matrix(get_laplacian(sims[:, :kd].copy(), ids[:, :kd]))
+    b = np.zeros(n_trunc)
+    b[0] = 1
+    allsc = np.empty((n, n_trunc))
+    for i in range(n):
+        sub = lap[ids[i]][:, ids[i]]
+        allsc[i], _ = spla.cg(sub, b, rtol=1e-6, atol=0.0, maxiter=20)
+    rows = np.repeat(np.arange(n), n_trunc)
+    off = sp.csr_matrix((allsc.reshape(-1), (rows, ids.reshape(-1))), shape=(n, n), dtype=np.float32)
+    if return_parts:
+        return off, sims, ids, lap, allsc
+    return off
+
+
+def diffusion_online(q_for_search, features, offline, k_query=3, truncation_number=2000):
+    """a4: src/utils/Reranking.py:238-253 -- top-k_query gallery neighbours of each query, sims**3,
+    scores = sims[i] @ offline[idx[i]], top-`truncation_number` by argpartition then argsort.
+    q_for_search [Q,D].  Returns (ranks_dfs [trunc,Q] int64, scores [Q,trunc] float32)."""
+    sims, idx = knn_flat_ip(features, q_for_search, k_query)
+    sims = sims ** 3
+    nq = idx.shape[0]
+    tr_s = np.empty((nq, truncation_number), dtype=np.float32)
+    tr_r = np.empty((nq, truncation_number), dtype=np.int64)
+    for i in range(nq):
+        sc = np.asarray(sims[i] @ offline[idx[i]]).ravel()
+        parts = np.argpartition(-sc, truncation_number)[:truncation_number]
+        o = np.argsort(-sc[parts])
+        tr_s[i] = sc[parts][o]
+        tr_r[i] = parts[o]
+    return tr_r.T, tr_s
+
+
+def qge_small(ranks, qvecs, vecs, AQE=True, truncation_number=2000, k_gallery=200, k_query=3):
+    """a4: src/utils/Reranking.py:212-253 (N < 120000): alpha-QE with k=10, w=4 and then the
+    diffusion re-search with the expanded (AQE) or original queries.  Returns
+    (qvecs_qe, ranks_aqe, ranks_dfs)."""
+    qx, ranks_aqe = feature_enhancement(10, ranks, vecs, 4.0)
+    feats = np.ascontiguousarray(vecs.T)
+    off = diffusion_offline(feats, truncation_number, k_gallery)
+    qs = qx.T if AQE else qvecs.T
+    ranks_dfs, _ = diffusion_online(qs, feats, off, k_query, truncation_number)
+    return qx, ranks_aqe, ranks_dfs
+
+
+# --------------------------------------------------------------------------- checkers
+def exact_scores_f64(gallery, queries, normalize=True):
+    """Ground truth for the tolerance checks: float64 cosine (or raw IP) scores [Q,N]."""
+    g = np.asarray(gallery, dtype=np.float64)
+    q = np.asarray(queries, dtype=np.float64)
+    if normalize:
+        g = g / np.linalg.norm(g, axis=1)[:, None]
+        q = q / np.linalg.norm(q, axis=1)[:, None]
+    return q @ g.T
+
+
+def exact_topk_f64(gallery, queries, K, normalize=True):
+    """Exact top-K by float64 score, ties to the lower index.  (idx [Q,K], scores [Q,K])."""
+    s = exact_scores_f64(gallery, queries, normalize)
+    order = np.argsort(-s, axis=1, kind="stable")[:, :K]
+    return order.astype(np.int64), np.take_along_axis(s, order, axis=1)
+
+
+def check_topk_parity(idx, scores_f64, K, tau):
+    """Near-tie tolerant parity.  `idx` [Q,K] from the system under test,
+    `scores_f64` [Q,N] ground-truth scores (higher = better).  For every query:
+      * no duplicates;
+      * every returned item scores >= s_K - tau  (s_K = K-th best ground-truth score);
+      * every item scoring > s_K + tau is returned;
+      * the returned order is non-increasing in ground-truth score up to tau.
+    Returns a list of violation strings (empty = parity)."""
+    bad = []
+    idx = np.asarray(idx)
+    for q in range(idx.shape[0]):
+        s = scores_f64[q]
+        sk = np.partition(s, -K)[-K]
+        got = idx[q, :K]
+        if len(np.unique(got)) != K:
+            bad.append(f"q{q}: duplicate indices")
+            continue
+        gs = s[got]
+        if (gs < sk - tau).any():
+            bad.append(f"q{q}: returned item below K-th score by {float((sk - gs).max()):.3e}")
+        must = np.flatnonzero(s > sk + tau)
+        miss = np.setdiff1d(must, got)
+        if len(miss):
+            bad.append(f"q{q}: missing {len(miss)} items clearly inside the top-K")
+        if (np.diff(gs) > tau).any():
+            bad.append(f"q{q}: order violates ground truth by {float(np.diff(gs).max()):.3e}")
+    return bad
+
+
+def merge_topk(scores_list, idx_list, K):
+    """Checker for the multi-shard merge: lists of per-shard (scores [Q,k], global idx [Q,k]) ->
+    top-K by (score desc, idx asc)."""
+    s = np.concatenate(scores_list, axis=1)
+    i = np.concatenate(idx_list, axis=1)
+    out_s = np.empty((s.shape[0], K), dtype=s.dtype)
+    out_i = np.empty((s.shape[0], K), dtype=np.int64)
+    for q in range(s.shape[0]):
+        o = np.lexsort((i[q], -s[q].astype(np.float64)))[:K]
+        out_s[q], out_i[q] = s[q][o], i[q][o]
+    return out_s, out_i
