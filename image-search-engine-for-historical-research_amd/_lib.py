@@ -1,0 +1,259 @@
+"""ctypes binding of libmi355_retrieval.so (include/mi355_retrieval.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised.  `load()` never builds; build with `python image-search-engine-for-historical-research_amd/build.py`
+or `__graft_entry__.build()`.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355_retrieval.so")
+
+MI_F32, MI_F64 = 0, 1
+MI_HOST, MI_DEVICE = 0, 1
+NORM_NONE, NORM_L2, NORM_L2_EPS = 0, 1, 2
+
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("searches", C.c_int64), ("queries", C.c_int64), ("overflow_batches", C.c_int64),
+                ("survivors", C.c_int64), ("candidates", C.c_int64), ("gemm_ms", C.c_double),
+                ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/mi355_retrieval.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mi_last_error": (C.c_char_p, []),
+    "mi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mi_gallery_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_int,
+                                    C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "mi_gallery_destroy": (C.c_int, [C.c_void_p]),
+    "mi_gallery_info": (C.c_int, [C.c_void_p, c_i64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), c_i64p, c_i64p]),
+    "mi_gallery_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mi_gallery_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mi_gallery_get_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "mi_knn_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
+                                C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_knn_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "mi_knn_phase1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_kth_of_gathered_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_knn_phase2_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "mi_topk_merge_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "mi_aqe_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                        C.c_double, C.c_void_p, C.c_void_p]),
+    "mi_aqe_finish_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "mi_aqe_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
+                                C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
+    "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Loads the HIP library; raises RuntimeError (never falls back) if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmi355_retrieval.so is not built (%s). Run `python __graft_entry__.py build`; "
+                "this package has no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mi_last_error()
+        raise RuntimeError("mi355_retrieval error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def _strided(a):
+    """(pointer, dtype code, row stride, col stride) of a 2-D float32/float64 array, in elements.
+    Arrays whose strides are not whole, non-negative element multiples are copied once."""
+    a = np.asarray(a)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64 if a.dtype.itemsize > 4 else np.float32)
+    isz = a.dtype.itemsize
+    if any(s % isz or s < 0 for s in a.strides):
+        a = np.ascontiguousarray(a)
+    code = MI_F32 if a.dtype == np.float32 else MI_F64
+    return a, code, a.strides[0] // isz, a.strides[1] // isz
+
+
+def _base_pointer(a):
+    """Pointer to element (0,0) plus the lowest address of the strided block."""
+    return a.ctypes.data
+
+
+class Gallery:
+    """One gallery row shard resident on one MI355X (a `mi_gallery` handle)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        self._lock = threading.Lock()      # the handle is not re-entrant (Flask threads in online.py)
+        n, d = C.c_int64(), C.c_int32()
+        nm, dev = C.c_int32(), C.c_int32()
+        off, hb = C.c_int64(), C.c_int64()
+        check(load().mi_gallery_info(self._h, n, d, nm, dev, off, hb))
+        self.n, self.d, self.norm_mode, self.device = n.value, d.value, nm.value, dev.value
+        self.row_offset, self.hbm_bytes = off.value, hb.value
+
+    # ---- construction
+    @classmethod
+    def from_host(cls, rows, norm_mode=NORM_L2, device=0, row_offset=0):
+        """rows: [N, D] float32/float64, any strides (e.g. `vecs.T` of the reference's [D, N])."""
+        a, code, rs, cs = _strided(rows)
+        h = C.c_void_p()
+        check(load().mi_gallery_create(C.c_void_p(_base_pointer(a)), a.shape[0], a.shape[1], code, rs, cs, MI_HOST,
+                                       norm_mode, device, row_offset, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_device_ptr(cls, ptr, n, d, norm_mode=NORM_L2, device=0, row_offset=0, dtype=MI_F32, row_stride=None,
+                        col_stride=1):
+        h = C.c_void_p()
+        check(load().mi_gallery_create(C.c_void_p(ptr), n, d, dtype, d if row_stride is None else row_stride,
+                                       col_stride, MI_DEVICE, norm_mode, device, row_offset, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path, device=0):
+        h = C.c_void_p()
+        check(load().mi_gallery_load(os.fsencode(path), device, C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path):
+        check(load().mi_gallery_save(self._h, os.fsencode(path)))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            load().mi_gallery_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host API
+    def search(self, queries, k):
+        """-> (idx int64 [Q,k], scores float32 [Q,k], seconds)."""
+        a, code, rs, cs = _strided(queries)
+        if a.shape[1] != self.d:
+            raise ValueError("query dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        nq = a.shape[0]
+        idx = np.empty((nq, k), dtype=np.int64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        secs = C.c_double()
+        with self._lock:
+            check(load().mi_knn_search(self._h, C.c_void_p(_base_pointer(a)), nq, code, rs, cs, k,
+                                       idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), C.byref(secs)))
+        return idx, sc, secs.value
+
+    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6, return_qexp=False):
+        """ranks [K_in, Q] int64 (any strides) -> (idx [Q,k], scores [Q,k], qexp [Q,D] f64 | None, seconds)."""
+        r = np.asarray(ranks)
+        if r.dtype != np.int64:
+            r = r.astype(np.int64)
+        if any(s % 8 or s < 0 for s in r.strides):
+            r = np.ascontiguousarray(r)
+        nq = r.shape[1]
+        idx = np.empty((nq, k), dtype=np.int64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        qx = np.empty((nq, self.d), dtype=np.float64) if return_qexp else None
+        secs = C.c_double()
+        with self._lock:
+            check(load().mi_aqe_search(self._h, r.ctypes.data_as(C.c_void_p), r.strides[0] // 8, r.strides[1] // 8,
+                                       nq, k_qe, float(w), float(eps), k, idx.ctypes.data_as(C.c_void_p),
+                                       sc.ctypes.data_as(C.c_void_p),
+                                       qx.ctypes.data_as(C.c_void_p) if return_qexp else None, C.byref(secs)))
+        return idx, sc, qx, secs.value
+
+    def get_rows(self, row0, nrows):
+        out = np.empty((nrows, self.d), dtype=np.float32)
+        check(load().mi_gallery_get_rows(self._h, row0, nrows, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- device API (raw pointers; used by bench.py and the sharded path with torch tensors)
+    def search_device(self, q_ptr, nq, k, idx_ptr, score_ptr=None, score64_ptr=None, stream=None):
+        check(load().mi_knn_search_device(self._h, C.c_void_p(q_ptr), nq, k, C.c_void_p(idx_ptr),
+                                          C.c_void_p(score_ptr), C.c_void_p(score64_ptr), C.c_void_p(stream)))
+
+    def phase1_device(self, q_ptr, nq, k, approx_ptr, stream=None):
+        check(load().mi_knn_phase1_device(self._h, C.c_void_p(q_ptr), nq, k, C.c_void_p(approx_ptr),
+                                          C.c_void_p(stream)))
+
+    def phase2_device(self, nq, k, L_ptr, idx_ptr, score_ptr, score64_ptr, stream=None):
+        check(load().mi_knn_phase2_device(self._h, nq, k, C.c_void_p(L_ptr), C.c_void_p(idx_ptr),
+                                          C.c_void_p(score_ptr), C.c_void_p(score64_ptr), C.c_void_p(stream)))
+
+    def aqe_partial_device(self, ranks_ptr, stride_j, stride_q, nq, k_qe, w, sum_ptr, stream=None):
+        check(load().mi_aqe_partial_device(self._h, C.c_void_p(ranks_ptr), stride_j, stride_q, nq, k_qe, float(w),
+                                           C.c_void_p(sum_ptr), C.c_void_p(stream)))
+
+    # ---- instrumentation
+    def set_option(self, name, value):
+        check(load().mi_set_option(self._h, name.encode(), float(value)))
+
+    def profile(self, on=True):
+        check(load().mi_profile_enable(self._h, 1 if on else 0))
+
+    def status(self, reset=False):
+        st = SearchStats()
+        check(load().mi_search_status(self._h, C.byref(st), 1 if reset else 0))
+        return st.as_dict()
+
+
+def kth_of_gathered_device(gathered_ptr, nshards, nq, k, out_ptr, stream=None):
+    check(load().mi_kth_of_gathered_device(C.c_void_p(gathered_ptr), nshards, nq, k, C.c_void_p(out_ptr),
+                                           C.c_void_p(stream)))
+
+
+def topk_merge_device(score64_ptr, idx_ptr, nshards, nq, k, out_idx_ptr, out_score_ptr, stream=None):
+    check(load().mi_topk_merge_device(C.c_void_p(score64_ptr), C.c_void_p(idx_ptr), nshards, nq, k,
+                                      C.c_void_p(out_idx_ptr), C.c_void_p(out_score_ptr), C.c_void_p(stream)))
+
+
+def aqe_finish_device(sum_ptr, nq, d, eps, out_q_ptr, out_q64_ptr=None, stream=None):
+    check(load().mi_aqe_finish_device(C.c_void_p(sum_ptr), nq, d, float(eps), C.c_void_p(out_q_ptr),
+                                      C.c_void_p(out_q64_ptr), C.c_void_p(stream)))
+
+
+def synth_fill_device(dst_ptr, seed, row0, nrows, d, stream=None):
+    check(load().mi_synth_fill_device(C.c_void_p(dst_ptr), seed, row0, nrows, d, C.c_void_p(stream)))
+
+
+def device_count():
+    n = C.c_int()
+    check(load().mi_device_count(C.byref(n)))
+    return n.value

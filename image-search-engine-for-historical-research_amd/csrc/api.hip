@@ -1,0 +1,745 @@
+// Host side of the C ABI (include/mi355_retrieval.h): handle management, workspace, the chunked
+// scoring schedule and the two-phase exact top-K protocol.  No torch, no numpy: plain pointers.
+#include "../../include/mi355_retrieval.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace mi;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPC(expr)                                                                                   \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return fail(_e == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP,                             \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                                \
+  } while (0)
+#define REQUIRE(cond, msg) \
+  do {                     \
+    if (!(cond)) return fail(MI_ERR_INVALID, msg); \
+  } while (0)
+
+namespace {
+constexpr int QB = 1024;  // queries per batch (workspace size)
+
+struct Workspace {
+  int32_t qcap = 0, kcap = 0;
+  uint32_t cap = 0, rcap = 0;
+  float* q_f32 = nullptr;
+  void* q_bf16 = nullptr;
+  RowStat* q_stat = nullptr;
+  float *thr = nullptr, *margin = nullptr;
+  uint32_t* cnt = nullptr;
+  uint64_t* surv = nullptr;
+  uint32_t* flags = nullptr;
+  float *topvals = nullptr, *L = nullptr;
+  uint32_t *cand_rows = nullptr, *cand_cnt = nullptr;
+  double* cand_score = nullptr;
+  uint64_t* stats2 = nullptr;
+  std::vector<void*> allocs;
+};
+}  // namespace
+
+struct mi_gallery {
+  int device = 0;
+  int64_t n = 0, npad = 0, row_offset = 0;
+  int32_t d = 0, dp = 0, ksteps = 0, norm_mode = 0;
+  float* gal_f32 = nullptr;
+  void* gal_bf16 = nullptr;
+  RowStat* rowstat = nullptr;
+  float* gstat3 = nullptr;
+  int64_t hbm_bytes = 0;
+  hipStream_t stream = nullptr;
+  Workspace ws;
+  // options
+  int chunk0_tiles = 4, chunk_growth = 8, exact_fallback = 1, force_exact = 0;
+  uint32_t surv_cap = 8192, rescore_cap = 2048;
+  // stats
+  mi_search_stats stats{};
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  hipStream_t ev_stream = nullptr;
+  std::mutex mu;
+};
+
+static int ws_free(Workspace& ws) {
+  for (void* p : ws.allocs) (void)hipFree(p);
+  ws = Workspace();
+  return MI_OK;
+}
+
+template <typename T>
+static int dev_alloc(Workspace& ws, T** p, size_t count) {
+  void* v = nullptr;
+  HIPC(hipMalloc(&v, count * sizeof(T) + 256));
+  ws.allocs.push_back(v);
+  *p = reinterpret_cast<T*>(v);
+  return MI_OK;
+}
+
+static int ws_ensure(mi_gallery* g, int32_t k) {
+  Workspace& ws = g->ws;
+  if (ws.qcap >= QB && ws.kcap >= k && ws.cap == g->surv_cap && ws.rcap == g->rescore_cap) return MI_OK;
+  const int32_t kcap = std::max<int32_t>(k, ws.kcap);
+  ws_free(ws);
+  ws.qcap = QB;
+  ws.kcap = kcap;
+  ws.cap = g->surv_cap;
+  ws.rcap = g->rescore_cap;
+  int rc;
+#define A(ptr, count) \
+  if ((rc = dev_alloc(ws, &ws.ptr, (count))) != MI_OK) return rc;
+  A(q_f32, (size_t)QB * g->dp);
+  {
+    __hip_bfloat16* tmp = nullptr;
+    if ((rc = dev_alloc(ws, &tmp, (size_t)QB * g->dp)) != MI_OK) return rc;
+    ws.q_bf16 = tmp;
+  }
+  A(q_stat, QB);
+  A(thr, QB);
+  A(margin, QB);
+  A(cnt, QB);
+  A(surv, (size_t)QB * ws.cap);
+  A(flags, 4);
+  A(topvals, (size_t)QB * kcap);
+  A(L, QB);
+  A(cand_rows, (size_t)QB * ws.rcap);
+  A(cand_cnt, QB);
+  A(cand_score, (size_t)QB * ws.rcap);
+  A(stats2, 4);
+#undef A
+  HIPC(hipMemset(ws.flags, 0, 16));
+  HIPC(hipMemset(ws.stats2, 0, 32));
+  return MI_OK;
+}
+
+static QueryState make_state(const Workspace& ws) {
+  QueryState st;
+  st.thr = ws.thr;
+  st.margin = ws.margin;
+  st.cnt = ws.cnt;
+  st.surv = ws.surv;
+  st.flags = ws.flags;
+  st.cap = ws.cap;
+  return st;
+}
+
+static void prof_begin(mi_gallery* g, hipStream_t s, size_t* slot) {
+  *slot = (size_t)-1;
+  if (!g->profile) return;
+  if (g->ev_used == g->ev_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g->ev_pool.emplace_back(a, b);
+  }
+  *slot = g->ev_used++;
+  g->ev_stream = s;
+  (void)hipEventRecord(g->ev_pool[*slot].first, s);
+}
+static void prof_end(mi_gallery* g, hipStream_t s, size_t slot) {
+  if (slot == (size_t)-1) return;
+  (void)hipEventRecord(g->ev_pool[slot].second, s);
+}
+static void prof_collect(mi_gallery* g) {
+  for (size_t i = 0; i < g->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g->ev_pool[i].second) == hipSuccess &&
+        hipEventElapsedTime(&ms, g->ev_pool[i].first, g->ev_pool[i].second) == hipSuccess) {
+      g->stats.gemm_ms += ms;
+      g->stats.gemm_launches += 1;
+    }
+  }
+  g->ev_used = 0;
+}
+
+// ---- phase 1 for one batch (nq <= QB): query ingest, chunked scoring + threshold maintenance ----------
+static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
+                        int32_t nq, int32_t k, bool exact, hipStream_t s) {
+  Workspace& ws = g->ws;
+  const int32_t qpad = (int32_t)round_up(nq, TILE);
+  launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_bf16, ws.q_stat, g->dp, qpad, s);
+  QueryState st = make_state(ws);
+  const int64_t ntiles = g->npad / TILE;
+  // bootstrap chunk: stored completely (no threshold yet); must hold >= K rows and fit the survivor buffer
+  int64_t t0 = std::max<int64_t>(g->chunk0_tiles, (2 * (int64_t)k + TILE - 1) / TILE);
+  t0 = std::min<int64_t>(t0, ws.cap / TILE);
+  t0 = std::min<int64_t>(t0, ntiles);
+  const uint32_t first_cnt = (uint32_t)std::min<int64_t>(g->n, t0 * TILE);
+  const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
+  launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
+  int64_t t = 0, len = t0;
+  bool first = true;
+  while (t < ntiles) {
+    const int64_t cur = std::min<int64_t>(len, ntiles - t);
+    const int64_t rows0 = t * TILE, rows1 = std::min<int64_t>(g->n, (t + cur) * TILE);
+    if (exact) {
+      ExactArgs a;
+      a.gal_f32 = g->gal_f32;
+      a.qry_f32 = ws.q_f32;
+      a.dp = g->dp;
+      a.row0 = rows0;
+      a.row1 = rows1;
+      a.n = g->n;
+      a.nq = nq;
+      a.st = st;
+      launch_exact_select(a, first, s);
+    } else {
+      ScoreArgs a;
+      a.gal_bf16 = g->gal_bf16;
+      a.qry_bf16 = ws.q_bf16;
+      a.ksteps = g->ksteps;
+      a.tile0 = (int32_t)t;
+      a.ntiles = (int32_t)cur;
+      a.nqt = qpad / TILE;
+      a.n = g->n;
+      a.nq = nq;
+      a.st = st;
+      size_t slot;
+      prof_begin(g, s, &slot);
+      launch_gemm_select(a, first, s);
+      prof_end(g, s, slot);
+      if (g->profile) {
+        const double rows = (double)(rows1 - rows0);
+        g->stats.gemm_flops += 2.0 * nq * rows * g->d;
+        g->stats.gemm_bytes += rows * g->d * 2.0 + (double)nq * g->d * 2.0;
+      }
+    }
+    t += cur;
+    const bool last = (t >= ntiles);
+    launch_select_maintain(st, nq, k, last ? 1 : 0, ws.topvals, ws.L, ws.stats2, s);
+    first = false;
+    len = (t == t0 && g->chunk_growth > 1) ? t0 * g->chunk_growth : len * std::max(1, g->chunk_growth);
+  }
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+// ---- phase 2 for one batch: candidates within the margin of L, exact f64 re-score, sorted emit --------
+static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev, int64_t* out_idx, float* out_score,
+                        double* out_score64, hipStream_t s) {
+  Workspace& ws = g->ws;
+  QueryState st = make_state(ws);
+  launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
+  launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
+  launch_emit(ws.cand_rows, ws.cand_cnt, ws.cand_score, ws.rcap, nq, k, g->row_offset, out_idx, out_score,
+              out_score64, s);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+static int check_k(const mi_gallery* g, int32_t k) {
+  REQUIRE(k >= 1, "k must be >= 1");
+  if ((int64_t)k > g->n)
+    return fail(MI_ERR_INVALID, "k > number of gallery rows (the reference fails in numpy broadcasting here, "
+                                "src/utils/nnsearch.py:703)");
+  if ((uint32_t)k * 4 > g->surv_cap || (uint32_t)k > g->rescore_cap)
+    return fail(MI_ERR_UNSUPPORTED, "k too large for the top-K path (needs k <= survivor_cap/4 and k <= rescore_cap)");
+  return MI_OK;
+}
+
+// full search of up to any nq on device inputs (strided, any dtype), outputs on device
+static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
+                         int64_t nq, int32_t k, int64_t* out_idx, float* out_score, double* out_score64, bool exact,
+                         hipStream_t s) {
+  int rc = check_k(g, k);
+  if (rc != MI_OK) return rc;
+  if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
+  const size_t esz = q_dtype == MI_F32 ? 4 : 8;
+  for (int64_t q0 = 0; q0 < nq; q0 += QB) {
+    const int32_t b = (int32_t)std::min<int64_t>(QB, nq - q0);
+    const char* src = (const char*)q_src + (size_t)q0 * q_rs * esz;
+    if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s)) != MI_OK) return rc;
+    if ((rc = phase2_batch(g, b, k, g->ws.L, out_idx + q0 * k, out_score ? out_score + q0 * k : nullptr,
+                           out_score64 ? out_score64 + q0 * k : nullptr, s)) != MI_OK)
+      return rc;
+    g->stats.searches += 1;
+    g->stats.queries += b;
+  }
+  return MI_OK;
+}
+
+static int strided_extent(int64_t n, int64_t d, int64_t rs, int64_t cs, int64_t* elems) {
+  REQUIRE(rs >= 0 && cs >= 0, "negative strides are not supported");
+  *elems = (n > 0 && d > 0) ? (n - 1) * rs + (d - 1) * cs + 1 : 0;
+  return MI_OK;
+}
+
+// =====================================================================================================
+extern "C" {
+
+const char* mi_last_error(void) { return g_err.c_str(); }
+
+int mi_device_count(int* count) {
+  REQUIRE(count, "null");
+  HIPC(hipGetDeviceCount(count));
+  return MI_OK;
+}
+
+int mi_gallery_destroy(mi_gallery* g) {
+  if (!g) return MI_OK;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  (void)hipDeviceSynchronize();
+  ws_free(g->ws);
+  for (auto& e : g->ev_pool) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  (void)hipFree(g->gal_f32);
+  (void)hipFree(g->gal_bf16);
+  (void)hipFree(g->rowstat);
+  (void)hipFree(g->gstat3);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+  return MI_OK;
+}
+
+static int gallery_alloc(mi_gallery* g) {
+  g->dp = (int32_t)round_up(g->d, BK);
+  g->ksteps = g->dp / BK;
+  g->npad = round_up(g->n, TILE);
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  const size_t f32_bytes = (size_t)g->n * g->dp * 4, bf_bytes = (size_t)g->npad * g->dp * 2;
+  HIPC(hipMalloc((void**)&g->gal_f32, f32_bytes + 256));
+  HIPC(hipMalloc(&g->gal_bf16, bf_bytes + 256));
+  HIPC(hipMalloc((void**)&g->rowstat, (size_t)g->npad * sizeof(RowStat)));
+  HIPC(hipMalloc((void**)&g->gstat3, 16));
+  g->hbm_bytes = (int64_t)(f32_bytes + bf_bytes + (size_t)g->npad * sizeof(RowStat));
+  return MI_OK;
+}
+
+int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
+                      int memspace, int norm_mode, int device, int64_t row_offset, mi_gallery** out) {
+  REQUIRE(data && out, "null pointer");
+  REQUIRE(n >= 1 && d >= 1, "empty gallery");
+  REQUIRE(n < (int64_t)1 << 32, "a shard holds at most 2^32-1 rows");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  REQUIRE(norm_mode >= 0 && norm_mode <= 2, "bad norm_mode");
+  int64_t elems;
+  int rc = strided_extent(n, d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  mi_gallery* g = new mi_gallery();
+  g->device = device;
+  g->n = n;
+  g->d = d;
+  g->norm_mode = norm_mode;
+  g->row_offset = row_offset;
+  if ((rc = gallery_alloc(g)) != MI_OK) {
+    mi_gallery_destroy(g);
+    return rc;
+  }
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  void* staged = nullptr;
+  const void* src = data;
+  auto cleanup = [&](int code) {
+    if (staged) (void)hipFree(staged);
+    mi_gallery_destroy(g);
+    return code;
+  };
+  if (memspace == MI_HOST) {
+    hipError_t e = hipMalloc(&staged, (size_t)elems * esz + 256);
+    if (e != hipSuccess) return cleanup(fail(MI_ERR_NOMEM, std::string("staging hipMalloc: ") + hipGetErrorString(e)));
+    e = hipMemcpy(staged, data, (size_t)elems * esz, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return cleanup(fail(MI_ERR_HIP, std::string("H2D copy: ") + hipGetErrorString(e)));
+    src = staged;
+  }
+  launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_bf16, g->rowstat, g->dp,
+                g->npad, g->stream);
+  launch_rowstat_max(g->rowstat, n, g->gstat3, g->stream);
+  hipError_t e = hipStreamSynchronize(g->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return cleanup(fail(MI_ERR_HIP, std::string("ingest: ") + hipGetErrorString(e)));
+  if (staged) (void)hipFree(staged);
+  *out = g;
+  return MI_OK;
+}
+
+int mi_gallery_info(const mi_gallery* g, int64_t* n, int32_t* d, int32_t* norm_mode, int32_t* device,
+                    int64_t* row_offset, int64_t* hbm_bytes) {
+  REQUIRE(g, "null handle");
+  if (n) *n = g->n;
+  if (d) *d = g->d;
+  if (norm_mode) *norm_mode = g->norm_mode;
+  if (device) *device = g->device;
+  if (row_offset) *row_offset = g->row_offset;
+  if (hbm_bytes) *hbm_bytes = g->hbm_bytes;
+  return MI_OK;
+}
+
+int mi_gallery_get_rows(const mi_gallery* g, int64_t row0, int64_t nrows, float* out_host) {
+  REQUIRE(g && out_host, "null");
+  REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= g->n, "row range out of bounds");
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipMemcpy2D(out_host, (size_t)g->d * 4, g->gal_f32 + row0 * g->dp, (size_t)g->dp * 4, (size_t)g->d * 4,
+                   (size_t)nrows, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+// ---- persistence -----------------------------------------------------------------------------------
+namespace {
+struct FileHeader {
+  char magic[8];
+  int64_t version, n, npad, row_offset;
+  int32_t d, dp, norm_mode, pad;
+};
+int copy_dev_to_file(FILE* f, const void* dev, size_t bytes) {
+  std::vector<char> buf(std::min<size_t>(bytes, (size_t)64 << 20));
+  for (size_t off = 0; off < bytes; off += buf.size()) {
+    const size_t c = std::min(buf.size(), bytes - off);
+    HIPC(hipMemcpy(buf.data(), (const char*)dev + off, c, hipMemcpyDeviceToHost));
+    if (fwrite(buf.data(), 1, c, f) != c) return fail(MI_ERR_IO, "short write");
+  }
+  return MI_OK;
+}
+int copy_file_to_dev(FILE* f, void* dev, size_t bytes) {
+  std::vector<char> buf(std::min<size_t>(bytes, (size_t)64 << 20));
+  for (size_t off = 0; off < bytes; off += buf.size()) {
+    const size_t c = std::min(buf.size(), bytes - off);
+    if (fread(buf.data(), 1, c, f) != c) return fail(MI_ERR_IO, "short read (truncated gallery file)");
+    HIPC(hipMemcpy((char*)dev + off, buf.data(), c, hipMemcpyHostToDevice));
+  }
+  return MI_OK;
+}
+}  // namespace
+
+int mi_gallery_save(const mi_gallery* g, const char* path) {
+  REQUIRE(g && path, "null");
+  HIPC(hipSetDevice(g->device));
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(MI_ERR_IO, std::string("cannot open for writing: ") + path);
+  FileHeader h{};
+  memcpy(h.magic, "MI355GAL", 8);
+  h.version = 1;
+  h.n = g->n;
+  h.npad = g->npad;
+  h.row_offset = g->row_offset;
+  h.d = g->d;
+  h.dp = g->dp;
+  h.norm_mode = g->norm_mode;
+  int rc = MI_OK;
+  if (fwrite(&h, sizeof h, 1, f) != 1) rc = fail(MI_ERR_IO, "short write");
+  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_f32, (size_t)g->n * g->dp * 4);
+  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_bf16, (size_t)g->npad * g->dp * 2);
+  if (rc == MI_OK) rc = copy_dev_to_file(f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
+  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gstat3, 12);
+  if (fclose(f) != 0 && rc == MI_OK) rc = fail(MI_ERR_IO, "close failed");
+  return rc;
+}
+
+int mi_gallery_load(const char* path, int device, mi_gallery** out) {
+  REQUIRE(path && out, "null");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(MI_ERR_IO, std::string("cannot open: ") + path);
+  FileHeader h{};
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MI355GAL", 8) != 0 || h.version != 1) {
+    fclose(f);
+    return fail(MI_ERR_IO, "not a MI355GAL v1 file");
+  }
+  mi_gallery* g = new mi_gallery();
+  g->device = device;
+  g->n = h.n;
+  g->d = h.d;
+  g->norm_mode = h.norm_mode;
+  g->row_offset = h.row_offset;
+  int rc = gallery_alloc(g);
+  if (rc == MI_OK && (g->dp != h.dp || g->npad != h.npad)) rc = fail(MI_ERR_IO, "inconsistent header");
+  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_f32, (size_t)g->n * g->dp * 4);
+  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_bf16, (size_t)g->npad * g->dp * 2);
+  if (rc == MI_OK) rc = copy_file_to_dev(f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
+  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gstat3, 12);
+  fclose(f);
+  if (rc != MI_OK) {
+    mi_gallery_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return MI_OK;
+}
+
+// ---- search ----------------------------------------------------------------------------------------
+static int read_and_clear_flags(mi_gallery* g, uint32_t* flags) {
+  HIPC(hipMemcpy(flags, g->ws.flags, 4, hipMemcpyDeviceToHost));
+  if (*flags) HIPC(hipMemset(g->ws.flags, 0, 4));
+  return MI_OK;
+}
+
+// synchronous search with overflow handling: bf16 pass, then (if buffers overflowed) the f32 pass
+static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs, int64_t cs, int q_norm, int64_t nq,
+                       int32_t k, int64_t* idx_dev, float* score_dev, double* score64_dev) {
+  hipStream_t s = g->stream;
+  int rc = check_k(g, k);
+  if (rc != MI_OK) return rc;
+  if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
+  const size_t esz = q_dtype == MI_F32 ? 4 : 8;
+  for (int64_t q0 = 0; q0 < nq; q0 += QB) {
+    const int64_t b = std::min<int64_t>(QB, nq - q0);
+    const char* src = (const char*)q_dev + (size_t)q0 * rs * esz;
+    bool exact = g->force_exact != 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if ((rc = search_device(g, src, q_dtype, rs, cs, q_norm, b, k, idx_dev + q0 * k,
+                              score_dev ? score_dev + q0 * k : nullptr,
+                              score64_dev ? score64_dev + q0 * k : nullptr, exact, s)) != MI_OK)
+        return rc;
+      HIPC(hipStreamSynchronize(s));
+      uint32_t flags = 0;
+      if ((rc = read_and_clear_flags(g, &flags)) != MI_OK) return rc;
+      if (!flags) break;
+      g->stats.overflow_batches += 1;
+      if (exact || !g->exact_fallback)
+        return fail(MI_ERR_OVERFLOW,
+                    "candidate buffers overflowed (more than survivor_cap / rescore_cap rows within the error margin "
+                    "of the K-th score); raise the caps with mi_set_option");
+      exact = true;
+    }
+  }
+  return MI_OK;
+}
+
+int mi_knn_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                  int32_t k, int64_t* out_idx, float* out_score, double* out_seconds) {
+  REQUIRE(g && q && out_idx, "null pointer");
+  REQUIRE(nq >= 1, "no queries");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int64_t elems;
+  int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  void* qd = nullptr;
+  int64_t* idx_d = nullptr;
+  float* sc_d = nullptr;
+  HIPC(hipMalloc(&qd, (size_t)elems * esz + 256));
+  auto done = [&](int code) {
+    (void)hipFree(qd);
+    (void)hipFree(idx_d);
+    (void)hipFree(sc_d);
+    return code;
+  };
+  if (hipMalloc((void**)&idx_d, (size_t)nq * k * 8) != hipSuccess || hipMalloc((void**)&sc_d, (size_t)nq * k * 4) != hipSuccess)
+    return done(fail(MI_ERR_NOMEM, "output buffers"));
+  if (hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "H2D query copy failed"));
+  rc = search_sync(g, qd, dtype, row_stride, col_stride, g->norm_mode, nq, k, idx_d, sc_d, nullptr);
+  if (rc != MI_OK) return done(rc);
+  if (hipMemcpy(out_idx, idx_d, (size_t)nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "D2H idx copy failed"));
+  if (out_score && hipMemcpy(out_score, sc_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "D2H score copy failed"));
+  if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return done(MI_OK);
+}
+
+int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t k, int64_t* out_idx_dev,
+                         float* out_score_dev, double* out_score64_dev, void* stream) {
+  REQUIRE(g && q_dev && out_idx_dev, "null pointer");
+  REQUIRE(nq >= 1, "no queries");
+  HIPC(hipSetDevice(g->device));
+  return search_device(g, q_dev, MI_F32, g->d, 1, g->norm_mode, nq, k, out_idx_dev, out_score_dev, out_score64_dev,
+                       g->force_exact != 0, (hipStream_t)stream);
+}
+
+int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t k, float* out_approx_dev,
+                         void* stream) {
+  REQUIRE(g && q_dev && out_approx_dev, "null pointer");
+  REQUIRE(nq >= 1 && nq <= QB, "phase API handles one batch of at most 1024 queries");
+  HIPC(hipSetDevice(g->device));
+  REQUIRE(k >= 1, "k must be >= 1");
+  // a shard may hold fewer than k rows: clamp the local k, pad the tail with -inf
+  const int32_t kl = (int32_t)std::min<int64_t>(k, g->n);
+  int rc = check_k(g, kl);
+  if (rc != MI_OK) return rc;
+  if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = phase1_batch(g, q_dev, MI_F32, g->d, 1, g->norm_mode, (int32_t)nq, kl, g->force_exact != 0, s)) != MI_OK)
+    return rc;
+  if (kl == k) {
+    HIPC(hipMemcpyAsync(out_approx_dev, g->ws.topvals, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    std::vector<float> ninf((size_t)nq * k, -INFINITY);
+    HIPC(hipMemcpyAsync(out_approx_dev, ninf.data(), ninf.size() * 4, hipMemcpyHostToDevice, s));
+    HIPC(hipStreamSynchronize(s));
+    HIPC(hipMemcpy2DAsync(out_approx_dev, (size_t)k * 4, g->ws.topvals, (size_t)kl * 4, (size_t)kl * 4, (size_t)nq,
+                          hipMemcpyDeviceToDevice, s));
+  }
+  g->stats.searches += 1;
+  g->stats.queries += nq;
+  return MI_OK;
+}
+
+int mi_kth_of_gathered_device(const float* gathered_dev, int32_t nshards, int64_t nq, int32_t k, float* out_L_dev,
+                              void* stream) {
+  REQUIRE(gathered_dev && out_L_dev, "null pointer");
+  REQUIRE(nshards >= 1 && (int64_t)nshards * k <= 16384, "nshards * k too large");
+  launch_kth_of_gathered(gathered_dev, nshards, nq, k, out_L_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_knn_phase2_device(mi_gallery* g, int64_t nq, int32_t k, const float* L_dev, int64_t* out_idx_dev,
+                         float* out_score_dev, double* out_score64_dev, void* stream) {
+  REQUIRE(g && L_dev && out_idx_dev, "null pointer");
+  REQUIRE(nq >= 1 && nq <= QB, "phase API handles one batch of at most 1024 queries");
+  REQUIRE(g->ws.qcap > 0, "phase 2 without phase 1");
+  HIPC(hipSetDevice(g->device));
+  return phase2_batch(g, (int32_t)nq, k, L_dev, out_idx_dev, out_score_dev, out_score64_dev, (hipStream_t)stream);
+}
+
+int mi_topk_merge_device(const double* score64_dev, const int64_t* idx_dev, int32_t nshards, int64_t nq, int32_t k,
+                         int64_t* out_idx_dev, float* out_score_dev, void* stream) {
+  REQUIRE(score64_dev && idx_dev && out_idx_dev, "null pointer");
+  REQUIRE(nshards >= 1 && (int64_t)nshards * k <= 8192, "nshards * k too large");
+  launch_merge(score64_dev, idx_dev, nshards, nq, k, out_idx_dev, out_score_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+// ---- alpha query expansion ---------------------------------------------------------------------------
+int mi_aqe_partial_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_stride_j, int64_t rank_stride_q,
+                          int64_t nq, int32_t k_qe, double w, double* out_sum_dev, void* stream) {
+  REQUIRE(g && ranks_dev && out_sum_dev, "null pointer");
+  REQUIRE(nq >= 1 && k_qe >= 1, "bad sizes");
+  HIPC(hipSetDevice(g->device));
+  launch_aqe_partial(g->gal_f32, g->dp, g->d, g->n, g->row_offset, ranks_dev, rank_stride_j, rank_stride_q, nq, k_qe,
+                     w, out_sum_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_aqe_finish_device(const double* sum_dev, int64_t nq, int32_t d, double eps, float* out_q_dev,
+                         double* out_q64_dev, void* stream) {
+  REQUIRE(sum_dev && out_q_dev, "null pointer");
+  launch_aqe_finish(sum_dev, nq, d, eps, out_q_dev, out_q64_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, int64_t rank_stride_q, int64_t nq,
+                  int32_t k_qe, double w, double eps, int32_t k, int64_t* out_idx, float* out_score, double* out_qexp,
+                  double* out_seconds) {
+  REQUIRE(g && ranks && out_idx, "null pointer");
+  REQUIRE(nq >= 1 && k_qe >= 1, "bad sizes");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int64_t elems;
+  int rc = strided_extent(k_qe, nq, rank_stride_j, rank_stride_q, &elems);
+  if (rc != MI_OK) return rc;
+  std::vector<void*> tmp;
+  auto alloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes + 256) != hipSuccess) return nullptr;
+    tmp.push_back(p);
+    return p;
+  };
+  auto done = [&](int code) {
+    for (void* p : tmp) (void)hipFree(p);
+    return code;
+  };
+  int64_t* ranks_d = (int64_t*)alloc((size_t)elems * 8);
+  double* sum_d = (double*)alloc((size_t)nq * g->d * 8);
+  double* q64_d = (double*)alloc((size_t)nq * g->d * 8);
+  float* q_d = (float*)alloc((size_t)nq * g->d * 4);
+  int64_t* idx_d = (int64_t*)alloc((size_t)nq * k * 8);
+  float* sc_d = (float*)alloc((size_t)nq * k * 4);
+  if (!ranks_d || !sum_d || !q64_d || !q_d || !idx_d || !sc_d) return done(fail(MI_ERR_NOMEM, "aqe buffers"));
+  // validate the row ids on the host: an out-of-range id must not become a wild gather
+  for (int64_t j = 0; j < k_qe; ++j)
+    for (int64_t q = 0; q < nq; ++q) {
+      const int64_t v = ranks[j * rank_stride_j + q * rank_stride_q] - g->row_offset;
+      if (v < 0 || v >= g->n) return done(fail(MI_ERR_INVALID, "rank id outside the gallery"));
+    }
+  if (hipMemcpy(ranks_d, ranks, (size_t)elems * 8, hipMemcpyHostToDevice) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "H2D ranks copy failed"));
+  hipStream_t s = g->stream;
+  launch_aqe_partial(g->gal_f32, g->dp, g->d, g->n, g->row_offset, ranks_d, rank_stride_j, rank_stride_q, nq, k_qe, w,
+                     sum_d, s);
+  launch_aqe_finish(sum_d, nq, g->d, eps, q_d, q64_d, s);
+  // the expanded query is used as is (no second normalisation), like `np.dot(vecs.T, qvecs_qe)`
+  rc = search_sync(g, q_d, MI_F32, g->d, 1, MI_NORM_NONE, nq, k, idx_d, sc_d, nullptr);
+  if (rc != MI_OK) return done(rc);
+  if (hipMemcpy(out_idx, idx_d, (size_t)nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "D2H idx copy failed"));
+  if (out_score && hipMemcpy(out_score, sc_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "D2H score copy failed"));
+  if (out_qexp && hipMemcpy(out_qexp, q64_d, (size_t)nq * g->d * 8, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(fail(MI_ERR_HIP, "D2H qexp copy failed"));
+  if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return done(MI_OK);
+}
+
+// ---- status / options ------------------------------------------------------------------------------
+int mi_profile_enable(mi_gallery* g, int on) {
+  REQUIRE(g, "null handle");
+  g->profile = on != 0;
+  return MI_OK;
+}
+
+int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
+  REQUIRE(g, "null handle");
+  HIPC(hipSetDevice(g->device));
+  if (g->ev_stream) HIPC(hipStreamSynchronize(g->ev_stream));
+  HIPC(hipStreamSynchronize(g->stream));
+  HIPC(hipDeviceSynchronize());
+  prof_collect(g);
+  if (g->ws.qcap) {
+    uint64_t s2[2] = {0, 0};
+    HIPC(hipMemcpy(s2, g->ws.stats2, 16, hipMemcpyDeviceToHost));
+    g->stats.survivors += (int64_t)s2[0];
+    g->stats.candidates += (int64_t)s2[1];
+    HIPC(hipMemset(g->ws.stats2, 0, 16));
+    uint32_t flags = 0;
+    HIPC(hipMemcpy(&flags, g->ws.flags, 4, hipMemcpyDeviceToHost));
+    if (flags) {
+      g->stats.overflow_batches += 1;   // sticky: a device-API batch overflowed since the last status call
+      if (reset) HIPC(hipMemset(g->ws.flags, 0, 4));
+    }
+  }
+  if (out) *out = g->stats;
+  if (reset) g->stats = mi_search_stats{};
+  return MI_OK;
+}
+
+int mi_set_option(mi_gallery* g, const char* name, double value) {
+  REQUIRE(g && name, "null");
+  const std::string n(name);
+  if (n == "chunk0_tiles") { REQUIRE(value >= 1, "chunk0_tiles >= 1"); g->chunk0_tiles = (int)value; }
+  else if (n == "chunk_growth") { REQUIRE(value >= 1, "chunk_growth >= 1"); g->chunk_growth = (int)value; }
+  else if (n == "survivor_cap") {
+    const uint32_t v = (uint32_t)value;
+    REQUIRE(v >= 1024 && v <= 12288 && (v % 256) == 0, "survivor_cap: multiple of 256 in [1024, 12288]");
+    g->surv_cap = v;
+  } else if (n == "rescore_cap") {
+    const uint32_t v = (uint32_t)value;
+    REQUIRE(v >= 64 && v <= 8192 && (v & (v - 1)) == 0, "rescore_cap: power of two in [64, 8192]");
+    g->rescore_cap = v;
+  } else if (n == "exact_fallback") g->exact_fallback = value != 0;
+  else if (n == "force_exact") g->force_exact = value != 0;
+  else return fail(MI_ERR_INVALID, "unknown option: " + n);
+  return MI_OK;
+}
+
+int mi_synth_fill_device(float* dst_dev, uint64_t seed, int64_t row0, int64_t nrows, int32_t d, void* stream) {
+  REQUIRE(dst_dev, "null pointer");
+  launch_synth_fill(dst_dev, seed, row0, nrows, d, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// alpha query expansion (feature_enhancement, src/utils/Reranking.py:195-208 / :288-301):
+//   q'[d] = sum_{j<k} ((k-j)/k)^w * G[ranks[j,q]][d] ;  q' /= (||q'||_2 + eps)
+// The reference's f64 weight array promotes the sum to f64; here the gathered f32 rows are accumulated
+// in f64 as well.  `partial` adds only the rows this shard owns (the sum is all-reduced across shards by
+// the host); `finish` normalises.  HBM-bound gather of k rows per query (k = 3 or 10).
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+__global__ __launch_bounds__(256) void aqe_partial_kernel(const float* __restrict__ gal, int32_t dp, int32_t d,
+                                                          int64_t n, int64_t row_offset,
+                                                          const int64_t* __restrict__ ranks, int64_t sj, int64_t sq,
+                                                          int32_t k_qe, double w, double* __restrict__ out_sum) {
+  const int64_t q = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < k_qe; ++j) {
+      const int64_t gid = ranks[j * sj + q * sq] - row_offset;
+      if (gid < 0 || gid >= n) continue;
+      const double wt = pow((double)(k_qe - j) / (double)k_qe, w);
+      acc += (double)gal[gid * dp + c] * wt;
+    }
+    out_sum[q * d + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void aqe_finish_kernel(const double* __restrict__ sum, int32_t d, double eps,
+                                                         float* __restrict__ out_q, double* __restrict__ out_q64) {
+  __shared__ double red[4];
+  const int64_t q = blockIdx.x;
+  double ss = 0.0;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    const double v = sum[q * d + c];
+    ss += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+  const double inv = 1.0 / (nrm + eps);
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    const double v = sum[q * d + c] * inv;
+    out_q[q * d + c] = (float)v;
+    if (out_q64) out_q64[q * d + c] = v;
+  }
+}
+
+void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,
+                        const int64_t* ranks, int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, double w,
+                        double* out_sum, hipStream_t stream) {
+  hipLaunchKernelGGL(aqe_partial_kernel, dim3((unsigned)nq), dim3(256), 0, stream, gal_f32, dp, d, n, row_offset,
+                     ranks, sj, sq, k_qe, w, out_sum);
+}
+
+void launch_aqe_finish(const double* sum, int64_t nq, int32_t d, double eps, float* out_q, double* out_q64,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(aqe_finish_kernel, dim3((unsigned)nq), dim3(256), 0, stream, sum, d, eps, out_q, out_q64);
+}
+
+}  // namespace mi

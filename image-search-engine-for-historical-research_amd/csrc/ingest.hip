@@ -1,0 +1,160 @@
+// Gallery / query ingest for gfx950: strided f32|f64 input -> (a) normalised f32 rows [n][dp],
+// (b) tile-blocked, chunk-swizzled bf16 image [npad/256][dp/64][256][64], (c) per-row rounding stats.
+//
+// Restates the normalisation of matching_L2 (src/utils/nnsearch.py:693-698, no eps), of l2n
+// (src/layers/functional.py:129-130, eps 1e-6) and the tail of whitenapply (src/utils/whiten.py:10);
+// the reference redoes it on every call, here it is done once per gallery (HBM-bound, one-off).
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+template <typename InT>
+__global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
+                                                     int64_t rs, int64_t cs, int norm_mode,
+                                                     float* __restrict__ out_f32,
+                                                     __hip_bfloat16* __restrict__ out_bf16,
+                                                     RowStat* __restrict__ rowstat, int32_t dp,
+                                                     int64_t npad) {
+  __shared__ double tile[64][65];
+  const int t = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const bool row_contig = (rs == 1 && cs != 1);
+  const int ksteps = dp / BK;
+  // compute-phase mapping: thread -> (row ci, 16 columns starting at cj)
+  const int ci = t >> 2, cj = (t & 3) * 16;
+  const int64_t crow = row0 + ci;
+
+  auto load_tile = [&](int col0) {
+    // load-phase mapping follows the contiguous axis of the input
+    if (row_contig) {
+      const int j = t >> 2, i0 = (t & 3) * 16;
+      const int64_t col = col0 + j;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + i0 + e;
+        double v = 0.0;
+        if (row < n && col < d) v = (double)src[row * rs + col * cs];
+        tile[i0 + e][j] = v;
+      }
+    } else {
+      const int i = t >> 2, j0 = (t & 3) * 16;
+      const int64_t row = row0 + i;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t col = col0 + j0 + e;
+        double v = 0.0;
+        if (row < n && col < d) v = (double)src[row * rs + col * cs];
+        tile[i][j0 + e] = v;
+      }
+    }
+  };
+
+  double scale = 1.0;
+  if (norm_mode != 0) {
+    double ss = 0.0;
+    for (int col0 = 0; col0 < dp; col0 += 64) {
+      load_tile(col0);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const double v = tile[ci][cj + e];
+        ss += v * v;
+      }
+      __syncthreads();
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const double nrm = sqrt(ss);
+    scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);   // norm 0 -> inf -> NaN row, like the reference
+  }
+
+  double s_g = 0.0, s_b = 0.0, s_d = 0.0;
+  for (int col0 = 0; col0 < dp; col0 += 64) {
+    load_tile(col0);
+    __syncthreads();
+    float vf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) vf[e] = (float)(tile[ci][cj + e] * scale);
+    if (crow < npad) {
+      const int ks = col0 / BK;
+      const int64_t tileidx = crow / TILE;
+      const uint32_t r = (uint32_t)(crow % TILE);
+      __hip_bfloat16* blk = out_bf16 + (tileidx * ksteps + ks) * (int64_t)BLOCK_ELEMS + (int64_t)r * BK;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t c = (uint32_t)(cj >> 3) + half;
+        union { __hip_bfloat16 h[8]; uint4 u; } pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (crow < n) ? vf[half * 8 + e] : 0.0f;
+          pk.h[e] = __float2bfloat16(v);
+          const double vb = (double)__bfloat162float(pk.h[e]);
+          s_b += vb * vb;
+          s_d += (vb - (double)v) * (vb - (double)v);
+          s_g += (double)v * (double)v;
+        }
+        *reinterpret_cast<uint4*>(blk + (swz_chunk(r, c) << 3)) = pk.u;
+      }
+      if (crow < n) {
+        float4* o = reinterpret_cast<float4*>(out_f32 + crow * dp + col0 + cj);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = make_float4(vf[4 * e], vf[4 * e + 1], vf[4 * e + 2], vf[4 * e + 3]);
+      }
+    }
+    __syncthreads();
+  }
+  s_g += __shfl_xor(s_g, 1); s_g += __shfl_xor(s_g, 2);
+  s_b += __shfl_xor(s_b, 1); s_b += __shfl_xor(s_b, 2);
+  s_d += __shfl_xor(s_d, 1); s_d += __shfl_xor(s_d, 2);
+  if ((t & 3) == 0 && crow < npad) {
+    RowStat rsd;
+    // round the norms UP a little so that they stay upper bounds after the f32 conversion
+    rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
+    rsd.norm_bf16 = (float)(sqrt(s_b) * (1.0 + 1e-6));
+    rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
+    rowstat[crow] = rsd;
+  }
+}
+
+// max over valid rows of the three norms (non-finite rows -- zero-norm rows normalised to NaN -- skipped)
+__global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restrict__ rowstat, int64_t n,
+                                                          float* __restrict__ out3) {
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const RowStat r = rowstat[i];
+    if (isfinite(r.norm_f32) && isfinite(r.norm_bf16) && isfinite(r.norm_diff)) {
+      m0 = fmaxf(m0, r.norm_f32); m1 = fmaxf(m1, r.norm_bf16); m2 = fmaxf(m2, r.norm_diff);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); m2 = fmaxf(m2, __shfl_xor(m2, o));
+  }
+  if ((threadIdx.x & 63) == 0) {   // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(out3 + 0), __float_as_uint(m0));
+    atomicMax(reinterpret_cast<unsigned int*>(out3 + 1), __float_as_uint(m1));
+    atomicMax(reinterpret_cast<unsigned int*>(out3 + 2), __float_as_uint(m2));
+  }
+}
+
+void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
+                   float* out_f32, void* out_bf16, RowStat* rowstat, int32_t dp, int64_t npad,
+                   hipStream_t stream) {
+  const int64_t blocks = (npad + 63) / 64;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ingest_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, n, d,
+                       rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+  else
+    hipLaunchKernelGGL(ingest_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)src, n,
+                       d, rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+}
+
+void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream) {
+  hipMemsetAsync(out3, 0, 3 * sizeof(float), stream);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(rowstat_max_kernel, dim3(blocks), dim3(256), 0, stream, rowstat, n, out3);
+}
+
+}  // namespace mi

@@ -1,0 +1,67 @@
+// Host-callable launchers of the gfx950 kernels (internal).
+#pragma once
+#include "common.h"
+
+namespace mi {
+
+// ingest.hip
+void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
+                   float* out_f32, void* out_bf16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream);
+void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream);
+
+// gemm_select.hip -- bf16 MFMA scoring of gallery tiles [tile0, tile0+ntiles) against nqt query tiles with the
+// fused survivor filter.  first != 0: store every score of the chunk (rows tile0*256.. at position row).
+struct ScoreArgs {
+  const void* gal_bf16;   // blocked image of the shard
+  const void* qry_bf16;   // blocked image of the query batch
+  int32_t ksteps;         // dp / 64
+  int32_t tile0, ntiles;  // gallery tiles of this launch
+  int32_t nqt;            // query tiles (qpad / 256)
+  int64_t n;              // valid gallery rows in the shard
+  int32_t nq;             // valid queries
+  QueryState st;
+};
+void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
+
+// exact_score.hip -- f32 FMA scoring with the same filter (fallback / force_exact)
+struct ExactArgs {
+  const float* gal_f32;   // [n][dp]
+  const float* qry_f32;   // [qpad][dp]
+  int32_t dp;
+  int64_t row0, row1;     // gallery rows of this launch
+  int64_t n;
+  int32_t nq;
+  QueryState st;
+};
+void launch_exact_select(const ExactArgs& a, bool first, hipStream_t stream);
+
+// select.hip
+void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t nq, int32_t qpad, float gamma,
+                             int use_bf16_terms, uint32_t first_cnt, QueryState st, hipStream_t stream);
+// mode 0: maintain (threshold <- K-th largest - margin, compact survivors)
+// mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
+void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
+                            uint64_t* stats2, hipStream_t stream);
+void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_t* cand_rows, uint32_t* cand_cnt,
+                              uint32_t rcap, uint64_t* stats2, hipStream_t stream);
+void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
+                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream);
+void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
+                 int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score,
+                 double* out_score64, hipStream_t stream);
+void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, int32_t k, float* out_L,
+                            hipStream_t stream);
+void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k,
+                  int64_t* out_idx, float* out_score, hipStream_t stream);
+
+// aqe.hip
+void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,
+                        const int64_t* ranks, int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, double w,
+                        double* out_sum, hipStream_t stream);
+void launch_aqe_finish(const double* sum, int64_t nq, int32_t d, double eps, float* out_q, double* out_q64,
+                       hipStream_t stream);
+
+// synth.hip
+void launch_synth_fill(float* dst, uint64_t seed, int64_t row0, int64_t nrows, int32_t d, hipStream_t stream);
+
+}  // namespace mi

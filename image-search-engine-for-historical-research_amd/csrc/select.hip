@@ -1,0 +1,393 @@
+// Per-query selection kernels around the scoring pass (gfx950): threshold maintenance by radix select,
+// candidate extraction with the rigorous error margin, exact f64 re-score, final bitonic sort, and the
+// multi-shard merge.  Together they replace the `np.argsort(dist)[:K]` of matching_L2
+// (src/utils/nnsearch.py:703) and `np.argsort(-scores, axis=0)` of src/utils/Reranking.py:207 for the
+// top-K the callers actually consume (src/online.py:152, src/test_rOP1m.py:157-159).
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+// ------------------------------------------------------------------------------------------------
+// block-wide K-th largest key among keys[0..n) held in LDS (MSB-first 8-bit radix select).
+// hist: 256 uint32 of LDS scratch; sh: 2 uint32 of LDS scratch.  All threads must call; returns the key.
+// Requires 1 <= K <= n and blockDim.x >= 256.
+__device__ uint32_t block_kth_largest(const uint32_t* keys, uint32_t n, uint32_t K, uint32_t* hist, uint32_t* sh) {
+  uint32_t prefix = 0, mask = 0, remaining = K;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t k = keys[i];
+      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // suffix sums over bins 255..0 by the first wave: lane l owns bins 4l..4l+3
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+      const uint32_t tot = h0 + h1 + h2 + h3;
+      uint32_t suf = tot;   // inclusive suffix over lanes >= l
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(suf, o);
+        if (l + o < 64) suf += v;
+      }
+      const uint32_t above = suf - tot;   // keys in bins of higher lanes
+      // bins 4l+3 .. 4l in descending order
+      uint32_t c = above;
+      const uint32_t hs[4] = {h3, h2, h1, h0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c < remaining && c + hs[e] >= remaining) {
+          sh[0] = (uint32_t)(4 * l + 3 - e);
+          sh[1] = remaining - c;
+        }
+        c += hs[e];
+      }
+    }
+    __syncthreads();
+    prefix |= sh[0] << shift;
+    mask |= 255u << shift;
+    remaining = sh[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const float* __restrict__ gstat3,
+                                        int32_t nq, int32_t qpad, float gamma, int use_bf16_terms,
+                                        uint32_t first_cnt, QueryState st) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0) st.flags[0] = 0;
+  if (q >= qpad) return;
+  if (q < nq) {
+    const RowStat r = qstat[q];
+    const float g_f32 = gstat3[0], g_bf = gstat3[1], g_diff = gstat3[2];
+    // |approx - exact| <= gamma*|q^||g^| + |q^||g^ - g| + |q^ - q||g|   (Cauchy-Schwarz)
+    float eps;
+    if (use_bf16_terms)
+      eps = gamma * r.norm_bf16 * g_bf + r.norm_bf16 * g_diff + r.norm_diff * g_f32;
+    else
+      eps = gamma * r.norm_f32 * g_f32;
+    float margin = 2.0f * eps * 1.001f + 1e-30f;
+    if (!(margin == margin)) margin = 0.f;   // NaN query (zero-norm): nothing will match anyway
+    st.thr[q] = -INFINITY;
+    st.margin[q] = margin;
+    st.cnt[q] = first_cnt;
+  } else {
+    st.thr[q] = INFINITY;
+    st.margin[q] = 0.f;
+    st.cnt[q] = 0;
+  }
+}
+
+void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t nq, int32_t qpad, float gamma,
+                             int use_bf16_terms, uint32_t first_cnt, QueryState st, hipStream_t stream) {
+  hipLaunchKernelGGL(init_query_state_kernel, dim3((qpad + 255) / 256), dim3(256), 0, stream, qstat, gstat3, nq,
+                     qpad, gamma, use_bf16_terms, first_cnt, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// maintain: L = K-th largest approximate score among the survivors so far (a lower bound of the final
+// K-th largest); threshold <- L - margin; survivors below the new threshold are dropped.
+// LDS: entries[cap] (u64) | hist[256] | sh[4] | counter
+template <int MODE>
+__global__ __launch_bounds__(512) void select_maintain_kernel(QueryState st, int32_t k, float* __restrict__ topvals,
+                                                              float* __restrict__ l_local,
+                                                              uint64_t* __restrict__ stats2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t q = blockIdx.x;
+  const uint32_t cap = st.cap;
+  uint64_t* ent = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
+  uint32_t* hist = keys + cap;
+  uint32_t* sh = hist + 256;
+  const uint32_t n = min(st.cnt[q], cap);
+  uint64_t* gsurv = st.surv + (uint64_t)q * cap;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t e = gsurv[i];
+    ent[i] = e;
+    keys[i] = f2key(entry_score(e));
+  }
+  if (threadIdx.x == 0) sh[2] = 0;
+  __syncthreads();
+  float L = -INFINITY;
+  uint32_t keyL = 0;
+  if (n >= (uint32_t)k) {
+    keyL = block_kth_largest(keys, n, (uint32_t)k, hist, sh);
+    L = key2f(keyL);
+  }
+  const float thr_new = L - st.margin[q];
+  // compaction (order is irrelevant)
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t e = ent[i];
+    if (entry_score(e) >= thr_new) {
+      const uint32_t pos = atomicAdd(&sh[2], 1u);
+      gsurv[pos] = e;
+    }
+  }
+  if (MODE == 1) {
+    // the K largest approximate values (unsorted): everything above L plus copies of L for the ties
+    if (threadIdx.x == 0) sh[3] = 0;
+    __syncthreads();
+    float* tv = topvals + (uint64_t)q * k;
+    if (n >= (uint32_t)k) {
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (keys[i] > keyL) tv[atomicAdd(&sh[3], 1u)] = entry_score(ent[i]);
+      __syncthreads();
+      for (uint32_t i = sh[3] + threadIdx.x; i < (uint32_t)k; i += blockDim.x) tv[i] = L;
+    } else {
+      for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) tv[i] = (i < n) ? entry_score(ent[i]) : -INFINITY;
+    }
+    if (threadIdx.x == 0) l_local[q] = L;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.thr[q] = thr_new;
+    st.cnt[q] = sh[2];
+    if (MODE == 1 && stats2) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)sh[2]);
+  }
+}
+
+void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
+                            uint64_t* stats2, hipStream_t stream) {
+  const size_t lds = (size_t)st.cap * 12 + 256 * 4 + 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)select_maintain_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)select_maintain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (mode == 0)
+    hipLaunchKernelGGL(select_maintain_kernel<0>, dim3(nq), dim3(512), lds, stream, st, k, topvals, l_local, stats2);
+  else
+    hipLaunchKernelGGL(select_maintain_kernel<1>, dim3(nq), dim3(512), lds, stream, st, k, topvals, l_local, stats2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidates: every surviving row whose approximate score is >= L - margin may belong to the exact
+// top-K (DESIGN.md "Exactness certificate"); rows below cannot.
+__global__ __launch_bounds__(256) void select_candidates_kernel(QueryState st, const float* __restrict__ L,
+                                                                uint32_t* __restrict__ cand_rows,
+                                                                uint32_t* __restrict__ cand_cnt, uint32_t rcap,
+                                                                uint64_t* __restrict__ stats2) {
+  __shared__ uint32_t counter;
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = min(st.cnt[q], st.cap);
+  if (st.cnt[q] > st.cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+  if (threadIdx.x == 0) counter = 0;
+  __syncthreads();
+  const float lim = L[q] - st.margin[q];
+  const uint64_t* gsurv = st.surv + (uint64_t)q * st.cap;
+  uint32_t* out = cand_rows + (uint64_t)q * rcap;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t e = gsurv[i];
+    if (entry_score(e) >= lim) {
+      const uint32_t pos = atomicAdd(&counter, 1u);
+      if (pos < rcap) out[pos] = entry_row(e);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (counter > rcap) atomicOr(st.flags, FLAG_CAND_OVERFLOW);
+    cand_cnt[q] = min(counter, rcap);
+    if (stats2) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[1]), (unsigned long long)min(counter, rcap));
+  }
+}
+
+void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_t* cand_rows, uint32_t* cand_cnt,
+                              uint32_t rcap, uint64_t* stats2, hipStream_t stream) {
+  hipLaunchKernelGGL(select_candidates_kernel, dim3(nq), dim3(256), 0, stream, st, L, cand_rows, cand_cnt, rcap, stats2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact re-score: s = sum_k g[k] * q[k] with f32 inputs, exact f64 products and f64 accumulation
+// (HBM-bound gather of 4*dp bytes per candidate row).  One wave per row, two rows in flight.
+constexpr int RESCORE_ROWS_PER_WG = 32;
+
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
+                                                      int32_t dp, const uint32_t* __restrict__ cand_rows,
+                                                      const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
+                                                      double* __restrict__ cand_score) {
+  const uint32_t q = blockIdx.y;
+  const uint32_t c0 = blockIdx.x * RESCORE_ROWS_PER_WG;
+  const uint32_t nc = cand_cnt[q];
+  if (c0 >= nc) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float4* qv = reinterpret_cast<const float4*>(qry + (uint64_t)q * dp);
+  const int nvec = dp >> 2;            // float4 per row (dp is a multiple of 64 -> nvec multiple of 16)
+  const uint32_t* rows = cand_rows + (uint64_t)q * rcap;
+  double* outs = cand_score + (uint64_t)q * rcap;
+  for (uint32_t c = c0 + w * 2; c < min(nc, c0 + RESCORE_ROWS_PER_WG); c += 8) {
+    const bool two = (c + 1 < nc);
+    const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
+    const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
+    double a0 = 0.0, a1 = 0.0;
+    for (int v = lane; v < nvec; v += 64) {
+      const float4 x = qv[v];
+      const float4 y0 = g0[v];
+      const float4 y1 = g1[v];
+      a0 += (double)x.x * (double)y0.x; a0 += (double)x.y * (double)y0.y;
+      a0 += (double)x.z * (double)y0.z; a0 += (double)x.w * (double)y0.w;
+      a1 += (double)x.x * (double)y1.x; a1 += (double)x.y * (double)y1.y;
+      a1 += (double)x.z * (double)y1.z; a1 += (double)x.w * (double)y1.w;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      a0 += __shfl_xor(a0, o);
+      a1 += __shfl_xor(a1, o);
+    }
+    if (lane == 0) {
+      outs[c] = a0;
+      if (two) outs[c + 1] = a1;
+    }
+  }
+}
+
+void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
+                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
+  dim3 grid((rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG, nq);
+  hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, stream, gal_f32, qry_f32, dp, cand_rows, cand_cnt, rcap,
+                     cand_score);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bitonic sort of (score64 desc, id asc) pairs in LDS; n2 = power of two >= count
+template <typename IdT>
+__device__ void bitonic_sort_desc(double* s, IdT* id, uint32_t n2) {
+  for (uint32_t size = 2; size <= n2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+        const uint32_t lo = 2 * t - (t & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const double a = s[lo], b = s[hi];
+        const IdT ia = id[lo], ib = id[hi];
+        // "a before b" in the final order: higher score first, NaN last, ties to the lower id
+        const bool a_nan = (a != a), b_nan = (b != b);
+        bool a_first;
+        if (a_nan || b_nan) a_first = (!a_nan) || (b_nan && ia < ib);
+        else a_first = (a > b) || (a == b && ia < ib);
+        if (a_first != desc) {
+          s[lo] = b; s[hi] = a;
+          id[lo] = ib; id[hi] = ia;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ cand_rows,
+                                                   const uint32_t* __restrict__ cand_cnt,
+                                                   const double* __restrict__ cand_score, uint32_t rcap, int32_t k,
+                                                   int64_t row_offset, int64_t* __restrict__ out_idx,
+                                                   float* __restrict__ out_score, double* __restrict__ out_score64) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t q = blockIdx.x;
+  const uint32_t nc = min(cand_cnt[q], rcap);
+  uint32_t n2 = 1;
+  while (n2 < nc) n2 <<= 1;
+  if (n2 < 2) n2 = 2;
+  double* s = reinterpret_cast<double*>(smem);
+  uint32_t* id = reinterpret_cast<uint32_t*>(smem + (size_t)rcap * 8);
+  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
+    if (i < nc) {
+      s[i] = cand_score[(uint64_t)q * rcap + i];
+      id[i] = cand_rows[(uint64_t)q * rcap + i];
+    } else {
+      s[i] = -INFINITY;
+      id[i] = 0xFFFFFFFFu;
+    }
+  }
+  bitonic_sort_desc<uint32_t>(s, id, n2);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
+    const bool ok = (i < nc);
+    out_idx[(uint64_t)q * k + i] = ok ? row_offset + (int64_t)id[i] : -1;
+    if (out_score) out_score[(uint64_t)q * k + i] = ok ? (float)s[i] : -INFINITY;
+    if (out_score64) out_score64[(uint64_t)q * k + i] = ok ? s[i] : -INFINITY;
+  }
+}
+
+void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
+                 int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64,
+                 hipStream_t stream) {
+  // rcap is a power of two (enforced by the host), LDS = rcap * 12
+  hipLaunchKernelGGL(emit_kernel, dim3(nq), dim3(256), (size_t)rcap * 12, stream, cand_rows, cand_cnt, cand_score,
+                     rcap, k, row_offset, out_idx, out_score, out_score64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-th largest of the gathered per-shard top-K approximate values (the global top-K is contained in the
+// union of the shards' top-K, so this is the exact K-th largest approximate score of the whole gallery).
+__global__ __launch_bounds__(256) void kth_of_gathered_kernel(const float* __restrict__ gathered, int32_t nshards,
+                                                              int64_t nq, int32_t k, float* __restrict__ out_L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = (uint32_t)nshards * (uint32_t)k;
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* hist = keys + n;
+  uint32_t* sh = hist + 256;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t s = i / k, e = i % k;
+    keys[i] = f2key(gathered[((uint64_t)s * nq + q) * k + e]);
+  }
+  __syncthreads();
+  const uint32_t key = block_kth_largest(keys, n, (uint32_t)k, hist, sh);
+  if (threadIdx.x == 0) out_L[q] = key2f(key);
+}
+
+void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, int32_t k, float* out_L,
+                            hipStream_t stream) {
+  const size_t lds = (size_t)nshards * k * 4 + 256 * 4 + 16;
+  hipLaunchKernelGGL(kth_of_gathered_kernel, dim3((unsigned)nq), dim3(256), lds, stream, gathered, nshards, nq, k,
+                     out_L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of the shards' exact top-K lists by (score64 desc, idx asc); padded entries carry idx -1 / -inf.
+__global__ __launch_bounds__(256) void merge_kernel(const double* __restrict__ score64, const int64_t* __restrict__ idx,
+                                                    int32_t nshards, int64_t nq, int32_t k,
+                                                    int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = (uint32_t)nshards * (uint32_t)k;
+  uint32_t n2 = 2;
+  while (n2 < n) n2 <<= 1;
+  double* s = reinterpret_cast<double*>(smem);
+  unsigned long long* id = reinterpret_cast<unsigned long long*>(smem + (size_t)n2 * 8);
+  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
+    if (i < n) {
+      const uint32_t sh = i / k, e = i % k;
+      const uint64_t src = ((uint64_t)sh * nq + q) * k + e;
+      const int64_t v = idx[src];
+      s[i] = (v < 0) ? -INFINITY : score64[src];
+      id[i] = (unsigned long long)v;          // -1 -> max, sorts last among equals
+    } else {
+      s[i] = -INFINITY;
+      id[i] = ~0ull;
+    }
+  }
+  bitonic_sort_desc<unsigned long long>(s, id, n2);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
+    out_idx[(uint64_t)q * k + i] = (int64_t)id[i];
+    if (out_score) out_score[(uint64_t)q * k + i] = (float)s[i];
+  }
+}
+
+void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k, int64_t* out_idx,
+                  float* out_score, hipStream_t stream) {
+  uint32_t n2 = 2;
+  while (n2 < (uint32_t)nshards * (uint32_t)k) n2 <<= 1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), (size_t)n2 * 16, stream, score64, idx, nshards, nq,
+                     k, out_idx, out_score);
+}
+
+}  // namespace mi

@@ -1,0 +1,108 @@
+"""Host-side mirror of the reference's matcher surface (src/utils/nnsearch.py) for the HIP path.
+
+    matching_HIP(K, embedded_features_train[N,D], embedded_features_test[Q,D], dataset=None,
+                 ifgenerate=False) -> (idx int64 [Q,K], time_per_query seconds)
+
+follows the convention of the reference's matchers: stateless ones are called as
+`matching_L2(K, train, test)` (src/utils/nnsearch.py:687), stateful ones take `dataset` /
+`ifgenerate`, persist under `outputs/<dataset>/` and rebuild iff `ifgenerate`
+(src/utils/nnsearch.py:503-525, 1033-1044).  Callers pass `vecs.T` / `qvecs.T` and use
+`match_idx.T` as ranks[K,Q] (src/offline.py:107-118, src/online.py:132-147).
+
+Results: the exact top-K by cosine similarity of the L2-normalised rows -- the ordering
+matching_L2 computes via ||q - g|| -- with ties to the lower index.  All arithmetic runs in the
+HIP library; there is no CPU path.
+"""
+import os
+import threading
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import Gallery, NORM_L2, NORM_NONE, NORM_L2_EPS  # noqa: F401
+
+_cache = {}
+_cache_lock = threading.Lock()
+
+
+def _gallery_path(dataset):
+    return os.path.join("outputs", dataset.replace("/", "_"), "mi355_gallery.bin")
+
+
+def get_gallery(train, dataset=None, ifgenerate=False, norm_mode=NORM_L2, device=0):
+    """Device-resident prepared gallery for `train` [N,D].
+
+    dataset=None: a fresh (uncached) gallery.  Otherwise the gallery is cached in-process under
+    `dataset`, persisted to outputs/<dataset>/mi355_gallery.bin, and rebuilt iff `ifgenerate`
+    (or when its shape no longer matches `train`, which the reference leaves to the user:
+    README "delete the cache when the database changes")."""
+    if dataset is None:
+        return Gallery.from_host(train, norm_mode=norm_mode, device=device)
+    key = (dataset, norm_mode, device)
+    with _cache_lock:
+        g = _cache.get(key)
+        shape = tuple(np.shape(train))
+        if g is not None and not ifgenerate and (g.n, g.d) == shape:
+            return g
+        if g is not None:
+            g.close()
+            _cache.pop(key, None)
+        path = _gallery_path(dataset)
+        if not ifgenerate and os.path.exists(path):
+            g = Gallery.load(path, device=device)
+            if (g.n, g.d) != shape or g.norm_mode != norm_mode:
+                g.close()
+                g = None
+        else:
+            g = None
+        if g is None:
+            g = Gallery.from_host(train, norm_mode=norm_mode, device=device)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            g.save(path)
+        _cache[key] = g
+        return g
+
+
+def drop_cached_galleries():
+    with _cache_lock:
+        for g in _cache.values():
+            g.close()
+        _cache.clear()
+
+
+def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=None, ifgenerate=False,
+                 device=0, return_scores=False):
+    """Drop-in `--matching_method HIP`.  The timer spans everything the call does (for a stateless
+    call that includes the gallery ingest, like matching_L2's timer includes its normalisation,
+    src/utils/nnsearch.py:688-705), device-synchronised."""
+    t1 = time.time()
+    num_test = np.shape(embedded_features_test)[0]
+    g = get_gallery(embedded_features_train, dataset, ifgenerate, NORM_L2, device)
+    try:
+        idx, scores, _ = g.search(embedded_features_test, int(K))
+    finally:
+        if dataset is None:
+            g.close()
+    t2 = time.time()
+    time_per_query = (t2 - t1) / num_test
+    if return_scores:
+        return idx, time_per_query, scores
+    return idx, time_per_query
+
+
+def matching_L2_hip(K, embedded_features_train, embedded_features_test):
+    """Same signature as matching_L2 (src/utils/nnsearch.py:687)."""
+    return matching_HIP(K, embedded_features_train, embedded_features_test)
+
+
+def ip_topk_hip(vecs, qvecs, K, dataset=None, ifgenerate=False, device=0):
+    """Top-K rows of `argsort(-(vecs.T @ qvecs), axis=0)` (src/main_retrieve.py:175-176): raw inner
+    product, no normalisation.  vecs [D,N], qvecs [D,Q] -> (ranks int64 [K,Q], scores f32 [K,Q])."""
+    g = get_gallery(np.asarray(vecs).T, dataset, ifgenerate, NORM_NONE, device)
+    try:
+        idx, sc, _ = g.search(np.asarray(qvecs).T, int(K))
+    finally:
+        if dataset is None:
+            g.close()
+    return idx.T, sc.T

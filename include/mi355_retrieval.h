@@ -1,0 +1,148 @@
+/*
+ * mi355_retrieval.h -- C ABI of libmi355_retrieval.so, the MI355X (gfx950) retrieval hot path.
+ *
+ * Plain pointers and sizes only (no torch / numpy types).  Each entry point names the reference
+ * interface it replaces (paths relative to the reference tree).  The reference has no FFI: its
+ * "plugin surface" is the --matching_method if/elif chain calling free functions of
+ * src/utils/nnsearch.py (src/offline.py:107-118, src/online.py:132-143), so the binding a
+ * maintainer adds is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - status codes (MI_OK == 0); mi_last_error() returns the message of the calling thread's last
+ *     failure.  Nothing throws across the boundary.
+ *   - a gallery handle is ONE row shard on ONE device (one process per GPU; row_offset globalises
+ *     the indices it returns).  Inputs are never modified; outputs are caller-owned.
+ *   - "host" entry points are synchronous and take strided f32/f64 host arrays (callers of the
+ *     reference pass `.T` views of [D,N] arrays, so strides are part of the contract).
+ *   - "_device" entry points take device pointers, enqueue on `stream` (a hipStream_t) and return
+ *     without synchronising; sticky error flags are read with mi_search_status().
+ *   - a handle is not re-entrant: serialise calls on one handle (online.py's Flask threads must
+ *     hold a lock; the Python wrapper does).
+ */
+#ifndef MI355_RETRIEVAL_H
+#define MI355_RETRIEVAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_gallery mi_gallery; /* opaque */
+
+enum mi_status {
+  MI_OK = 0,
+  MI_ERR_INVALID = 1,     /* bad argument (K > N like the reference's broadcast error, null ptr, ...) */
+  MI_ERR_HIP = 2,         /* HIP runtime failure; message carries hipGetErrorString */
+  MI_ERR_NOMEM = 3,
+  MI_ERR_IO = 4,
+  MI_ERR_OVERFLOW = 5,    /* candidate buffers overflowed and the exact fallback was disabled */
+  MI_ERR_UNSUPPORTED = 6
+};
+enum mi_dtype { MI_F32 = 0, MI_F64 = 1 };
+enum mi_memspace { MI_HOST = 0, MI_DEVICE = 1 };
+enum mi_norm {
+  MI_NORM_NONE = 0,  /* rows used as given: inner-product ranker, src/main_retrieve.py:175-176; faiss
+                        IndexFlatIP, src/utils/knn.py:33-40; QGE re-score, src/utils/Reranking.py:206 */
+  MI_NORM_L2 = 1,    /* x / ||x||, no eps: matching_L2, src/utils/nnsearch.py:693-698 */
+  MI_NORM_L2_EPS = 2 /* x / (||x|| + 1e-6): l2n, src/layers/functional.py:129-130; whitenapply tail,
+                        src/utils/whiten.py:10 */
+};
+
+const char* mi_last_error(void);
+int mi_device_count(int* count);
+
+/* ---- gallery ingest: replaces the per-call normalisation of matching_L2
+ * (src/utils/nnsearch.py:693-698) and faiss index.add (src/utils/knn.py:17-23).
+ * data: element (i,j) at data[i*row_stride + j*col_stride] (strides in elements), n rows, d cols.
+ * Builds, resident in HBM: normalised f32 rows [n][d64], the tile-blocked bf16 copy the MFMA
+ * kernel streams, and per-row rounding-error norms used for the exactness certificate. */
+int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t row_stride,
+                      int64_t col_stride, int memspace, int norm_mode, int device,
+                      int64_t row_offset, mi_gallery** out);
+int mi_gallery_destroy(mi_gallery* g);
+int mi_gallery_info(const mi_gallery* g, int64_t* n, int32_t* d, int32_t* norm_mode, int32_t* device,
+                    int64_t* row_offset, int64_t* hbm_bytes);
+/* Prepared-gallery persistence: the counterpart of the ANN methods' `outputs/<dataset>/` index files
+ * guarded by `ifgenerate` (src/utils/nnsearch.py:503-525, 1033-1044). */
+int mi_gallery_save(const mi_gallery* g, const char* path);
+int mi_gallery_load(const char* path, int device, mi_gallery** out);
+/* Copies normalised f32 rows [row0,row0+nrows) x d to a host buffer (tests / diffusion host logic). */
+int mi_gallery_get_rows(const mi_gallery* g, int64_t row0, int64_t nrows, float* out_host);
+
+/* ---- exhaustive kNN: replaces matching_L2(K, train, test) -> (idx, time_per_query)
+ * (src/utils/nnsearch.py:687-706) and KNN.search (src/utils/knn.py:25-31).
+ * q: nq x d strided host array.  out_idx [nq][k] int64 (row_offset + local row), out_score [nq][k]
+ * f32 (may be NULL): exact inner product of the stored rows with the (normalised) query, descending,
+ * ties to the lower index.  out_seconds (may be NULL): device-synchronised wall time of the call
+ * including query upload/normalisation, excluding nothing. */
+int mi_knn_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride,
+                  int64_t col_stride, int32_t k, int64_t* out_idx, float* out_score,
+                  double* out_seconds);
+
+/* Device-resident variant: q_dev [nq][d] row-major f32 (C order), outputs are device buffers.
+ * out_score64_dev (may be NULL) receives the float64 exact scores. */
+int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t k,
+                         int64_t* out_idx_dev, float* out_score_dev, double* out_score64_dev,
+                         void* stream);
+
+/* Sharded search = phase 1 on every shard, all-gather of approx top-k values, phase 2, all-gather of
+ * exact (score64, idx), merge.  New functionality (the reference is single-process).
+ * phase 1: bf16 MFMA scoring + survivor filtering; writes the shard's k largest approximate scores
+ *          (unsorted) to out_approx_dev [nq][k] (-inf padded when the shard has < k rows). */
+int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t k,
+                         float* out_approx_dev, void* stream);
+/* K-th largest of the gathered [g][nq][k] approximate values -> lower bound L [nq]. */
+int mi_kth_of_gathered_device(const float* gathered_dev, int32_t nshards, int64_t nq, int32_t k,
+                              float* out_L_dev, void* stream);
+/* phase 2: exact f64 re-score of every local row whose approximate score is within the rigorous error
+ *          margin of L; emits the shard's exact top-k (score64 desc, idx asc), -inf/-1 padded. */
+int mi_knn_phase2_device(mi_gallery* g, int64_t nq, int32_t k, const float* L_dev,
+                         int64_t* out_idx_dev, float* out_score_dev, double* out_score64_dev,
+                         void* stream);
+/* merge of [nshards][nq][k] exact lists -> [nq][k] by (score64 desc, idx asc). */
+int mi_topk_merge_device(const double* score64_dev, const int64_t* idx_dev, int32_t nshards,
+                         int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev,
+                         void* stream);
+
+/* ---- alpha query expansion: replaces feature_enhancement (src/utils/Reranking.py:195-208, copy at
+ * :288-301): q' = sum_j ((k-j)/k)^w * G[ranks[j,q]], q' /= (||q'|| + eps), then a full re-search.
+ * ranks: element (j,q) at ranks[j*rank_stride_j + q*rank_stride_q], global row ids (int64).
+ * partial: this shard's contribution sum (rows it owns) as f64 [nq][d]; finish: normalise the
+ * (all-reduced) sum into f32 queries [nq][d]. */
+int mi_aqe_partial_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_stride_j,
+                          int64_t rank_stride_q, int64_t nq, int32_t k_qe, double w,
+                          double* out_sum_dev, void* stream);
+int mi_aqe_finish_device(const double* sum_dev, int64_t nq, int32_t d, double eps, float* out_q_dev,
+                         double* out_q64_dev, void* stream);
+/* Host convenience (single shard): ranks host int64; out_qexp (may be NULL) f64 [nq][d]. */
+int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, int64_t rank_stride_q,
+                  int64_t nq, int32_t k_qe, double w, double eps, int32_t k, int64_t* out_idx,
+                  float* out_score, double* out_qexp, double* out_seconds);
+
+/* ---- status / instrumentation */
+typedef struct mi_search_stats {
+  int64_t searches;           /* query batches processed */
+  int64_t queries;
+  int64_t overflow_batches;   /* batches re-run through the exact fallback */
+  int64_t survivors;          /* sum over queries of entries kept by the filter */
+  int64_t candidates;         /* sum over queries of rows re-scored exactly */
+  double gemm_ms;             /* HIP-event time of the MFMA scoring launches (profiling on) */
+  int64_t gemm_launches;
+  double gemm_flops;          /* algorithmic 2*Q*N*D of those launches */
+  double gemm_bytes;          /* algorithmic gallery + query bytes of those launches */
+} mi_search_stats;
+int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches with hipEvents */
+int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
+/* Tunables: "chunk0_tiles", "chunk_growth", "survivor_cap", "rescore_cap", "exact_fallback",
+ * "force_exact" (score with the f32 kernel instead of bf16 MFMA). */
+int mi_set_option(mi_gallery* g, const char* name, double value);
+
+/* ---- synthetic data (bench / tests): device twin of synth.synth_rows. */
+int mi_synth_fill_device(float* dst_dev, uint64_t seed, int64_t row0, int64_t nrows, int32_t d,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_RETRIEVAL_H */
