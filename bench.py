@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: exhaustive top-100 retrieval, queries/sec (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2]): synthetic rOxford5k + 1M distractors gallery,
+N = 1,005,994 x D = 2048 f32 descriptors (seeded counter-based generator, L2-normalised by the
+ingest kernel), one step = one batch of 1024 queries -> exact top-100 per query.  Inputs are
+resident in HBM when the timed region starts.  With --gpus N the SAME gallery is row-sharded over N
+ranks (strong scaling; one process per GPU, RCCL all-gathers of the per-shard top-K).
+
+Prints ONE JSON line on rank 0 (contract in the task description): metric/value/unit, `roofline`
+(dominant kernel = the bf16 MFMA scoring kernel, HIP-event timed inside the timed region) and
+`cpu_baseline` (the oracle's matching_L2 restatement timed on a bounded sample on the host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (gallery rows, description)
+    "roxford5k+1m": (1005994, "rOxford5k+1M distractors (synthetic 2048-d), HIP MFMA QxG^T + top-100"),
+    "roxford5k": (4993, "rOxford5k-sized synthetic gallery"),
+    "10m": (10000000, "synthetic 10Mx2048 gallery"),
+}
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="roxford5k+1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="override gallery rows")
+    ap.add_argument("--dim", type=int, default=2048)
+    ap.add_argument("--queries", type=int, default=1024)
+    ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=131072)
+    ap.add_argument("--cpu-sample-queries", type=int, default=4)
+    ap.add_argument("--option", action="append", default=[], help="name=value passed to mi_set_option")
+    return ap.parse_args()
+
+
+def cpu_baseline(gallery, q_host, n_total, args):
+    """Oracle (numpy restatement of matching_L2, src/utils/nnsearch.py:687-706) on a bounded sample:
+    the first `cpu_sample_rows` gallery rows and `cpu_sample_queries` queries; its cost is linear in
+    the number of gallery rows, so queries/s at the full gallery = measured * sample_rows / N."""
+    import numpy as np
+    import oracle
+    ns = min(args.cpu_sample_rows, gallery.n)
+    nqs = min(args.cpu_sample_queries, q_host.shape[0])
+    g = gallery.get_rows(0, ns)
+    t0 = time.time()
+    oracle.matching_l2(args.topk, g, q_host[:nqs])
+    dt = time.time() - t0
+    qps_sample = nqs / dt
+    try:
+        import threadpoolctl
+        blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        blas_threads = None
+    return {
+        "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port",
+        "sample": "oracle.matching_l2 (numpy, f32, single thread like the reference) on the first %d of %d gallery "
+                  "rows x %d queries, K=%d: %.2f s; scaled by rows (cost is linear in N)" % (ns, n_total, nqs,
+                                                                                            args.topk, dt),
+        "host_cpus": os.cpu_count(), "blas_threads": blas_threads, "numpy": np.__version__,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import isehr_amd  # noqa: F401
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    n_total = args.rows or WORKLOADS[args.workload][0]
+    d, nq, k = args.dim, args.queries, args.topk
+    lo, hi = shard_bounds(n_total, world, rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic shard, generated on device (rows are a pure function of (seed, row))
+    raw = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), args.seed, lo, hi - lo, d, stream)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=local_rank,
+                                       row_offset=lo)
+    ingest_s = time.time() - t0
+    del raw
+    torch.cuda.empty_cache()
+    for opt in args.option:
+        name, val = opt.split("=")
+        gal.set_option(name, float(val))
+    sg = ShardedGallery(gal)
+
+    # a small pool of query batches (seeded), cycled over the steps
+    pool = []
+    for i in range(4):
+        qb = torch.empty((nq, d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(qb.data_ptr(), args.seed + 1 + i, 0, nq, d, stream)
+        pool.append(qb)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        sg.search(pool[i % len(pool)], k)
+    barrier()
+    gal.status(reset=True)
+    gal.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        idx, sc = sg.search(pool[i % len(pool)], k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gal.profile(False)
+    st = gal.status(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ov = torch.tensor([st["overflow_batches"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(ov, op=dist.ReduceOp.SUM)
+        overflow = int(ov.item())
+    else:
+        overflow = st["overflow_batches"]
+
+    # result sanity on the last batch (size-independent properties; the oracle cannot run at this size)
+    sc_h = sc.cpu().numpy()
+    idx_h = idx.cpu().numpy()
+    import numpy as np
+    assert (np.diff(sc_h, axis=1) <= 0).all(), "scores not sorted"
+    assert all(len(set(r)) == k for r in idx_h[:32]), "duplicate indices"
+    assert idx_h.min() >= 0 and idx_h.max() < n_total
+    if overflow:
+        raise SystemExit("bench invalid: %d batches overflowed the candidate buffers" % overflow)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        gemm_s = st["gemm_ms"] * 1e-3
+        achieved = st["gemm_flops"] / gemm_s / 1e12 if gemm_s > 0 else None
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("gemm_select_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "queries/sec", "value": nq * args.steps / elapsed, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
+                       "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
+                       "parallelism": "row-shard x%d" % world, "exact": "bf16 MFMA filter + f64 re-score certificate",
+                       "ingest_s": round(ingest_s, 3),
+                       "candidates_per_query": st["candidates"] / max(1, st["queries"]),
+                       "survivors_per_query": st["survivors"] / max(1, st["queries"])},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / MFMA_BF16_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
+                         "kernel": "gemm_select_kernel", "launches": st["gemm_launches"],
+                         "avg_launch_ms": st["gemm_ms"] / max(1, st["gemm_launches"]),
+                         "kernel_share_of_step": gemm_s / elapsed},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(gal, pool[(args.steps - 1) % len(pool)].cpu().numpy(), n_total, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    gal.close()
+
+
+if __name__ == "__main__":
+    main()

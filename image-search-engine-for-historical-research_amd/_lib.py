@@ -79,6 +79,11 @@ def load():
             raise RuntimeError(
                 "libmi355_retrieval.so is not built (%s). Run `python __graft_entry__.py build`; "
                 "this package has no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
+        # Two HIP runtimes in one process cannot both own the device, and torch tensors / streams /
+        # RCCL buffers are handed to this library as raw pointers, so torch is imported first: the
+        # dynamic linker then resolves our DT_NEEDED libamdhip64.so.7 to the already-loaded copy.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)        # AttributeError here = header/library mismatch
