@@ -49,6 +49,9 @@ struct Workspace {
   uint32_t *cand_rows = nullptr, *cand_cnt = nullptr;
   double* cand_score = nullptr;
   uint64_t* stats2 = nullptr;
+  SurvRec* rec = nullptr;
+  uint32_t* rec_cnt = nullptr;
+  uint32_t rec_cap = 2048, nseg = 0;
   std::vector<void*> allocs;
 };
 }  // namespace
@@ -56,7 +59,7 @@ struct Workspace {
 struct mi_gallery {
   int device = 0;
   int64_t n = 0, npad = 0, row_offset = 0;
-  int32_t d = 0, dp = 0, ksteps = 0, norm_mode = 0;
+  int32_t d = 0, dp = 0, norm_mode = 0;
   float* gal_f32 = nullptr;
   void* gal_bf16 = nullptr;
   RowStat* rowstat = nullptr;
@@ -65,8 +68,8 @@ struct mi_gallery {
   hipStream_t stream = nullptr;
   Workspace ws;
   // options
-  int chunk0_tiles = 4, chunk_growth = 8, exact_fallback = 1, force_exact = 0;
-  uint32_t surv_cap = 8192, rescore_cap = 2048;
+  int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0;
+  uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
   mi_search_stats stats{};
   bool profile = false;
@@ -112,7 +115,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(q_stat, QB);
   A(thr, QB);
   A(margin, QB);
-  A(cnt, QB);
+  A(cnt, (size_t)QB * CNT_STRIDE);
   A(surv, (size_t)QB * ws.cap);
   A(flags, 4);
   A(topvals, (size_t)QB * kcap);
@@ -121,6 +124,10 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cand_cnt, QB);
   A(cand_score, (size_t)QB * ws.rcap);
   A(stats2, 4);
+  ws.rec_cap = 2048;
+  ws.nseg = gemm_select_grid() * 8;
+  A(rec, (size_t)ws.nseg * ws.rec_cap);
+  A(rec_cnt, ws.nseg);
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 32));
@@ -181,6 +188,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   const uint32_t first_cnt = (uint32_t)std::min<int64_t>(g->n, t0 * TILE);
   const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
   launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
+  // chunk boundaries (cumulative tiles): t0, t0*g, t0*g*max(2,g/2), then everything that is left
+  const int64_t gr = std::max(1, g->chunk_growth);
+  const int64_t bounds[3] = {t0, t0 * gr, t0 * gr * std::max<int64_t>(2, gr / 2)};
+  int bi = 0;
   int64_t t = 0, len = t0;
   bool first = true;
   while (t < ntiles) {
@@ -201,17 +212,22 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       ScoreArgs a;
       a.gal_bf16 = g->gal_bf16;
       a.qry_bf16 = ws.q_bf16;
-      a.ksteps = g->ksteps;
+      a.nslices = g->dp / SLICE_K;
       a.tile0 = (int32_t)t;
       a.ntiles = (int32_t)cur;
       a.nqt = qpad / TILE;
       a.n = g->n;
       a.nq = nq;
+      a.debug = g->debug;
+      a.rec = ws.rec;
+      a.rec_cnt = ws.rec_cnt;
+      a.rec_cap = ws.rec_cap;
       a.st = st;
       size_t slot;
       prof_begin(g, s, &slot);
       launch_gemm_select(a, first, s);
       prof_end(g, s, slot);
+      if (!first) launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, s);
       if (g->profile) {
         const double rows = (double)(rows1 - rows0);
         g->stats.gemm_flops += 2.0 * nq * rows * g->d;
@@ -222,7 +238,9 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     const bool last = (t >= ntiles);
     launch_select_maintain(st, nq, k, last ? 1 : 0, ws.topvals, ws.L, ws.stats2, s);
     first = false;
-    len = (t == t0 && g->chunk_growth > 1) ? t0 * g->chunk_growth : len * std::max(1, g->chunk_growth);
+    ++bi;
+    len = (gr > 1 && bi < 3) ? std::max<int64_t>(1, bounds[bi] - t) : (ntiles - t);
+    if (gr == 1) len = t0;
   }
   HIPC(hipGetLastError());
   return MI_OK;
@@ -310,7 +328,6 @@ int mi_gallery_destroy(mi_gallery* g) {
 
 static int gallery_alloc(mi_gallery* g) {
   g->dp = (int32_t)round_up(g->d, BK);
-  g->ksteps = g->dp / BK;
   g->npad = round_up(g->n, TILE);
   HIPC(hipSetDevice(g->device));
   HIPC(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
@@ -731,6 +748,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
     g->rescore_cap = v;
   } else if (n == "exact_fallback") g->exact_fallback = value != 0;
   else if (n == "force_exact") g->force_exact = value != 0;
+  else if (n == "debug") g->debug = (int)value;
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
   return MI_OK;
 }

@@ -8,25 +8,30 @@ namespace mi {
 
 // ---- geometry of the tile-blocked bf16 images streamed by the MFMA kernel -------------------
 // A matrix X[rows][dp] (dp = d rounded up to 64) is stored as
-//   blocked[tile = row / 256][ks = k / 64][row % 256][64]      (bf16, 32 KiB per (tile, ks) block)
-// with the eight 16-byte chunks of each 128-byte row permuted: physical chunk = c ^ ((row >> 1) & 7).
-// One (tile, ks) block is exactly the LDS image of one K-step, so the global->LDS DMA is a linear
-// copy and `ds_read_b128` of the MFMA fragments is bank-conflict free (see DESIGN.md "LDS image").
+//   blocked[tile = row / 256][slice = k / 32][row % 256][32]     (bf16, 16 KiB per (tile, slice) block)
+// with the four 16-byte chunks of each 64-byte row permuted: physical chunk = c ^ ((-(row >> 2)) & 3).
+// One (tile, slice) block is exactly the LDS image of one K-slice of one operand, so the global->LDS
+// DMA is a linear copy and the `ds_read_b128` fragment reads of v_mfma_f32_16x16x32_bf16 (lane l: row
+// l & 15, chunk l >> 4) hit 16 distinct 16-byte slots in each of the instruction's four lane groups,
+// i.e. they are bank-conflict free (derivation in DESIGN.md "LDS image").
 constexpr int TILE = 256;     // gallery rows / queries per workgroup tile
-constexpr int BK = 64;        // K-step (bf16 elements)
-constexpr int BLOCK_ELEMS = TILE * BK;
+constexpr int BK = 64;        // column padding granule of dp
+constexpr int SLICE_K = 32;   // K-depth of one slice = one v_mfma_f32_16x16x32_bf16
+constexpr int SLICE_ELEMS = TILE * SLICE_K;          // 8192 bf16 = 16 KiB
+constexpr int SLICE_BYTES = SLICE_ELEMS * 2;
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-__device__ __forceinline__ uint32_t swz_chunk(uint32_t row, uint32_t c) { return c ^ ((row >> 1) & 7u); }
+__host__ __device__ __forceinline__ uint32_t swz_chunk(uint32_t row, uint32_t c) {
+  return c ^ ((0u - (row >> 2)) & 3u);
+}
 
-// element offset of (row, k) inside the blocked image
-__device__ __forceinline__ int64_t blocked_offset(int64_t row, int32_t k, int32_t ksteps) {
+// element offset of (row, k) inside the blocked image (nslices = dp / 32)
+__host__ __device__ __forceinline__ int64_t blocked_offset(int64_t row, int32_t k, int32_t nslices) {
   const int64_t tile = row / TILE;
   const uint32_t r = (uint32_t)(row % TILE);
-  const uint32_t ks = (uint32_t)k / BK, kk = (uint32_t)k % BK;
-  const uint32_t c = kk >> 3;
-  return ((tile * ksteps + ks) * (int64_t)BLOCK_ELEMS) + (int64_t)r * BK + (swz_chunk(r, c) << 3) + (kk & 7);
+  const uint32_t sl = (uint32_t)k / SLICE_K, kk = (uint32_t)k % SLICE_K;
+  return ((tile * nslices + sl) * (int64_t)SLICE_ELEMS) + (int64_t)r * SLICE_K + (swz_chunk(r, kk >> 3) << 3) + (kk & 7);
 }
 
 // float <-> order-preserving uint32 key (larger float -> larger key); NaN maps below -inf
@@ -55,13 +60,23 @@ struct RowStat {
   float norm_diff;   // ||g_hat - g||
 };
 
+// survivor record written by the scoring kernel into wave-private segments (no atomics in the hot kernel)
+struct __attribute__((aligned(16))) SurvRec {
+  float score;
+  uint32_t row;
+  uint32_t q;
+  uint32_t pad;
+};
+
 // sticky device-side flags
-enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u };
+enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u, FLAG_REC_OVERFLOW = 4u };
+
+constexpr uint32_t CNT_STRIDE = 32;   // one survivor counter per 128-byte line (atomics to one line serialise in L2)
 
 struct QueryState {       // all arrays sized for qpad queries
   float* thr;             // current pass threshold (approx-score domain), +inf for padded queries
   float* margin;          // 2 * eps_q  (rigorous |approx - exact| bound, both sides)
-  uint32_t* cnt;          // survivors appended
+  uint32_t* cnt;          // survivors appended: counter of query q at cnt[q * CNT_STRIDE]
   uint64_t* surv;         // [qpad][cap]
   uint32_t* flags;        // [1]
   uint32_t cap;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void exact_select_kernel(ExactArgs p) {
       if (FIRST) {
         p.st.surv[(uint64_t)q * p.st.cap + (uint64_t)row] = pack_entry(v, (uint32_t)row);
       } else if (v >= thr) {
-        const uint32_t pos = atomicAdd(&p.st.cnt[q], 1u);
+        const uint32_t pos = atomicAdd(&p.st.cnt[q * CNT_STRIDE], 1u);
         if (pos < p.st.cap) p.st.surv[(uint64_t)q * p.st.cap + pos] = pack_entry(v, (uint32_t)row);
         else atomicOr(p.st.flags, FLAG_SURV_OVERFLOW);
       }

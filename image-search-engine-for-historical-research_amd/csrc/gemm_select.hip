@@ -6,11 +6,20 @@
 // v_mfma_f32_16x16x32_bf16; the Q x N score matrix is never written: every accumulator is compared
 // with its query's running threshold in registers and only survivors are appended.
 //
-// Geometry: workgroup = 512 threads = 8 waves as 2 (gallery) x 4 (query); tile 256 gallery rows x 256
-// queries x BK 64; per wave 128 x 64 outputs = 8 x 4 MFMA blocks of 16x16 (128 accumulator VGPRs).
-// Operands are streamed from the tile-blocked images (common.h) by global_load_lds_dwordx4 into a
-// double-buffered LDS ring (2 x (32 KiB A + 32 KiB B) = 128 KiB, one workgroup per CU); the images
-// are already chunk-swizzled so that the DMA is linear and ds_read_b128 is conflict free.
+// Structure (DESIGN.md "Scoring kernel"):
+//  * persistent grid, one 512-thread workgroup per CU, walking (gallery tile, query tile) pairs in an
+//    XCD-aware order (the query tiles of one gallery tile run on one XCD, so a gallery tile is fetched
+//    from HBM once and re-served from that XCD's L2);
+//  * tile 256 gallery rows x 256 queries; 8 waves as 2 (gallery) x 4 (query), 128 x 64 outputs per wave
+//    = 8 x 4 blocks of 16x16 (128 accumulator VGPRs);
+//  * operands stream as K-slices of 32 (one MFMA depth): 16 KiB of A + 16 KiB of B per slice, copied by
+//    global_load_lds_dwordx4 (4 DMA pieces per wave per slice) into a 4-slot LDS ring (128 KiB) that
+//    runs three slices ahead and never drains: counted `s_waitcnt vmcnt(8)`, raw `s_barrier`;
+//  * the two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) are staggered by one barrier:
+//    while one group issues its 32 MFMAs of a slice, the other reads its fragments (12 ds_read_b128)
+//    and issues the DMA of the slice three ahead -- the matrix pipe of every SIMD alternates between
+//    its two waves and stays busy;
+//  * the ring keeps running across tile boundaries (no prologue/epilogue bubble per tile).
 #include "common.h"
 #include "kernels.h"
 
@@ -22,51 +31,84 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
+constexpr int RING_SLOTS = 4;
+constexpr int SLOT_BYTES = 2 * SLICE_BYTES;                 // A + B
+constexpr int RING_BYTES = RING_SLOTS * SLOT_BYTES;         // 128 KiB
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* ldst) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)ldst, 16, 0, 0);
 }
 
-__device__ __forceinline__ void append_survivor(const QueryState& st, uint32_t q, float v, uint32_t row) {
-  const uint32_t pos = atomicAdd(&st.cnt[q], 1u);
-  if (pos < st.cap)
-    st.surv[(uint64_t)q * st.cap + pos] = pack_entry(v, row);
-  else
-    atomicOr(st.flags, FLAG_SURV_OVERFLOW);
-}
 
-template <bool FIRST>
+// DBG: diagnostics-only build variants (bit0 skip DMA, bit1 skip MFMA, bit2 skip the filter); 0 = product
+template <bool FIRST, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD-aware tile map: blocks b and b+8 share an XCD (round-robin dispatch), so the nqt query tiles of
-  // one gallery tile are given to consecutive blocks of one XCD and the gallery tile is fetched from
-  // HBM once and served to the other query tiles from that XCD's L2.
-  const uint32_t b = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ring | thr[nqt * 256]  (ONE LDS object)
+  float* thr_lds = reinterpret_cast<float*>(smem + RING_BYTES);
+
+  // ---- work assignment.  Blocks b, b+8, ... share an XCD (round-robin dispatch; speed only).  XCD label x
+  // owns gallery tiles tl = x (mod 8); its virtual list v -> (tl = (v / nqt) * 8 + x, qt = v % nqt) is dealt
+  // round-robin to the nwg blocks of that label, so concurrently running blocks share gallery tiles.
+  const uint32_t b = blockIdx.x, nwg = gridDim.x >> 3;
   const uint32_t xcd = b & 7u, j = b >> 3;
-  const uint32_t qt = j % (uint32_t)p.nqt;
-  const uint32_t tl = (j / (uint32_t)p.nqt) * 8u + xcd;
-  if (tl >= (uint32_t)p.ntiles) return;
-  const uint32_t gt = (uint32_t)p.tile0 + tl;
+  const uint32_t nqt = (uint32_t)p.nqt;
+  const uint32_t cnt_x = ((uint32_t)p.ntiles > xcd) ? ((uint32_t)p.ntiles - xcd + 7u) / 8u : 0u;
+  const uint32_t nvirt = cnt_x * nqt;
+  if (j >= nvirt) {
+    if (!FIRST && (threadIdx.x & 63) == 0) p.rec_cnt[b * 8 + (threadIdx.x >> 6)] = 0;
+    return;
+  }
+  const uint32_t my_tiles = (nvirt - j + nwg - 1) / nwg;
+  const uint32_t KSL = (uint32_t)p.nslices;
+  const uint32_t T_total = my_tiles * KSL;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3;
+  const int grp = w >> 2;                 // wave group = gallery half (wr)
+  const int wr = grp, wc = w & 3;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  const char* gA = (const char*)p.gal_bf16 + (int64_t)gt * p.ksteps * (BLOCK_ELEMS * 2);
-  const char* gB = (const char*)p.qry_bf16 + (int64_t)qt * p.ksteps * (BLOCK_ELEMS * 2);
+  for (uint32_t i = tid; i < nqt * TILE; i += 512) thr_lds[i] = FIRST ? 0.f : p.st.thr[i];
+  __syncthreads();
 
-  // stage K-step ks into ring slot buf: each wave copies 4 KiB of A and 4 KiB of B (8 DMA pieces of 1 KiB)
-  auto stage = [&](int buf, int ks) {
-    const char* sa = gA + (int64_t)ks * (BLOCK_ELEMS * 2) + w * 4096 + lane * 16;
-    const char* sb = gB + (int64_t)ks * (BLOCK_ELEMS * 2) + w * 4096 + lane * 16;
-    char* la = smem + buf * 32768 + w * 4096;
-    char* lb = smem + 65536 + buf * 32768 + w * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(sa + i * 1024, la + i * 1024);
-      glds16(sb + i * 1024, lb + i * 1024);
+  auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
+    const uint32_t v = j + i * nwg;
+    qt = v % nqt;
+    gt = (uint32_t)p.tile0 + (v / nqt) * 8u + xcd;
+  };
+
+  // ---- DMA prefetch state (runs 3 slices ahead of the compute state)
+  uint32_t pf_i = 0, pf_sl = 0;
+  const char *pfA, *pfB;
+  auto pf_set = [&](uint32_t i) {
+    uint32_t gt, qt;
+    tile_of(i < my_tiles ? i : my_tiles - 1, gt, qt);     // past the end: harmless re-load of the last tile
+    pfA = (const char*)p.gal_bf16 + (int64_t)gt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
+    pfB = (const char*)p.qry_bf16 + (int64_t)qt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
+  };
+  pf_set(0);
+  constexpr bool dbg_nodma = DBG & 1, dbg_nomfma = DBG & 2;
+  // one DMA piece (1 KiB per wave): piece 0/1 = A halves, 2/3 = B halves of this wave's share of the slice
+  auto issue_piece = [&](uint32_t slot, int piece) {
+    char* la = smem + slot * SLOT_BYTES + w * 2048 + (piece >> 1) * SLICE_BYTES + (piece & 1) * 1024;
+    const char* src = ((piece >> 1) ? pfB : pfA) + (piece & 1) * 1024;
+    if (!dbg_nodma) glds16(src, la);
+  };
+  auto issue_advance = [&]() {
+    pfA += SLICE_BYTES;
+    pfB += SLICE_BYTES;
+    if (++pf_sl == KSL) {
+      pf_sl = 0;
+      pf_set(++pf_i);
     }
+  };
+  auto issue = [&](uint32_t slot) {
+    issue_piece(slot, 0);
+    issue_piece(slot, 1);
+    issue_piece(slot, 2);
+    issue_piece(slot, 3);
+    issue_advance();
   };
 
   f32x4 acc[8][4];
@@ -75,95 +117,201 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets (bytes inside one 32 KiB operand image); kk = 1 is the same offset ^ 64
-  const uint32_t sw = (uint32_t)(l15 >> 1);
-  const uint32_t a_off = (uint32_t)(wr * 128 + l15) * 128u + ((((uint32_t)lq) ^ sw) << 4);
-  const uint32_t b_off = (uint32_t)(wc * 64 + l15) * 128u + ((((uint32_t)lq) ^ sw) << 4);
+  // fragment read offsets inside one operand image ([256 rows][32 k] bf16, 64-byte rows, chunk-swizzled)
+  const uint32_t fsw = (0u - (uint32_t)(l15 >> 2)) & 3u;
+  const uint32_t a_off = (uint32_t)(wr * 128 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+  const uint32_t b_off = (uint32_t)SLICE_BYTES + (uint32_t)(wc * 64 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
 
-  stage(0, 0);
-  const int KS = p.ksteps;
-  for (int ks = 0; ks < KS; ++ks) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ks + 1 < KS) stage((ks + 1) & 1, ks + 1);
-    const char* Ab = smem + (ks & 1) * 32768;
-    const char* Bb = smem + 65536 + (ks & 1) * 32768;
+  uint32_t cur_i = 0, cur_sl = 0, gt, qt;
+  tile_of(0, gt, qt);
+  // wave-private survivor record segment: positions come from ballot/popcount, so the hot kernel issues no
+  // returning atomics (a returning atomic forces vmcnt(0) and drains the DMA ring)
+  SurvRec* my_rec = p.rec + (uint64_t)(b * 8 + w) * p.rec_cap;
+  uint32_t my_cnt = 0;
+
+  // ---- prologue: three slices in flight, slice 0 landed for everybody
+  issue(0);
+  issue(1);
+  issue(2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
+
+  for (uint32_t S = 0; S < T_total; ++S) {
+    const uint32_t slot = S & 3u;
+    // ================= LOAD segment (the partner group is in its MFMA segment) =================
+    const char* sbase = smem + slot * SLOT_BYTES;
+    bf16x8 af[8], bfr[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[8], bfr[4];
+    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(sbase + b_off + nb * 1024);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-        bfr[nb] = *reinterpret_cast<const bf16x8*>(Bb + ((b_off ^ (kk * 64)) + nb * 2048));
+    for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(sbase + a_off + mb * 1024);
+    // group 1 has slices S+1, S+2 in flight here (S+3 is issued in its MFMA segment): S+1 must have landed
+    // before the barrier that opens group 0's LOAD(S+1)
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier: frees the slot (WAR)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= MFMA segment: 32 MFMAs with the 4 DMA pieces of slice S+3 spread between them ==========
+    // target slot held slice S-1, whose reads (both groups) retired two barriers ago
+    __builtin_amdgcn_s_setprio(1);
+    if (!dbg_nomfma) {
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-        af[mb] = *reinterpret_cast<const bf16x8*>(Ab + ((a_off ^ (kk * 64)) + mb * 2048));
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
+      for (int mb = 0; mb < 8; ++mb) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: C layout of 16x16x32: column (query) = lane & 15, row (gallery) = (lane >> 4) * 4 + reg
-  const uint32_t row_base = gt * TILE + wr * 128 + lq * 4;          // + mb*16 + reg
-  const uint32_t q_base = qt * TILE + wc * 64 + l15;                // + nb*16
-  const int64_t rows_valid = p.n - (int64_t)gt * TILE;              // rows of this tile that exist
-  const bool full_tile = rows_valid >= TILE;
-
-  if (FIRST) {
-    // bootstrap chunk: keep everything, slot = local row (chunk starts at row 0 of the shard)
+        if (mb & 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece((S + 3u) & 3u, mb >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const uint32_t q = q_base + nb * 16;
-      if (q < (uint32_t)p.nq) {
-        uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
+      for (int mb = 0; mb < 8; ++mb) asm volatile("" ::"v"(af[mb]));
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(bfr[nb]));
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) issue_piece((S + 3u) & 3u, pc);
+    }
+    issue_advance();
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // S+1 landed (S+2, S+3 may be in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (++cur_sl == KSL) {
+      // ---- tile finished: filter.  C layout of 16x16x32: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+      const uint32_t row_base = gt * TILE + wr * 128 + lq * 4;          // + mb*16 + reg
+      const uint32_t ql_base = qt * TILE + wc * 64 + l15;               // + nb*16
+      if (DBG & 4) {
+        // diagnostics: no filter, accumulators kept live
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint32_t row = row_base + mb * 16 + r;
-            if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
+          for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(acc[mb][nb]));
+      } else if (FIRST) {
+        // bootstrap chunk: keep everything, slot = local row (the chunk starts at row 0 of the shard)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const uint32_t q = ql_base + nb * 16;
+          if (q < (uint32_t)p.nq) {
+            uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t row = row_base + mb * 16 + r;
+                if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
+              }
           }
+        }
+      } else {
+        const bool full_tile = (int64_t)(gt + 1) * TILE <= p.n;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const uint32_t q = ql_base + nb * 16;
+          const float thr = thr_lds[q];      // +inf for padded queries
+          float m = acc[0][nb][0];
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
+          if (!__any(m >= thr)) continue;
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = acc[mb][nb][r];
+              const uint32_t row = row_base + mb * 16 + r;
+              const bool keep = v >= thr && (full_tile || row < (uint64_t)p.n);
+              const unsigned long long mask = __ballot(keep);
+              if (mask) {
+                const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (keep && pos < p.rec_cap) {
+                  SurvRec rc;
+                  rc.score = v; rc.row = row; rc.q = q; rc.pad = 0;
+                  my_rec[pos] = rc;
+                }
+                my_cnt += (uint32_t)__popcll(mask);
+              }
+            }
+        }
       }
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cur_sl = 0;
+      ++cur_i;
+      tile_of(cur_i < my_tiles ? cur_i : my_tiles - 1, gt, qt);
     }
-    return;
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the stagger barrier
+  if (!FIRST && lane == 0) {
+    p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
+    if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (unused) DMA pieces land before the LDS is released
+}
 
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    const uint32_t q = q_base + nb * 16;
-    const float thr = p.st.thr[q];      // +inf for padded queries
-    float m = acc[0][nb][0];
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
-    if (!__any(m >= thr)) continue;
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[mb][nb][r];
-        const uint32_t row = row_base + mb * 16 + r;
-        if (v >= thr && (full_tile || row < (uint64_t)p.n)) append_survivor(p.st, q, v, row);
-      }
+static unsigned persistent_grid() {
+  static unsigned cached = 0;
+  if (!cached) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cached = (unsigned)(cus / 8) * 8u;
+    if (cached < 8) cached = 8;
+  }
+  return cached;
+}
+
+unsigned gemm_select_grid() { return persistent_grid(); }
+
+__global__ __launch_bounds__(256) void scatter_records_kernel(const SurvRec* __restrict__ rec,
+                                                              const uint32_t* __restrict__ rec_cnt, uint32_t rec_cap,
+                                                              QueryState st) {
+  const uint32_t seg = blockIdx.x;
+  const uint32_t n = rec_cnt[seg];
+  const SurvRec* r = rec + (uint64_t)seg * rec_cap;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const SurvRec e = r[i];
+    const uint32_t pos = atomicAdd(&st.cnt[e.q * CNT_STRIDE], 1u);
+    if (pos < st.cap) st.surv[(uint64_t)e.q * st.cap + pos] = pack_entry(e.score, e.row);
+    else atomicOr(st.flags, FLAG_SURV_OVERFLOW);
   }
 }
 
-void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
-  const unsigned groups = (unsigned)((a.ntiles + 7) / 8);
-  const unsigned grid = groups * 8u * (unsigned)a.nqt;
+void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
+                            QueryState st, hipStream_t stream) {
+  hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(256), 0, stream, rec, rec_cnt, rec_cap, st);
+}
+
+template <bool FIRST, int DBG>
+static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void*)gemm_select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_select_kernel<FIRST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     attr_done = true;
   }
-  if (first)
-    hipLaunchKernelGGL(gemm_select_kernel<true>, dim3(grid), dim3(512), 131072, stream, a);
-  else
-    hipLaunchKernelGGL(gemm_select_kernel<false>, dim3(grid), dim3(512), 131072, stream, a);
+  hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+}
+
+void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
+  const size_t lds = (size_t)RING_BYTES + (size_t)a.nqt * TILE * 4;
+  if (first) return launch_variant<true, 0>(a, lds, stream);
+  switch (a.debug) {
+    case 4: return launch_variant<false, 4>(a, lds, stream);
+    case 5: return launch_variant<false, 5>(a, lds, stream);
+    case 6: return launch_variant<false, 6>(a, lds, stream);
+    default: return launch_variant<false, 0>(a, lds, stream);
+  }
 }
 
 }  // namespace mi

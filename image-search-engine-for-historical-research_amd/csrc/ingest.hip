@@ -1,5 +1,5 @@
 // Gallery / query ingest for gfx950: strided f32|f64 input -> (a) normalised f32 rows [n][dp],
-// (b) tile-blocked, chunk-swizzled bf16 image [npad/256][dp/64][256][64], (c) per-row rounding stats.
+// (b) tile-blocked, chunk-swizzled bf16 image [npad/256][dp/32][256][32], (c) per-row rounding stats.
 //
 // Restates the normalisation of matching_L2 (src/utils/nnsearch.py:693-698, no eps), of l2n
 // (src/layers/functional.py:129-130, eps 1e-6) and the tail of whitenapply (src/utils/whiten.py:10);
@@ -20,7 +20,6 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src
   const int t = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * 64;
   const bool row_contig = (rs == 1 && cs != 1);
-  const int ksteps = dp / BK;
   // compute-phase mapping: thread -> (row ci, 16 columns starting at cj)
   const int ci = t >> 2, cj = (t & 3) * 16;
   const int64_t crow = row0 + ci;
@@ -77,13 +76,14 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src
 #pragma unroll
     for (int e = 0; e < 16; ++e) vf[e] = (float)(tile[ci][cj + e] * scale);
     if (crow < npad) {
-      const int ks = col0 / BK;
+      const int nslices = dp / SLICE_K;
       const int64_t tileidx = crow / TILE;
       const uint32_t r = (uint32_t)(crow % TILE);
-      __hip_bfloat16* blk = out_bf16 + (tileidx * ksteps + ks) * (int64_t)BLOCK_ELEMS + (int64_t)r * BK;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const uint32_t c = (uint32_t)(cj >> 3) + half;
+        const uint32_t kcol = (uint32_t)(col0 + cj + half * 8);
+        const uint32_t sl = kcol / SLICE_K, c = (kcol % SLICE_K) >> 3;
+        __hip_bfloat16* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
         union { __hip_bfloat16 h[8]; uint4 u; } pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -117,6 +117,78 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src
   }
 }
 
+// Row-per-workgroup variant for small row counts (query batches): 256 threads stride over the columns of ONE
+// row, so a 1024-query batch runs on 1024 workgroups instead of 16.  Same arithmetic as ingest_kernel.
+template <typename InT>
+__global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
+                                                             int64_t rs, int64_t cs, int norm_mode,
+                                                             float* __restrict__ out_f32,
+                                                             __hip_bfloat16* __restrict__ out_bf16,
+                                                             RowStat* __restrict__ rowstat, int32_t dp, int64_t npad) {
+  __shared__ double red[3][4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t row = blockIdx.x;
+  const bool valid = row < n;
+  auto block_sum3 = [&](double& a, double& b, double& c) {
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    __syncthreads();
+    if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  };
+  double scale = 1.0;
+  if (norm_mode != 0) {
+    double ss = 0.0, z0 = 0.0, z1 = 0.0;
+    if (valid)
+      for (int c = t; c < d; c += 256) {
+        const double v = (double)src[row * rs + (int64_t)c * cs];
+        ss += v * v;
+      }
+    block_sum3(ss, z0, z1);
+    const double nrm = sqrt(ss);
+    scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);
+  }
+  double s_g = 0.0, s_b = 0.0, s_d = 0.0;
+  const int nslices = dp / SLICE_K;
+  const int64_t tileidx = row / TILE;
+  const uint32_t r = (uint32_t)(row % TILE);
+  for (int c0 = t * 8; c0 < dp; c0 += 2048) {
+    float vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      vf[e] = (valid && c < d) ? (float)((double)src[row * rs + (int64_t)c * cs] * scale) : 0.0f;
+    }
+    const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
+    __hip_bfloat16* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+    union { __hip_bfloat16 h[8]; uint4 u; } pk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pk.h[e] = __float2bfloat16(vf[e]);
+      const double vb = (double)__bfloat162float(pk.h[e]);
+      s_b += vb * vb;
+      s_d += (vb - (double)vf[e]) * (vb - (double)vf[e]);
+      s_g += (double)vf[e] * (double)vf[e];
+    }
+    *reinterpret_cast<uint4*>(blk + (swz_chunk(r, ch) << 3)) = pk.u;
+    if (valid) {
+      float4* o = reinterpret_cast<float4*>(out_f32 + row * dp + c0);
+      o[0] = make_float4(vf[0], vf[1], vf[2], vf[3]);
+      o[1] = make_float4(vf[4], vf[5], vf[6], vf[7]);
+    }
+  }
+  block_sum3(s_g, s_b, s_d);
+  if (t == 0) {
+    RowStat rsd;
+    rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
+    rsd.norm_bf16 = (float)(sqrt(s_b) * (1.0 + 1e-6));
+    rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
+    rowstat[row] = rsd;
+  }
+}
+
 // max over valid rows of the three norms (non-finite rows -- zero-norm rows normalised to NaN -- skipped)
 __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restrict__ rowstat, int64_t n,
                                                           float* __restrict__ out3) {
@@ -140,6 +212,15 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                    float* out_f32, void* out_bf16, RowStat* rowstat, int32_t dp, int64_t npad,
                    hipStream_t stream) {
+  if (npad <= 4096) {   // small batches (queries): one workgroup per row
+    if (dtype == 0)
+      hipLaunchKernelGGL(ingest_rowwise_kernel<float>, dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
+                         d, rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+    else
+      hipLaunchKernelGGL(ingest_rowwise_kernel<double>, dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
+                         n, d, rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+    return;
+  }
   const int64_t blocks = (npad + 63) / 64;
   if (dtype == 0)
     hipLaunchKernelGGL(ingest_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, n, d,

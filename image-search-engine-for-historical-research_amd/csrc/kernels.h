@@ -14,14 +14,22 @@ void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStrea
 struct ScoreArgs {
   const void* gal_bf16;   // blocked image of the shard
   const void* qry_bf16;   // blocked image of the query batch
-  int32_t ksteps;         // dp / 64
+  int32_t nslices;        // dp / 32
   int32_t tile0, ntiles;  // gallery tiles of this launch
   int32_t nqt;            // query tiles (qpad / 256)
   int64_t n;              // valid gallery rows in the shard
   int32_t nq;             // valid queries
+  int32_t debug;          // diagnostics only: bit0 skip DMA, bit1 skip MFMA, bit2 skip filter (results invalid)
+  SurvRec* rec;           // [grid * 8 waves][rec_cap] wave-private survivor records of this launch
+  uint32_t* rec_cnt;      // [grid * 8]
+  uint32_t rec_cap;
   QueryState st;
 };
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
+unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
+// buckets the wave-private records of the last scoring launch into the per-query survivor buffers
+void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
+                            QueryState st, hipStream_t stream);
 
 // exact_score.hip -- f32 FMA scoring with the same filter (fallback / force_exact)
 struct ExactArgs {

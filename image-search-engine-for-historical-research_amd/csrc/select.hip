@@ -75,11 +75,11 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
     if (!(margin == margin)) margin = 0.f;   // NaN query (zero-norm): nothing will match anyway
     st.thr[q] = -INFINITY;
     st.margin[q] = margin;
-    st.cnt[q] = first_cnt;
+    st.cnt[q * CNT_STRIDE] = first_cnt;
   } else {
     st.thr[q] = INFINITY;
     st.margin[q] = 0.f;
-    st.cnt[q] = 0;
+    st.cnt[q * CNT_STRIDE] = 0;
   }
 }
 
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void select_maintain_kernel(QueryState st, int
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
   uint32_t* hist = keys + cap;
   uint32_t* sh = hist + 256;
-  const uint32_t n = min(st.cnt[q], cap);
+  const uint32_t n = min(st.cnt[q * CNT_STRIDE], cap);
   uint64_t* gsurv = st.surv + (uint64_t)q * cap;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint64_t e = gsurv[i];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) void select_maintain_kernel(QueryState st, int
   __syncthreads();
   if (threadIdx.x == 0) {
     st.thr[q] = thr_new;
-    st.cnt[q] = sh[2];
+    st.cnt[q * CNT_STRIDE] = sh[2];
     if (MODE == 1 && stats2) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)sh[2]);
   }
 }
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(QueryState st, c
                                                                 uint64_t* __restrict__ stats2) {
   __shared__ uint32_t counter;
   const uint32_t q = blockIdx.x;
-  const uint32_t n = min(st.cnt[q], st.cap);
-  if (st.cnt[q] > st.cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+  const uint32_t n = min(st.cnt[q * CNT_STRIDE], st.cap);
+  if (st.cnt[q * CNT_STRIDE] > st.cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
   if (threadIdx.x == 0) counter = 0;
   __syncthreads();
   const float lim = L[q] - st.margin[q];
