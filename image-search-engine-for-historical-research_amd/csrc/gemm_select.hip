@@ -12,14 +12,16 @@
 //    from HBM once and re-served from that XCD's L2);
 //  * tile 256 gallery rows x 256 queries; 8 waves as 2 (gallery) x 4 (query), 128 x 64 outputs per wave
 //    = 8 x 4 blocks of 16x16 (128 accumulator VGPRs);
-//  * operands stream as K-slices of 32 (one MFMA depth): 16 KiB of A + 16 KiB of B per slice, copied by
-//    global_load_lds_dwordx4 (4 DMA pieces per wave per slice) into a 4-slot LDS ring (128 KiB) that
-//    runs three slices ahead and never drains: counted `s_waitcnt vmcnt(8)`, raw `s_barrier`;
-//  * the two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) are staggered by one barrier:
-//    while one group issues its 32 MFMAs of a slice, the other reads its fragments (12 ds_read_b128)
-//    and issues the DMA of the slice three ahead -- the matrix pipe of every SIMD alternates between
-//    its two waves and stays busy;
-//  * the ring keeps running across tile boundaries (no prologue/epilogue bubble per tile).
+//  * operands stream as K-slices of 32 (one MFMA depth), 16 KiB of A (gallery) + 16 KiB of B (queries) per
+//    slice, copied by global_load_lds_dwordx4 into LDS rings that never drain (counted `s_waitcnt vmcnt(N)`,
+//    raw `s_barrier`).  vmcnt retires in order per wave, so the loader roles are split by wave group:
+//    waves 0-3 stream only A through a 5-slot ring (4 slices = 64 KiB in flight: the gallery comes from HBM,
+//    ~2 us loaded latency), waves 4-7 stream only B through a 4-slot ring (3 in flight: the query tile is
+//    L2-resident).  4 DMA pieces of 1 KiB per wave per slice either way, issued between the MFMAs;
+//  * the two wave groups (one wave of each per SIMD) are staggered by one barrier: while one group issues its
+//    32 MFMAs of a slice, the other reads its fragments (12 ds_read_b128) -- the matrix pipe of every SIMD
+//    alternates between its two waves and stays busy;
+//  * the rings keep running across tile boundaries (no prologue/epilogue bubble per tile).
 #include "common.h"
 #include "kernels.h"
 
@@ -31,12 +33,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-constexpr int RING_SLOTS = 4;
-constexpr int SLOT_BYTES = 2 * SLICE_BYTES;                 // A + B
-constexpr int RING_BYTES = RING_SLOTS * SLOT_BYTES;         // 128 KiB
-constexpr int HIT_SLOTS = 16;                               // per-wave filter scratch: 16 lanes x 32 scores + meta
-constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;   // 2304 B
-constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 18 KiB per workgroup
+constexpr int A_SLOTS = 5, B_SLOTS = 4;
+constexpr int A_RING = 0, B_RING = A_SLOTS * SLICE_BYTES;                 // byte offsets in LDS
+constexpr int RING_BYTES = (A_SLOTS + B_SLOTS) * SLICE_BYTES;             // 144 KiB
+constexpr int HIT_SLOTS = 8;                                // per-wave filter scratch: 8 lanes x 32 scores + meta
+constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1152 B
+constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 9 KiB per workgroup
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* ldst) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)ldst, 16, 0, 0);
@@ -81,36 +83,37 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     gt = (uint32_t)p.tile0 + (v / nqt) * 8u + xcd;
   };
 
-  // ---- DMA prefetch state (runs 3 slices ahead of the compute state)
+  // ---- DMA prefetch state.  Group 0 owns the A stream (lead 4 slices), group 1 the B stream (lead 3 slices).
+  // A wave copies 4 KiB (4 pieces) of its operand's 16 KiB slice block.
   uint32_t pf_i = 0, pf_sl = 0;
-  const char *pfA, *pfB;
+  const char* pf;
   auto pf_set = [&](uint32_t i) {
     uint32_t gt, qt;
     tile_of(i < my_tiles ? i : my_tiles - 1, gt, qt);     // past the end: harmless re-load of the last tile
-    pfA = (const char*)p.gal_bf16 + (int64_t)gt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
-    pfB = (const char*)p.qry_bf16 + (int64_t)qt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
+    pf = (grp == 0 ? (const char*)p.gal_bf16 + (int64_t)gt * KSL * SLICE_BYTES
+                   : (const char*)p.qry_bf16 + (int64_t)qt * KSL * SLICE_BYTES) + (w & 3) * 4096 + lane * 16;
   };
   pf_set(0);
   constexpr bool dbg_nodma = DBG & 1, dbg_nomfma = DBG & 2;
-  // one DMA piece (1 KiB per wave): piece 0/1 = A halves, 2/3 = B halves of this wave's share of the slice
-  auto issue_piece = [&](uint32_t slot, int piece) {
-    char* la = smem + slot * SLOT_BYTES + w * 2048 + (piece >> 1) * SLICE_BYTES + (piece & 1) * 1024;
-    const char* src = ((piece >> 1) ? pfB : pfA) + (piece & 1) * 1024;
-    if (!dbg_nodma) glds16(src, la);
+  const uint32_t ring_base = (grp == 0 ? A_RING : B_RING) + (w & 3) * 4096;
+  uint32_t wr_slot = 0;                                   // ring slot the next issued slice goes to
+  const uint32_t my_slots = grp == 0 ? A_SLOTS : B_SLOTS;
+  auto issue_piece = [&](int piece) {
+    if (!dbg_nodma) glds16(pf + piece * 1024, smem + ring_base + wr_slot * SLICE_BYTES + piece * 1024);
   };
   auto issue_advance = [&]() {
-    pfA += SLICE_BYTES;
-    pfB += SLICE_BYTES;
+    pf += SLICE_BYTES;
     if (++pf_sl == KSL) {
       pf_sl = 0;
       pf_set(++pf_i);
     }
+    if (++wr_slot == my_slots) wr_slot = 0;
   };
-  auto issue = [&](uint32_t slot) {
-    issue_piece(slot, 0);
-    issue_piece(slot, 1);
-    issue_piece(slot, 2);
-    issue_piece(slot, 3);
+  auto issue = [&]() {
+    issue_piece(0);
+    issue_piece(1);
+    issue_piece(2);
+    issue_piece(3);
     issue_advance();
   };
 
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // fragment read offsets inside one operand image ([256 rows][32 k] bf16, 64-byte rows, chunk-swizzled)
   const uint32_t fsw = (0u - (uint32_t)(l15 >> 2)) & 3u;
   const uint32_t a_off = (uint32_t)(wr * 128 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
-  const uint32_t b_off = (uint32_t)SLICE_BYTES + (uint32_t)(wc * 64 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+  const uint32_t b_off = (uint32_t)B_RING + (uint32_t)(wc * 64 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
 
   uint32_t cur_i = 0, cur_sl = 0, gt, qt;
   tile_of(0, gt, qt);
@@ -132,59 +135,63 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   SurvRec* my_rec = p.rec + (uint64_t)(b * 8 + w) * p.rec_cap;
   uint32_t my_cnt = 0;
   // filter scratch of this wave: scores of up to HIT_SLOTS "hit" lanes (32 each) + their (thr, q, row base)
-  float* sc_val = reinterpret_cast<float*>(smem + RING_BYTES + w * WAVE_SCRATCH);
+  float* sc_val = reinterpret_cast<float*>(smem + RING_BYTES + w * WAVE_SCRATCH);  // after both rings
   uint4* sc_meta = reinterpret_cast<uint4*>(smem + RING_BYTES + w * WAVE_SCRATCH + HIT_SLOTS * 32 * 4);
 
-  // ---- prologue: three slices in flight, slice 0 landed for everybody
-  issue(0);
-  issue(1);
-  issue(2);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // ---- prologue: group 0 puts A(0..3) in flight, group 1 B(0..2); slice 0 landed for everybody
+  issue();
+  issue();
+  issue();
+  if (grp == 0) {
+    issue();
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
 
+  uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding slice S
   for (uint32_t S = 0; S < T_total; ++S) {
-    const uint32_t slot = S & 3u;
     // ================= LOAD segment (the partner group is in its MFMA segment) =================
-    const char* sbase = smem + slot * SLOT_BYTES;
+    const char* abase = smem + a_rd * SLICE_BYTES;
+    const char* bbase = smem + b_rd * SLICE_BYTES;
+    if (++a_rd == A_SLOTS) a_rd = 0;
+    b_rd = (b_rd + 1) & (B_SLOTS - 1);
     bf16x8 af[8], bfr[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(sbase + b_off + nb * 1024);
+    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(bbase + b_off + nb * 1024);
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(sbase + a_off + mb * 1024);
-    // group 1 has slices S+1, S+2 in flight here (S+3 is issued in its MFMA segment): S+1 must have landed
-    // before the barrier that opens group 0's LOAD(S+1)
-    if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier: frees the slot (WAR)
+    for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(abase + a_off + mb * 1024);
+    // DMA issue sits behind the 12 fragment reads: its ~60 cycles per piece overlap the LDS read latency instead
+    // of stalling this wave's MFMAs (in the MFMA segment the partner wave cannot fill the matrix pipe).
+    // group 0 issues A(S+4) into the slot of A(S-1), group 1 issues B(S+3) into the slot of B(S-1); both groups'
+    // reads of slice S-1 retired before the barrier behind us.
+    __builtin_amdgcn_sched_barrier(0);
+    issue();
+    // group 1 (B loader): B(S+1) landed before the barrier that opens group 0's LOAD(S+1); B(S+2), B(S+3) may fly
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier: frees the slots (WAR)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ================= MFMA segment: 32 MFMAs with the 4 DMA pieces of slice S+3 spread between them ==========
-    // target slot held slice S-1, whose reads (both groups) retired two barriers ago
+    // ================= MFMA segment: 32 back-to-back MFMAs =================
     __builtin_amdgcn_s_setprio(1);
     if (!dbg_nomfma) {
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
+      for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-        if (mb & 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          issue_piece((S + 3u) & 3u, mb >> 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
     } else {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) asm volatile("" ::"v"(af[mb]));
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(bfr[nb]));
-#pragma unroll
-      for (int pc = 0; pc < 4; ++pc) issue_piece((S + 3u) & 3u, pc);
     }
-    issue_advance();
     __builtin_amdgcn_s_setprio(0);
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // S+1 landed (S+2, S+3 may be in flight)
+    // group 0 (A loader): A(S+1) landed, A(S+2..S+4) may be in flight
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
