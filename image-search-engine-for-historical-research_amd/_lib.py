@@ -62,6 +62,7 @@ SIGNATURES = {
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mi_debug_read_cycles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
 }
 
@@ -232,6 +233,11 @@ class Gallery:
 
     def profile(self, on=True):
         check(load().mi_profile_enable(self._h, 1 if on else 0))
+
+    def debug_cycles(self, nseg=2048):
+        out = np.zeros((nseg, 8), dtype=np.uint64)
+        check(load().mi_debug_read_cycles(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
 
     def status(self, reset=False):
         st = SearchStats()

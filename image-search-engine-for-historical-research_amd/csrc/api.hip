@@ -51,6 +51,7 @@ struct Workspace {
   uint64_t* stats2 = nullptr;
   SurvRec* rec = nullptr;
   uint32_t* rec_cnt = nullptr;
+  unsigned long long* dbg = nullptr;
   uint32_t rec_cap = 2048, nseg = 0;
   std::vector<void*> allocs;
 };
@@ -128,6 +129,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   ws.nseg = gemm_select_grid() * 8;
   A(rec, (size_t)ws.nseg * ws.rec_cap);
   A(rec_cnt, ws.nseg);
+  A(dbg, (size_t)ws.nseg * 8);
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 32));
@@ -222,6 +224,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       a.rec = ws.rec;
       a.rec_cnt = ws.rec_cnt;
       a.rec_cap = ws.rec_cap;
+      a.dbg = ws.dbg;
       a.st = st;
       size_t slot;
       prof_begin(g, s, &slot);
@@ -750,6 +753,15 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "force_exact") g->force_exact = value != 0;
   else if (n == "debug") g->debug = (int)value;
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
+  return MI_OK;
+}
+
+int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count) {
+  REQUIRE(g && out_host, "null");
+  REQUIRE(g->ws.dbg && count <= (int64_t)g->ws.nseg * 8, "no diagnostics buffer");
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpy(out_host, g->ws.dbg, (size_t)count * 8, hipMemcpyDeviceToHost));
   return MI_OK;
 }
 

@@ -46,6 +46,12 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* ldst) {
 
 
 // DBG: diagnostics-only build variants (bit0 skip DMA, bit1 skip MFMA, bit2 skip the filter); 0 = product
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
 template <bool FIRST, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ring | record stage | thr[nqt * 256]  (ONE LDS object)
@@ -138,6 +144,96 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   float* sc_val = reinterpret_cast<float*>(smem + RING_BYTES + w * WAVE_SCRATCH);  // after both rings
   uint4* sc_meta = reinterpret_cast<uint4*>(smem + RING_BYTES + w * WAVE_SCRATCH + HIT_SLOTS * 32 * 4);
 
+  // ---- per-tile filter of the accumulators (+ reset).  Called by group 1 right after its last MFMA segment of
+  // the tile and by group 0 ONE INTERVAL LATER (before its first MFMA segment of the next tile), so that both
+  // groups filter in the same barrier interval instead of stalling each other in two different ones.
+  auto tile_epilogue = [&](uint32_t gt, uint32_t qt) {
+      // ---- tile finished: filter.  C layout of 16x16x32: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+    const uint32_t row_base = gt * TILE + wr * 128 + lq * 4;          // + mb*16 + reg
+    const uint32_t ql_base = qt * TILE + wc * 64 + l15;               // + nb*16
+    if (DBG & 4) {
+      // diagnostics: no filter, accumulators kept live
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(acc[mb][nb]));
+    } else if (FIRST) {
+      // bootstrap chunk: keep everything, slot = local row (the chunk starts at row 0 of the shard)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const uint32_t q = ql_base + nb * 16;
+        if (q < (uint32_t)p.nq) {
+          uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t row = row_base + mb * 16 + r;
+              if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
+            }
+        }
+      }
+    } else {
+      // Filter.  The common case (no score of this lane reaches its query's threshold) is branch-free VALU:
+      // a 32-value max per (lane, query block).  Lanes that hit dump their 32 scores into a small LDS scratch
+      // and a ROLLED loop scans them -- the unrolled code stays tiny (a fully unrolled compare+append per
+      // accumulator was measured 17 % slower: instruction fetch and taken branches, not the stores).
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const uint32_t q = ql_base + nb * 16;
+        const float thr = thr_lds[q];      // +inf for padded queries
+        float m = acc[0][nb][0];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
+        const bool hit = m >= thr;
+        unsigned long long hitmask = __ballot(hit);
+        bool pending = hit;
+        while (hitmask) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask, 0u));
+          const bool take = pending && rank < HIT_SLOTS;
+          if (take) {
+            float4* dst = reinterpret_cast<float4*>(sc_val + rank * 32);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+              dst[mb] = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
+            sc_meta[rank] = make_uint4(__float_as_uint(thr), q, row_base, 0u);
+            pending = false;
+          }
+          const uint32_t nslots = min((uint32_t)__popcll(hitmask), (uint32_t)HIT_SLOTS);
+          hitmask = __ballot(pending);
+          // rolled scan of nslots x 32 scores: entry e -> slot e >> 5, value index i = e & 31 = mb * 4 + r
+          for (uint32_t e0 = 0; e0 < nslots * 32; e0 += 64) {      // wave-uniform trip count (my_cnt stays uniform)
+            const uint32_t e = e0 + lane;
+            const bool valid = e < nslots * 32;
+            const uint4 mt = sc_meta[valid ? (e >> 5) : 0];
+            const float v = sc_val[valid ? e : 0];
+            const uint32_t i = e & 31u;
+            const uint32_t row = mt.z + (i >> 2) * 16 + (i & 3u);
+            const bool keep = valid && v >= __uint_as_float(mt.x) && row < (uint64_t)p.n;
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+              const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+              if (keep && pos < p.rec_cap)
+                reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(v), row, mt.y, 0u);
+              my_cnt += (uint32_t)__popcll(km);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  uint32_t ep_gt = 0, ep_qt = 0;
+  bool ep_pending = false;
+
   // ---- prologue: group 0 puts A(0..3) in flight, group 1 B(0..2); slice 0 landed for everybody
   issue();
   issue();
@@ -152,7 +248,9 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
 
   uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding slice S
+  unsigned long long d_load = 0, d_b1 = 0, d_mfma = 0, d_b2 = 0, d_epi = 0, tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0, tt4 = 0;
   for (uint32_t S = 0; S < T_total; ++S) {
+    if (DBG & 8) tt0 = stamp();
     // ================= LOAD segment (the partner group is in its MFMA segment) =================
     const char* abase = smem + a_rd * SLICE_BYTES;
     const char* bbase = smem + b_rd * SLICE_BYTES;
@@ -173,9 +271,15 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier: frees the slots (WAR)
     __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 8) tt1 = stamp();
     __builtin_amdgcn_s_barrier();
+    if (DBG & 8) tt2 = stamp();
     __builtin_amdgcn_sched_barrier(0);
     // ================= MFMA segment: 32 back-to-back MFMAs =================
+    if (grp == 0 && ep_pending) {          // deferred filter of the previous tile (fragments of slice S stay live)
+      tile_epilogue(ep_gt, ep_qt);
+      ep_pending = false;
+    }
     __builtin_amdgcn_s_setprio(1);
     if (!dbg_nomfma) {
 #pragma unroll
@@ -193,97 +297,29 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     // group 0 (A loader): A(S+1) landed, A(S+2..S+4) may be in flight
     if (grp == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (DBG & 8) tt3 = stamp();
     __builtin_amdgcn_s_barrier();
+    if (DBG & 8) {
+      tt4 = stamp();
+      d_load += tt1 - tt0; d_b1 += tt2 - tt1; d_mfma += tt3 - tt2; d_b2 += tt4 - tt3;
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     if (++cur_sl == KSL) {
-      // ---- tile finished: filter.  C layout of 16x16x32: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-      const uint32_t row_base = gt * TILE + wr * 128 + lq * 4;          // + mb*16 + reg
-      const uint32_t ql_base = qt * TILE + wc * 64 + l15;               // + nb*16
-      if (DBG & 4) {
-        // diagnostics: no filter, accumulators kept live
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(acc[mb][nb]));
-      } else if (FIRST) {
-        // bootstrap chunk: keep everything, slot = local row (the chunk starts at row 0 of the shard)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const uint32_t q = ql_base + nb * 16;
-          if (q < (uint32_t)p.nq) {
-            uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const uint32_t row = row_base + mb * 16 + r;
-                if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
-              }
-          }
-        }
-      } else {
-        // Filter.  The common case (no score of this lane reaches its query's threshold) is branch-free VALU:
-        // a 32-value max per (lane, query block).  Lanes that hit dump their 32 scores into a small LDS scratch
-        // and a ROLLED loop scans them -- the unrolled code stays tiny (a fully unrolled compare+append per
-        // accumulator was measured 17 % slower: instruction fetch and taken branches, not the stores).
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const uint32_t q = ql_base + nb * 16;
-          const float thr = thr_lds[q];      // +inf for padded queries
-          float m = acc[0][nb][0];
-#pragma unroll
-          for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
-          const bool hit = m >= thr;
-          unsigned long long hitmask = __ballot(hit);
-          bool pending = hit;
-          while (hitmask) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask, 0u));
-            const bool take = pending && rank < HIT_SLOTS;
-            if (take) {
-              float4* dst = reinterpret_cast<float4*>(sc_val + rank * 32);
-#pragma unroll
-              for (int mb = 0; mb < 8; ++mb)
-                dst[mb] = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
-              sc_meta[rank] = make_uint4(__float_as_uint(thr), q, row_base, 0u);
-              pending = false;
-            }
-            const uint32_t nslots = min((uint32_t)__popcll(hitmask), (uint32_t)HIT_SLOTS);
-            hitmask = __ballot(pending);
-            // rolled scan of nslots x 32 scores: entry e -> slot e >> 5, value index i = e & 31 = mb * 4 + r
-            for (uint32_t e0 = 0; e0 < nslots * 32; e0 += 64) {      // wave-uniform trip count (my_cnt stays uniform)
-              const uint32_t e = e0 + lane;
-              const bool valid = e < nslots * 32;
-              const uint4 mt = sc_meta[valid ? (e >> 5) : 0];
-              const float v = sc_val[valid ? e : 0];
-              const uint32_t i = e & 31u;
-              const uint32_t row = mt.z + (i >> 2) * 16 + (i & 3u);
-              const bool keep = valid && v >= __uint_as_float(mt.x) && row < (uint64_t)p.n;
-              const unsigned long long km = __ballot(keep);
-              if (km) {
-                const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                if (keep && pos < p.rec_cap)
-                  reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(v), row, mt.y, 0u);
-                my_cnt += (uint32_t)__popcll(km);
-              }
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       cur_sl = 0;
+      if (grp == 1) tile_epilogue(gt, qt);
+      else { ep_gt = gt; ep_qt = qt; ep_pending = true; }
       ++cur_i;
+      if (DBG & 8) d_epi += stamp() - tt4;
       tile_of(cur_i < my_tiles ? cur_i : my_tiles - 1, gt, qt);
     }
   }
+  if (grp == 0 && ep_pending) tile_epilogue(ep_gt, ep_qt);
   if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the stagger barrier
+  if ((DBG & 8) && lane == 0) {
+    unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
+    dbgp[0] = d_load; dbgp[1] = d_b1; dbgp[2] = d_mfma; dbgp[3] = d_b2; dbgp[4] = d_epi; dbgp[5] = T_total;
+  }
   if (!FIRST && lane == 0) {
     p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
     if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
@@ -342,6 +378,7 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
     case 4: return launch_variant<false, 4>(a, lds, stream);
     case 5: return launch_variant<false, 5>(a, lds, stream);
     case 6: return launch_variant<false, 6>(a, lds, stream);
+    case 8: return launch_variant<false, 8>(a, lds, stream);
     default: return launch_variant<false, 0>(a, lds, stream);
   }
 }

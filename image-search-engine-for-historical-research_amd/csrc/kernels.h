@@ -23,6 +23,7 @@ struct ScoreArgs {
   SurvRec* rec;           // [grid * 8 waves][rec_cap] wave-private survivor records of this launch
   uint32_t* rec_cnt;      // [grid * 8]
   uint32_t rec_cap;
+  unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);

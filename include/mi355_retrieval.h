@@ -138,6 +138,10 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
  * "force_exact" (score with the f32 kernel instead of bf16 MFMA). */
 int mi_set_option(mi_gallery* g, const char* name, double value);
 
+/* Diagnostics only: per-wave cycle sums written by the stamped build of the scoring kernel (option "debug"=8);
+ * layout [workgroups*8][8] = {load, barrier1, mfma, barrier2, epilogue, slices, -, -}. */
+int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count);
+
 /* ---- synthetic data (bench / tests): device twin of synth.synth_rows. */
 int mi_synth_fill_device(float* dst_dev, uint64_t seed, int64_t row0, int64_t nrows, int32_t d,
                          void* stream);
