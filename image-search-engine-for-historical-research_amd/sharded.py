@@ -30,9 +30,11 @@ def all_gather_stacked(t, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+    t = t.contiguous()
+    # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [world, ...]
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.view((world,) + tuple(t.shape))
 
 
 class ShardedGallery:

@@ -1,0 +1,28 @@
+"""CPU: the build's own mAP implementation against the oracle (pinned by the reference goldens)."""
+import os
+
+import numpy as np
+
+import oracle
+from isehr_amd import evaluate
+from isehr_amd.synth import planted_dataset
+
+
+def test_map_matches_oracle_and_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "map.npz"))
+    vecs, qv, gnd = planted_dataset(41, 1200, 64, 12)
+    rk = np.argsort(-(vecs.T @ qv), axis=0)
+    for name, r in (("full", rk), ("top100", rk[:100])):
+        got = evaluate.compute_map_revisited(r, gnd)
+        assert np.allclose(got, z[f"{name}_map_EMH"], rtol=0, atol=1e-12)
+        assert np.allclose(got, oracle.compute_map_revisited(r, gnd), rtol=0, atol=1e-12)
+
+
+def test_map_edge_cases():
+    # a query without positives is skipped; junk before a positive shifts it up
+    ranks = np.array([[3, 0], [1, 1], [2, 2], [0, 3]])
+    gnd = [{"ok": np.array([2]), "junk": np.array([3, 1])}, {"ok": np.array([], dtype=int), "junk": np.array([])}]
+    mp, aps = evaluate.compute_map(ranks, gnd)
+    assert mp == 1.0 and np.isnan(aps[1])          # positive 2 sits behind two junk entries -> rank 0
+    mo, _ = oracle.compute_map2(ranks, gnd)
+    assert mo == mp

