@@ -59,6 +59,13 @@ SIGNATURES = {
                                        C.c_void_p]),
     "mi_aqe_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
                                 C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_knn_dense_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
+                                      C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_diffusion_offline": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mi_diffusion_online": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
@@ -204,6 +211,50 @@ class Gallery:
                                        sc.ctypes.data_as(C.c_void_p),
                                        qx.ctypes.data_as(C.c_void_p) if return_qexp else None, C.byref(secs)))
         return idx, sc, qx, secs.value
+
+    def dense_search(self, queries, k):
+        """Exact f32 inner-product top-k for large k (k <= 4096): -> (idx [Q,k], scores [Q,k], seconds)."""
+        a, code, rs, cs = _strided(queries)
+        if a.shape[1] != self.d:
+            raise ValueError("query dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        nq = a.shape[0]
+        idx = np.empty((nq, k), dtype=np.int64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        secs = C.c_double()
+        with self._lock:
+            check(load().mi_knn_dense_search(self._h, C.c_void_p(_base_pointer(a)), nq, code, rs, cs, k,
+                                             idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                             C.byref(secs)))
+        return idx, sc, secs.value
+
+    def diffusion_offline(self, n_trunc, kd, alpha=0.99, gamma=3, maxiter=20, tol=1e-6, return_sims=False):
+        """-> (ids int64 [N,n_trunc], vals float32 [N,n_trunc][, knn sims float32 [N,n_trunc]])."""
+        ids = np.empty((self.n, n_trunc), dtype=np.int64)
+        vals = np.empty((self.n, n_trunc), dtype=np.float32)
+        sims = np.empty((self.n, n_trunc), dtype=np.float32) if return_sims else None
+        with self._lock:
+            check(load().mi_diffusion_offline(self._h, n_trunc, kd, float(alpha), gamma, maxiter, float(tol),
+                                              ids.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                              sims.ctypes.data_as(C.c_void_p) if return_sims else None))
+        return (ids, vals, sims) if return_sims else (ids, vals)
+
+    def diffusion_set_offline(self, ids, vals):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.float32)
+        with self._lock:
+            check(load().mi_diffusion_set_offline(self._h, ids.ctypes.data_as(C.c_void_p),
+                                                  vals.ctypes.data_as(C.c_void_p), ids.shape[1]))
+
+    def diffusion_online(self, queries, k_query=3, gamma=3, trunc=2000):
+        """-> (ranks int64 [Q,trunc], scores float32 [Q,trunc])."""
+        a, code, rs, cs = _strided(queries)
+        nq = a.shape[0]
+        ranks = np.empty((nq, trunc), dtype=np.int64)
+        sc = np.empty((nq, trunc), dtype=np.float32)
+        with self._lock:
+            check(load().mi_diffusion_online(self._h, C.c_void_p(_base_pointer(a)), nq, code, rs, cs, k_query, gamma,
+                                             trunc, ranks.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
+        return ranks, sc
 
     def get_rows(self, row0, nrows):
         out = np.empty((nrows, self.d), dtype=np.float32)

@@ -77,6 +77,10 @@ struct mi_gallery {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   hipStream_t ev_stream = nullptr;
+  // diffusion state (offline matrix rows kept on the device for the online stage)
+  int32_t* dif_ids = nullptr;
+  float* dif_vals = nullptr;
+  int32_t dif_T = 0;
   std::mutex mu;
 };
 
@@ -324,6 +328,8 @@ int mi_gallery_destroy(mi_gallery* g) {
   (void)hipFree(g->gal_bf16);
   (void)hipFree(g->rowstat);
   (void)hipFree(g->gstat3);
+  (void)hipFree(g->dif_ids);
+  (void)hipFree(g->dif_vals);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
   return MI_OK;
@@ -703,6 +709,191 @@ int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, in
   if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return done(MI_OK);
 }
+
+}  // extern "C"
+
+// ---- dense exact kNN (k a large fraction of N) and truncated graph diffusion ---------------------------------------
+namespace {
+struct TmpAlloc {
+  std::vector<void*> v;
+  ~TmpAlloc() { for (void* p : v) (void)hipFree(p); }
+  template <typename T> T* get(size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, count * sizeof(T) + 256) != hipSuccess) return nullptr;
+    v.push_back(p);
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+// exact f32 inner products of every stored row with nq (device, strided) queries -> top-k, all on `s`
+int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm, int64_t nq,
+                        int32_t k, int64_t* out_idx_dev, float* out_score_dev, hipStream_t s) {
+  REQUIRE(k >= 1 && (int64_t)k <= g->n, "k must be in [1, N]");
+  REQUIRE(k <= 4096, "dense top-k supports k <= 4096");
+  int rc = ws_ensure(g, std::min<int32_t>(k, 1024));
+  if (rc != MI_OK) return rc;
+  Workspace& ws = g->ws;
+  int64_t qb = std::min<int64_t>(QB, std::max<int64_t>(64, ((int64_t)1 << 28) / g->n / 64 * 64));
+  TmpAlloc tmp;
+  float* dense = tmp.get<float>((size_t)qb * g->n);
+  if (!dense) return fail(MI_ERR_NOMEM, "dense score buffer");
+  const size_t esz = q_dtype == MI_F32 ? 4 : 8;
+  for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+    const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
+    const int32_t qpad = (int32_t)round_up(b, TILE);
+    launch_ingest((const char*)q_src + (size_t)q0 * rs * esz, q_dtype, b, g->d, rs, cs, q_norm, ws.q_f32, ws.q_bf16,
+                  ws.q_stat, g->dp, qpad, s);
+    ExactArgs a;
+    a.gal_f32 = g->gal_f32;
+    a.qry_f32 = ws.q_f32;
+    a.dp = g->dp;
+    a.row0 = 0;
+    a.row1 = g->n;
+    a.n = g->n;
+    a.nq = b;
+    a.st = make_state(ws);
+    a.dense_out = dense;
+    a.dense_ld = g->n;
+    launch_exact_select(a, false, s);
+    launch_dense_topk(dense, g->n, g->n, b, k, g->row_offset, out_idx_dev + q0 * k,
+                      out_score_dev ? out_score_dev + q0 * k : nullptr, s);
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipStreamSynchronize(s));      // `dense` is freed on return
+  return MI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                        int32_t k, int64_t* out_idx, float* out_score, double* out_seconds) {
+  REQUIRE(g && q && out_idx, "null pointer");
+  REQUIRE(nq >= 1, "no queries");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int64_t elems;
+  int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  char* qd = tmp.get<char>((size_t)elems * esz);
+  int64_t* idx_d = tmp.get<int64_t>((size_t)nq * k);
+  float* sc_d = tmp.get<float>((size_t)nq * k);
+  if (!qd || !idx_d || !sc_d) return fail(MI_ERR_NOMEM, "dense search buffers");
+  HIPC(hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice));
+  if ((rc = dense_search_device(g, qd, dtype, row_stride, col_stride, g->norm_mode, nq, k, idx_d, sc_d, g->stream)) != MI_OK)
+    return rc;
+  HIPC(hipMemcpy(out_idx, idx_d, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+  if (out_score) HIPC(hipMemcpy(out_score, sc_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return MI_OK;
+}
+
+int mi_diffusion_offline(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma, int32_t maxiter,
+                         double tol, int64_t* out_ids, float* out_vals, float* out_knn_sims) {
+  REQUIRE(g, "null handle");
+  REQUIRE(n_trunc >= 2 && (int64_t)n_trunc <= g->n && n_trunc <= 4096, "n_trunc must be in [2, min(N, 4096)]");
+  REQUIRE(kd >= 1 && kd <= n_trunc, "kd must be in [1, n_trunc]");
+  REQUIRE(g->n < ((int64_t)1 << 31), "too many rows");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  hipStream_t s = g->stream;
+  const int64_t n = g->n;
+  const int32_t T = n_trunc;
+  TmpAlloc tmp;
+  int64_t* ids = tmp.get<int64_t>((size_t)n * T);
+  float* sims = tmp.get<float>((size_t)n * T);
+  float* lap = tmp.get<float>((size_t)n * kd);
+  float* dinv = tmp.get<float>((size_t)n);
+  float* diag = tmp.get<float>((size_t)n);
+  const unsigned grid = 512;
+  int32_t* map_all = tmp.get<int32_t>((size_t)grid * n);
+  if (!ids || !sims || !lap || !dinv || !diag || !map_all) return fail(MI_ERR_NOMEM, "diffusion buffers");
+  // 1) kNN graph: the stored rows against themselves, exact inner product, top n_trunc (knn.search(features, n_trunc))
+  int rc = dense_search_device(g, g->gal_f32, MI_F32, g->dp, 1, MI_NORM_NONE, n, T, ids, sims, s);
+  if (rc != MI_OK) return rc;
+  // 2) mutual-kNN affinity on the first kd columns, normalised Laplacian
+  launch_affinity(ids, sims, T, n, kd, gamma, (float)alpha, lap, dinv, diag, s);
+  // 3) truncated CG per node
+  HIPC(hipMemsetAsync(map_all, 0xFF, (size_t)grid * n * 4, s));
+  (void)hipFree(g->dif_ids);
+  (void)hipFree(g->dif_vals);
+  g->dif_ids = nullptr;
+  g->dif_vals = nullptr;
+  HIPC(hipMalloc((void**)&g->dif_ids, (size_t)n * T * 4));
+  HIPC(hipMalloc((void**)&g->dif_vals, (size_t)n * T * 4));
+  g->dif_T = T;
+  launch_diffusion_cg(ids, T, n, T, kd, lap, diag, maxiter, tol, map_all, grid, g->dif_ids, g->dif_vals, s);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(s));
+  if (out_ids) HIPC(hipMemcpy(out_ids, ids, (size_t)n * T * 8, hipMemcpyDeviceToHost));
+  if (out_vals) HIPC(hipMemcpy(out_vals, g->dif_vals, (size_t)n * T * 4, hipMemcpyDeviceToHost));
+  if (out_knn_sims) HIPC(hipMemcpy(out_knn_sims, sims, (size_t)n * T * 4, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_diffusion_set_offline(mi_gallery* g, const int64_t* ids, const float* vals, int32_t n_trunc) {
+  REQUIRE(g && ids && vals && n_trunc >= 1, "bad arguments");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const size_t cnt = (size_t)g->n * n_trunc;
+  std::vector<int32_t> ids32(cnt);
+  for (size_t i = 0; i < cnt; ++i) {
+    if (ids[i] < 0 || ids[i] >= g->n) return fail(MI_ERR_INVALID, "offline id outside the gallery");
+    ids32[i] = (int32_t)ids[i];
+  }
+  (void)hipFree(g->dif_ids);
+  (void)hipFree(g->dif_vals);
+  g->dif_ids = nullptr;
+  g->dif_vals = nullptr;
+  HIPC(hipMalloc((void**)&g->dif_ids, cnt * 4));
+  HIPC(hipMalloc((void**)&g->dif_vals, cnt * 4));
+  HIPC(hipMemcpy(g->dif_ids, ids32.data(), cnt * 4, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(g->dif_vals, vals, cnt * 4, hipMemcpyHostToDevice));
+  g->dif_T = n_trunc;
+  return MI_OK;
+}
+
+int mi_diffusion_online(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                        int32_t k_query, int32_t gamma, int32_t trunc, int64_t* out_ranks, float* out_scores) {
+  REQUIRE(g && q && out_ranks, "null pointer");
+  REQUIRE(g->dif_ids && g->dif_vals, "no offline diffusion result on this handle");
+  REQUIRE(nq >= 1 && k_query >= 1 && (int64_t)k_query <= g->n, "bad sizes");
+  REQUIRE(trunc >= 1 && (int64_t)trunc < g->n && trunc <= 4096, "trunc must be in [1, min(N-1, 4096)] (np.argpartition needs kth < N)");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  hipStream_t s = g->stream;
+  int64_t elems;
+  int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  char* qd = tmp.get<char>((size_t)elems * esz);
+  int64_t* nn_idx = tmp.get<int64_t>((size_t)nq * k_query);
+  float* nn_sims = tmp.get<float>((size_t)nq * k_query);
+  float* dense = tmp.get<float>((size_t)nq * g->n);
+  int64_t* ranks_d = tmp.get<int64_t>((size_t)nq * trunc);
+  float* sc_d = tmp.get<float>((size_t)nq * trunc);
+  if (!qd || !nn_idx || !nn_sims || !dense || !ranks_d || !sc_d) return fail(MI_ERR_NOMEM, "diffusion online buffers");
+  HIPC(hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice));
+  // knn.search(q, k_query): exact top-k_query by inner product (the queries are used as given)
+  if ((rc = search_sync(g, qd, dtype, row_stride, col_stride, MI_NORM_NONE, nq, k_query, nn_idx, nn_sims, nullptr)) != MI_OK)
+    return rc;
+  launch_diffusion_combine(nn_idx, nn_sims, k_query, gamma, g->dif_ids, g->dif_vals, g->dif_T, g->n, (int32_t)nq, dense, s);
+  launch_dense_topk(dense, g->n, g->n, (int32_t)nq, trunc, 0, ranks_d, sc_d, s);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipMemcpy(out_ranks, ranks_d, (size_t)nq * trunc * 8, hipMemcpyDeviceToHost));
+  if (out_scores) HIPC(hipMemcpy(out_scores, sc_d, (size_t)nq * trunc * 4, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- status / options ------------------------------------------------------------------------------
 int mi_profile_enable(mi_gallery* g, int on) {

@@ -7,8 +7,10 @@
 
 namespace mi {
 
-template <bool FIRST>
+// MODE 0: threshold filter, 1: bootstrap chunk (packed store-all), 2: dense -- every score to dense_out[q * ld + row]
+template <int MODE>
 __global__ __launch_bounds__(256) void exact_select_kernel(ExactArgs p) {
+  constexpr bool FIRST = (MODE == 1);
   __shared__ float As[16][68];
   __shared__ float Bs[16][68];
   const int t = threadIdx.x;
@@ -47,13 +49,15 @@ __global__ __launch_bounds__(256) void exact_select_kernel(ExactArgs p) {
   for (int j = 0; j < 4; ++j) {
     const uint32_t q = (uint32_t)(q0 + tx * 4 + j);
     if (q >= (uint32_t)p.nq) continue;
-    const float thr = FIRST ? -INFINITY : p.st.thr[q];
+    const float thr = (MODE != 0) ? -INFINITY : p.st.thr[q];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t row = row0 + ty * 4 + i;
       if (row >= p.row1) continue;
       const float v = acc[i][j];
-      if (FIRST) {
+      if (MODE == 2) {
+        p.dense_out[(uint64_t)q * p.dense_ld + (uint64_t)row] = v;
+      } else if (FIRST) {
         p.st.surv[(uint64_t)q * p.st.cap + (uint64_t)row] = pack_entry(v, (uint32_t)row);
       } else if (v >= thr) {
         const uint32_t pos = atomicAdd(&p.st.cnt[q * CNT_STRIDE], 1u);
@@ -69,8 +73,9 @@ void launch_exact_select(const ExactArgs& a, bool first, hipStream_t stream) {
   if (rows <= 0) return;
   const int qpad64 = (int)round_up(a.nq, 64);
   dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(qpad64 / 64));
-  if (first) hipLaunchKernelGGL(exact_select_kernel<true>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(exact_select_kernel<false>, grid, dim3(256), 0, stream, a);
+  if (a.dense_out) hipLaunchKernelGGL(exact_select_kernel<2>, grid, dim3(256), 0, stream, a);
+  else if (first) hipLaunchKernelGGL(exact_select_kernel<1>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(exact_select_kernel<0>, grid, dim3(256), 0, stream, a);
 }
 
 }  // namespace mi

@@ -41,6 +41,8 @@ struct ExactArgs {
   int64_t n;
   int32_t nq;
   QueryState st;
+  float* dense_out = nullptr;   // non-null: dense mode, scores to dense_out[q * dense_ld + row]
+  int64_t dense_ld = 0;
 };
 void launch_exact_select(const ExactArgs& a, bool first, hipStream_t stream);
 
@@ -62,6 +64,20 @@ void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, 
                             hipStream_t stream);
 void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k,
                   int64_t* out_idx, float* out_score, hipStream_t stream);
+
+// dense.hip -- exact top-k of dense score rows (global-memory radix select + LDS bitonic sort), k <= 4096
+void launch_dense_topk(const float* scores, int64_t ld, int64_t n, int32_t nq, int32_t k, int64_t row_offset,
+                       int64_t* out_idx, float* out_score, hipStream_t stream);
+
+// diffusion.hip
+void launch_affinity(const int64_t* ids, const float* sims, int64_t ld, int64_t n, int32_t kd, int32_t gamma,
+                     float alpha, float* lap, float* dinv, float* diag, hipStream_t stream);
+void launch_diffusion_cg(const int64_t* ids, int64_t ld, int64_t n, int32_t T, int32_t kd, const float* lap,
+                         const float* diag, int32_t maxiter, double tol, int32_t* map_all, unsigned grid,
+                         int32_t* out_ids, float* out_vals, hipStream_t stream);
+void launch_diffusion_combine(const int64_t* nn_idx, const float* nn_sims, int32_t kq, int32_t gamma,
+                              const int32_t* off_ids, const float* off_vals, int32_t T, int64_t n, int32_t nq,
+                              float* dense, hipStream_t stream);
 
 // aqe.hip
 void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,

@@ -1,0 +1,60 @@
+"""Counterpart of src/test_rOP1m.py:99-168 for pre-extracted (or synthetic) descriptors:
+match (HIP), print the average matching time and mAP, then QGE re-ranking.
+
+  python -m isehr_amd.entry.test_rOP1m --datasets roxford5k --ifextracted --mode 100
+  python -m isehr_amd.entry.test_rOP1m --synthetic 20000 --mode 100          (no files needed)
+"""
+import argparse
+import pickle
+
+import numpy as np
+
+from .. import evaluate
+from ..nnsearch import matching_HIP
+from ..reranking import QGE_hip
+from ..synth import planted_dataset
+from .features import load_path_features
+
+parser = argparse.ArgumentParser(description="Retrieval test (HIP exhaustive matcher)")
+parser.add_argument("--datasets", "-d", default="roxford5k,rparis6k")
+parser.add_argument("--ifextracted", action="store_true", help="kept for CLI parity; features are always read")
+parser.add_argument("--include1m", action="store_true", help="append outputs/features/revisitop1m_path_feature.pkl")
+parser.add_argument("--mode", default="100", help="'mAP' (rank as deep as the HIP path allows) or top-K as int")
+parser.add_argument("--gnd-dir", default="data/test")
+parser.add_argument("--synthetic", type=int, default=0, help="use a planted synthetic dataset with this many rows")
+parser.add_argument("--dim", type=int, default=2048)
+parser.add_argument("--gpu-id", "-g", default="0")
+
+
+def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0):
+    n = vecs.shape[1]
+    K = min(n, 2048) if mode == "mAP" else int(mode)      # full-length ranking: SURVEY.md §8 f-3
+    match_idx, time_per_query = matching_HIP(K, vecs.T, qvecs.T, device=device)
+    ranks = match_idx.T
+    print(">> {}: average matching time: {}".format(dataset, time_per_query))
+    res = {"map": evaluate.compute_map_and_print(dataset, ranks, gnd)}
+    res["qge"] = QGE_hip(ranks, qvecs, vecs, dataset, gnd, K=K, device=device)
+    return res
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    dev = int(args.gpu_id)
+    if args.synthetic:
+        vecs, qvecs, gnd = planted_dataset(1234, args.synthetic, args.dim, 70)
+        run_dataset("roxford5k-synthetic", vecs, qvecs, gnd, args.mode, dev)
+        return 0
+    for dataset in args.datasets.split(","):
+        vecs, _ = load_path_features(dataset + "_db")
+        qvecs, _ = load_path_features(dataset + "_query")
+        if args.include1m:
+            v1m, _ = load_path_features("revisitop1m")
+            vecs = np.concatenate([vecs, v1m], axis=1)
+        with open("{}/{}/gnd_{}.pkl".format(args.gnd_dir, dataset, dataset), "rb") as f:
+            gnd = pickle.load(f)["gnd"]
+        run_dataset(dataset, vecs, qvecs, gnd, args.mode, dev)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -120,6 +120,27 @@ int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, in
                   int64_t nq, int32_t k_qe, double w, double eps, int32_t k, int64_t* out_idx,
                   float* out_score, double* out_qexp, double* out_seconds);
 
+/* ---- dense exact kNN: faiss IndexFlatIP.search (src/utils/knn.py:25-31) when k is a large fraction of N (the kNN
+ * graph of the diffusion, src/utils/diffusion.py:66).  Exact f32 inner products (k-ordered fmaf chain) of all
+ * stored rows, top-k by (score desc, idx asc), k <= 4096. */
+int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride,
+                        int64_t col_stride, int32_t k, int64_t* out_idx, float* out_score,
+                        double* out_seconds);
+
+/* ---- truncated graph diffusion: Diffusion.get_offline_results (src/utils/diffusion.py:52-84 with :15-19, :87-116)
+ * on a MI_NORM_NONE gallery of the features.  out_ids [n][n_trunc] (the kNN lists = columns of the sparse
+ * `offline` matrix), out_vals [n][n_trunc] f32 (its values), out_knn_sims (may be NULL).  The result also stays
+ * on the device for mi_diffusion_online. */
+int mi_diffusion_offline(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma,
+                         int32_t maxiter, double tol, int64_t* out_ids, float* out_vals, float* out_knn_sims);
+/* Re-installs a cached offline result (the reference caches it as offline.jbl, src/utils/diffusion.py:21-40). */
+int mi_diffusion_set_offline(mi_gallery* g, const int64_t* ids, const float* vals, int32_t n_trunc);
+/* Online stage (src/utils/Reranking.py:238-253): top-k_query neighbours of each query, sims**gamma, weighted sum of
+ * their offline rows, top-`trunc` ranks [nq][trunc] (score desc, idx asc) and scores. */
+int mi_diffusion_online(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride,
+                        int64_t col_stride, int32_t k_query, int32_t gamma, int32_t trunc,
+                        int64_t* out_ranks, float* out_scores);
+
 /* ---- status / instrumentation */
 typedef struct mi_search_stats {
   int64_t searches;           /* query batches processed */
