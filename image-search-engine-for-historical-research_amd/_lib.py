@@ -66,6 +66,8 @@ SIGNATURES = {
     "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mi_diffusion_online": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_whiten_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_double, C.c_int, C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
@@ -313,6 +315,18 @@ def aqe_finish_device(sum_ptr, nq, d, eps, out_q_ptr, out_q64_ptr=None, stream=N
 
 def synth_fill_device(dst_ptr, seed, row0, nrows, d, stream=None):
     check(load().mi_synth_fill_device(C.c_void_p(dst_ptr), seed, row0, nrows, d, C.c_void_p(stream)))
+
+
+def whiten_apply(rows, m, P, dims, eps=1e-6, device=0):
+    """rows [N,D] (any strides) -> float64 [N,dims] = rows of P[:dims] (x - m) / (||.|| + eps)."""
+    a, code, rs, cs = _strided(rows)
+    m = np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(-1))
+    Pd = np.ascontiguousarray(np.asarray(P, dtype=np.float64)[:dims, :])
+    out = np.empty((a.shape[0], dims), dtype=np.float64)
+    check(load().mi_whiten_apply(C.c_void_p(_base_pointer(a)), a.shape[0], a.shape[1], code, rs, cs,
+                                 m.ctypes.data_as(C.c_void_p), Pd.ctypes.data_as(C.c_void_p), dims, float(eps), device,
+                                 out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def device_count():

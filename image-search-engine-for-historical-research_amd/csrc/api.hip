@@ -792,6 +792,32 @@ int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int
   return MI_OK;
 }
 
+int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
+                    const double* m, const double* P, int32_t dims, double eps, int device, double* out) {
+  REQUIRE(X && m && P && out, "null pointer");
+  REQUIRE(n >= 1 && d >= 1 && dims >= 1 && dims <= d, "bad sizes (dims must be in [1, d])");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  HIPC(hipSetDevice(device));
+  int64_t elems;
+  int rc = strided_extent(n, d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  char* xd = tmp.get<char>((size_t)elems * esz);
+  double* md = tmp.get<double>((size_t)d);
+  double* pd = tmp.get<double>((size_t)dims * d);
+  double* yd = tmp.get<double>((size_t)n * dims);
+  if (!xd || !md || !pd || !yd) return fail(MI_ERR_NOMEM, "whiten buffers");
+  HIPC(hipMemcpy(xd, X, (size_t)elems * esz, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(md, m, (size_t)d * 8, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(pd, P, (size_t)dims * d * 8, hipMemcpyHostToDevice));
+  launch_whiten(xd, dtype, n, d, row_stride, col_stride, md, pd, dims, eps, yd, nullptr);
+  HIPC(hipGetLastError());
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpy(out, yd, (size_t)n * dims * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
 int mi_diffusion_offline(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma, int32_t maxiter,
                          double tol, int64_t* out_ids, float* out_vals, float* out_knn_sims) {
   REQUIRE(g, "null handle");

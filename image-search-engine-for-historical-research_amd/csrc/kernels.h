@@ -79,6 +79,10 @@ void launch_diffusion_combine(const int64_t* nn_idx, const float* nn_sims, int32
                               const int32_t* off_ids, const float* off_vals, int32_t T, int64_t n, int32_t nq,
                               float* dense, hipStream_t stream);
 
+// whiten.hip
+void launch_whiten(const void* X, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, const double* m,
+                   const double* P, int32_t dims, double eps, double* Y, hipStream_t stream);
+
 // aqe.hip
 void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,
                         const int64_t* ranks, int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, double w,

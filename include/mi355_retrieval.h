@@ -141,6 +141,13 @@ int mi_diffusion_online(mi_gallery* g, const void* q, int64_t nq, int dtype, int
                         int64_t col_stride, int32_t k_query, int32_t gamma, int32_t trunc,
                         int64_t* out_ranks, float* out_scores);
 
+/* ---- whitenapply (src/utils/whiten.py:4-12): out[n][dims] = P[:dims] (x_n - m), rows divided by (||.|| + eps)
+ * (eps < 0: no normalisation).  X: n images x d, strided (the reference's [D,N] array is passed with
+ * row_stride 1, col_stride N); m f64 [d]; P f64 row-major [dims][d] (the first dims rows of the reference's P).
+ * float64 arithmetic like the reference. */
+int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
+                    const double* m, const double* P, int32_t dims, double eps, int device, double* out);
+
 /* ---- status / instrumentation */
 typedef struct mi_search_stats {
   int64_t searches;           /* query batches processed */

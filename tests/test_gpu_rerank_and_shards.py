@@ -192,3 +192,21 @@ def test_planted_dataset_map_end_to_end():
     ranks = idx.T
     ref = oracle.matching_l2(300, vecs.T, qv.T).T
     assert np.allclose(evaluate.compute_map_revisited(ranks, gnd), oracle.compute_map_revisited(ref, gnd), atol=1e-6)
+
+
+def test_whitenapply_golden(golden_dir):
+    """a8: P[:dims] @ (X - m) with the eps-normalisation, float64, against the reference's own output."""
+    from isehr_amd.whiten import whitenapply_hip
+    z = np.load(os.path.join(golden_dir, "normalise.npz"))
+    X = synth_rows(32, 0, 40, 24, np.float64).T.copy()
+    m = X.mean(axis=1, keepdims=True)
+    P = synth_rows(33, 0, 24, 24, np.float64)
+    assert np.abs(whitenapply_hip(X, m, P) - z["whiten"]).max() < 1e-12
+    assert np.abs(whitenapply_hip(X, m, P, 16) - z["whiten16"]).max() < 1e-12
+    # a bigger float32 case against the oracle
+    Xb = synth_rows(34, 0, 700, 300).T.copy()
+    mb = Xb.mean(axis=1, keepdims=True).astype(np.float64)
+    Pb = synth_rows(35, 0, 300, 300, np.float64) / 17.0
+    got = whitenapply_hip(Xb, mb, Pb, 200)
+    ref = oracle.whitenapply(Xb.astype(np.float64), mb, Pb, 200)
+    assert got.shape == (200, 700) and np.abs(got - ref).max() < 1e-12
