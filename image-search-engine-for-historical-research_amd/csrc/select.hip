@@ -204,16 +204,15 @@ void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_
 
 // ------------------------------------------------------------------------------------------------
 // exact re-score: s = sum_k g[k] * q[k] with f32 inputs, exact f64 products and f64 accumulation
-// (HBM-bound gather of 4*dp bytes per candidate row).  One wave per row, two rows per wave iteration, 32 rows
-// per workgroup (a 4-rows-per-iteration / 64-rows-per-workgroup form measured 1.6x slower at 112 VGPRs).
-constexpr int RESCORE_ROWS_PER_WG = 32;
+// (HBM-bound gather of 4*dp bytes per candidate row).  One wave per row, two rows per wave pass.
 
+template <int UNROLL, int ROWS_PER_WG>
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
                                                       int32_t dp, const uint32_t* __restrict__ cand_rows,
                                                       const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
                                                       double* __restrict__ cand_score) {
   const uint32_t q = blockIdx.y;
-  const uint32_t c0 = blockIdx.x * RESCORE_ROWS_PER_WG;
+  const uint32_t c0 = blockIdx.x * ROWS_PER_WG;
   const uint32_t nc = cand_cnt[q];
   if (c0 >= nc) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -221,12 +220,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
   const int nvec = dp >> 2;            // float4 per row (dp is a multiple of 64 -> nvec multiple of 16)
   const uint32_t* rows = cand_rows + (uint64_t)q * rcap;
   double* outs = cand_score + (uint64_t)q * rcap;
-  const uint32_t cend = min(nc, c0 + RESCORE_ROWS_PER_WG);
+  const uint32_t cend = min(nc, c0 + ROWS_PER_WG);
   for (uint32_t c = c0 + w * 2; c < cend; c += 8) {
     const bool two = (c + 1 < cend);
     const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
     const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
     double a0 = 0.0, a1 = 0.0;
+#pragma unroll UNROLL
     for (int v = lane; v < nvec; v += 64) {
       const float4 x = qv[v];
       const float4 y0 = g0[v];
@@ -247,11 +247,15 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
   }
 }
 
+// 8 rows per workgroup: every wave makes exactly one 2-row pass.  Measured on 1024 x ~358 candidate rows of 8 KiB:
+// 590 us (5.1 TB/s) vs 977 us with 32 rows per workgroup; the unroll factor of the column loop does not matter.
+constexpr int RESCORE_ROWS_PER_WG = 8;
+
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                     const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
-  dim3 grid((rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG, nq);
-  hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, stream, gal_f32, qry_f32, dp, cand_rows, cand_cnt, rcap,
-                     cand_score);
+  hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>),
+                     dim3((rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG, nq), dim3(256), 0, stream, gal_f32,
+                     qry_f32, dp, cand_rows, cand_cnt, rcap, cand_score);
 }
 
 // ------------------------------------------------------------------------------------------------
