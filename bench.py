@@ -87,13 +87,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ISEHR_DIST_BACKEND=gloo + ISEHR_SHARE_GPU=1: rehearsal of the multi-rank flow with all ranks on one GPU
+    # (RCCL refuses two ranks on one device); the real run is one rank per GPU over RCCL.
+    backend = os.environ.get("ISEHR_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("ISEHR_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     n_total = args.rows or WORKLOADS[args.workload][0]
     d, nq, k = args.dim, args.queries, args.topk
     lo, hi = shard_bounds(n_total, world, rank)
@@ -104,7 +109,7 @@ def main():
     _lib.synth_fill_device(raw.data_ptr(), args.seed, lo, hi - lo, d, stream)
     torch.cuda.synchronize()
     t0 = time.time()
-    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=local_rank,
+    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=dev_index,
                                        row_offset=lo)
     ingest_s = time.time() - t0
     del raw

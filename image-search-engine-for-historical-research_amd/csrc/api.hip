@@ -194,10 +194,11 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   const uint32_t first_cnt = (uint32_t)std::min<int64_t>(g->n, t0 * TILE);
   const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
   launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
-  // chunk boundaries (cumulative tiles): t0, t0*g, t0*g*max(2,g/2), then everything that is left
+  // chunk boundaries (cumulative tiles): t0, t0*g, then x max(2, g/2) per step (thresholds keep tightening as the
+  // sample grows; a 10M-row shard needs more steps than a 1M-row one); a tail shorter than half a step is merged
   const int64_t gr = std::max(1, g->chunk_growth);
-  const int64_t bounds[3] = {t0, t0 * gr, t0 * gr * std::max<int64_t>(2, gr / 2)};
-  int bi = 0;
+  const int64_t gr2 = std::max<int64_t>(2, gr / 2);
+  int64_t bound = t0;
   int64_t t = 0, len = t0;
   bool first = true;
   while (t < ntiles) {
@@ -245,9 +246,13 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     const bool last = (t >= ntiles);
     launch_select_maintain(st, nq, k, last ? 1 : 0, ws.topvals, ws.L, ws.stats2, s);
     first = false;
-    ++bi;
-    len = (gr > 1 && bi < 3) ? std::max<int64_t>(1, bounds[bi] - t) : (ntiles - t);
-    if (gr == 1) len = t0;
+    if (gr == 1) {
+      len = t0;
+    } else {
+      bound = (bound == t0) ? t0 * gr : bound * gr2;
+      len = std::max<int64_t>(1, bound - t);
+      if (ntiles - (t + len) < len / 2) len = ntiles - t;
+    }
   }
   HIPC(hipGetLastError());
   return MI_OK;
