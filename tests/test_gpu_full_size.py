@@ -1,0 +1,102 @@
+"""GPU: BASELINE.json's full size (rOxford5k + 1M distractors: N = 1,005,994 x D = 2048, K = 100) through
+size-independent properties -- the oracle cannot run here.  Gallery rows are generated on the device."""
+import numpy as np
+import pytest
+
+from isehr_amd.synth import synth_rows
+
+pytestmark = pytest.mark.gpu
+N, D, K = 1005994, 2048, 100
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    from isehr_amd import _lib
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    raw = torch.empty((N, D), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), 1234, 0, N, D, s)
+    # plant: gallery rows 7, 500000 and N-1 are (scaled) copies of query rows 0, 1, 2
+    q = torch.from_numpy(synth_rows(4321, 0, 64, D)).to(dev)
+    raw[7] = q[0] * 3.0
+    raw[500000] = q[1] * 0.5
+    raw[N - 1] = q[2]
+    torch.cuda.synchronize()
+    g = _lib.Gallery.from_device_ptr(raw.data_ptr(), N, D)
+    half = (N + 1) // 2
+    g0 = _lib.Gallery.from_device_ptr(raw.data_ptr(), half, D, row_offset=0)
+    g1 = _lib.Gallery.from_device_ptr(raw[half:].data_ptr(), N - half, D, row_offset=half)
+    del raw
+    torch.cuda.empty_cache()
+    yield g, g0, g1, q
+    for h in (g, g0, g1):
+        h.close()
+
+
+def _search(g, q, nq):
+    import torch
+    idx = torch.empty((nq, K), dtype=torch.int64, device=q.device)
+    sc = torch.empty((nq, K), dtype=torch.float32, device=q.device)
+    g.search_device(q.data_ptr(), nq, K, idx.data_ptr(), sc.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), sc.cpu().numpy()
+
+
+def test_full_size_properties(big):
+    g, g0, g1, q = big
+    idx, sc = _search(g, q, 64)
+    assert g.status()["overflow_batches"] == 0
+    assert (np.diff(sc, axis=1) <= 0).all()                          # sorted
+    assert all(len(set(r)) == K for r in idx)                        # no duplicates
+    assert idx.min() >= 0 and idx.max() < N
+    # planted copies are the nearest neighbour, cosine 1 regardless of their scale
+    assert idx[0, 0] == 7 and idx[1, 0] == 500000 and idx[2, 0] == N - 1
+    assert np.abs(sc[:3, 0] - 1.0).max() < 1e-6
+    # random 2048-d unit vectors: 100th best cosine of 1M is ~3.7 sigma = 0.082
+    assert 0.07 < sc[5:, K - 1].mean() < 0.095
+    # determinism / idempotence
+    idx2, sc2 = _search(g, q, 64)
+    assert np.array_equal(idx, idx2) and np.array_equal(sc, sc2)
+    # the returned scores are exact: recompute 64 x 100 of them in float64 from the stored rows
+    qn = q.cpu().numpy().astype(np.float64)
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    for qi in (0, 9, 63):
+        rows = np.stack([g.get_rows(int(r), 1)[0] for r in idx[qi, :10]]).astype(np.float64)
+        assert np.abs(rows @ qn[qi] - sc[qi, :10]).max() < 3e-7
+
+
+def test_full_size_bf16_path_equals_exact_path(big):
+    """The MFMA bf16 filter + certificate must reproduce the f32-scored path bit for bit."""
+    g, _, _, q = big
+    idx, sc = _search(g, q, 16)
+    g.set_option("force_exact", 1)
+    try:
+        idx_e, sc_e = _search(g, q, 16)
+    finally:
+        g.set_option("force_exact", 0)
+    assert np.array_equal(idx, idx_e) and np.array_equal(sc, sc_e)
+
+
+def test_full_size_two_shards_equal_one(big):
+    import torch
+    from isehr_amd import _lib
+    g, g0, g1, q = big
+    nq = 64
+    ref_idx, ref_sc = _search(g, q, nq)
+    dev, s = q.device, torch.cuda.current_stream().cuda_stream
+    approx = torch.empty((2, nq, K), dtype=torch.float32, device=dev)
+    for r, sh in enumerate((g0, g1)):
+        sh.phase1_device(q.data_ptr(), nq, K, approx[r].data_ptr(), s)
+    L = torch.empty((nq,), dtype=torch.float32, device=dev)
+    _lib.kth_of_gathered_device(approx.data_ptr(), 2, nq, K, L.data_ptr(), s)
+    idx = torch.empty((2, nq, K), dtype=torch.int64, device=dev)
+    sc = torch.empty((2, nq, K), dtype=torch.float32, device=dev)
+    sc64 = torch.empty((2, nq, K), dtype=torch.float64, device=dev)
+    for r, sh in enumerate((g0, g1)):
+        sh.phase2_device(nq, K, L.data_ptr(), idx[r].data_ptr(), sc[r].data_ptr(), sc64[r].data_ptr(), s)
+    oi = torch.empty((nq, K), dtype=torch.int64, device=dev)
+    osc = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    _lib.topk_merge_device(sc64.data_ptr(), idx.data_ptr(), 2, nq, K, oi.data_ptr(), osc.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy(), ref_idx) and np.array_equal(osc.cpu().numpy(), ref_sc)
