@@ -509,7 +509,12 @@ static int read_and_clear_flags(mi_gallery* g, uint32_t* flags) {
   return MI_OK;
 }
 
-// synchronous search with overflow handling: bf16 pass, then (if buffers overflowed) the f32 pass
+static int dense_search_device_fwd(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm,
+                                   int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, hipStream_t s);
+
+// synchronous search with overflow handling: bf16 pass, then (if buffers overflowed) the f32-scored filter pass, then
+// (massive ties: thousands of rows within the margin of the K-th score) the dense path, which scores every row in f32
+// and breaks ties by index
 static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs, int64_t cs, int q_norm, int64_t nq,
                        int32_t k, int64_t* idx_dev, float* score_dev, double* score64_dev) {
   hipStream_t s = g->stream;
@@ -521,7 +526,13 @@ static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs
     const int64_t b = std::min<int64_t>(QB, nq - q0);
     const char* src = (const char*)q_dev + (size_t)q0 * rs * esz;
     bool exact = g->force_exact != 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      if (attempt == 2) {
+        if ((rc = dense_search_device_fwd(g, src, q_dtype, rs, cs, q_norm, b, k, idx_dev + q0 * k,
+                                          score_dev ? score_dev + q0 * k : nullptr, s)) != MI_OK)
+          return rc;
+        break;
+      }
       if ((rc = search_device(g, src, q_dtype, rs, cs, q_norm, b, k, idx_dev + q0 * k,
                               score_dev ? score_dev + q0 * k : nullptr,
                               score64_dev ? score64_dev + q0 * k : nullptr, exact, s)) != MI_OK)
@@ -531,6 +542,7 @@ static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs
       if ((rc = read_and_clear_flags(g, &flags)) != MI_OK) return rc;
       if (!flags) break;
       g->stats.overflow_batches += 1;
+      if (exact && g->exact_fallback && !score64_dev && k <= 4096) continue;      // -> dense path
       if (exact || !g->exact_fallback)
         return fail(MI_ERR_OVERFLOW,
                     "candidate buffers overflowed (more than survivor_cap / rescore_cap rows within the error margin "
@@ -768,6 +780,11 @@ int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t r
   return MI_OK;
 }
 }  // namespace
+
+static int dense_search_device_fwd(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm,
+                                   int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, hipStream_t s) {
+  return dense_search_device(g, q_src, q_dtype, rs, cs, q_norm, nq, k, out_idx_dev, out_score_dev, s);
+}
 
 extern "C" {
 

@@ -120,3 +120,24 @@ def test_synth_device_matches_host(lib):
     _lib.synth_fill_device(t.data_ptr(), 1234, 5, 37, 96, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(t.cpu().numpy(), synth_rows(1234, 5, 37, 96))
+
+
+def test_massive_ties_fall_through_to_the_dense_path(lib):
+    """3000 exact duplicates of the best match: more rows within the error margin of the K-th score than the
+    candidate buffers hold.  The host API must still answer (dense path: ties to the lower index)."""
+    from isehr_amd._lib import Gallery
+    n, d, k = 20000, 128, 100
+    g = synth_rows(61, 0, n, d)
+    dup = np.arange(500, 3500)
+    g[dup] = g[17]
+    q = np.stack([g[17], synth_rows(62, 0, 1, d)[0]])
+    G = Gallery.from_host(g)
+    idx, sc, _ = G.search(q, k)
+    st = G.status()
+    G.close()
+    assert st["overflow_batches"] >= 1                     # the filter paths did overflow
+    expect = np.sort(np.concatenate([[17], dup]))[:k]
+    assert np.array_equal(idx[0], expect)
+    assert np.abs(sc[0] - 1.0).max() < 1e-6
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
