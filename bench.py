@@ -26,7 +26,7 @@ WORKLOADS = {
     "roxford5k": (4993, "rOxford5k-sized synthetic gallery"),
     "10m": (10000000, "synthetic 10Mx2048 gallery"),
 }
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 = dense f16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=131072)
     ap.add_argument("--cpu-sample-queries", type=int, default=4)
     ap.add_argument("--option", action="append", default=[], help="name=value passed to mi_set_option")
+    ap.add_argument("--image-dtype", default="f16", choices=["f16", "bf16"],
+                    help="element type of the streamed 16-bit operand image (MFMA input type)")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -108,6 +110,7 @@ def main():
     raw = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
     _lib.synth_fill_device(raw.data_ptr(), args.seed, lo, hi - lo, d, stream)
     torch.cuda.synchronize()
+    _lib.set_global_option("image_dtype", 1 if args.image_dtype == "f16" else 0)
     t0 = time.time()
     gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=dev_index,
                                        row_offset=lo)
@@ -180,11 +183,11 @@ def main():
         out = {
             "metric": "queries/sec", "value": nq * args.steps / elapsed, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.image_dtype,
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
                        "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
-                       "parallelism": "row-shard x%d" % world, "exact": "bf16 MFMA filter + f64 re-score certificate",
+                       "parallelism": "row-shard x%d" % world, "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        "ingest_s": round(ingest_s, 3),
                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                        "survivors_per_query": st["survivors"] / max(1, st["queries"])},

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mi_debug_read_cycles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi_set_global_option": (C.c_int, [C.c_char_p, C.c_double]),
     "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
 }
 
@@ -327,6 +328,10 @@ def whiten_apply(rows, m, P, dims, eps=1e-6, device=0):
                                  m.ctypes.data_as(C.c_void_p), Pd.ctypes.data_as(C.c_void_p), dims, float(eps), device,
                                  out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def set_global_option(name, value):
+    check(load().mi_set_global_option(name.encode(), float(value)))
 
 
 def device_count():

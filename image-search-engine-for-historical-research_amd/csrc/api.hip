@@ -16,6 +16,7 @@
 using namespace mi;
 
 static thread_local std::string g_err;
+static int g_default_img_f16 = 1;   // mi_set_global_option("image_dtype", 0 = bf16 | 1 = fp16)
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -61,6 +62,7 @@ struct mi_gallery {
   int device = 0;
   int64_t n = 0, npad = 0, row_offset = 0;
   int32_t d = 0, dp = 0, norm_mode = 0;
+  int img_f16 = 1;          // 16-bit image element type of the gallery AND of the query batches searched on it
   float* gal_f32 = nullptr;
   void* gal_bf16 = nullptr;
   RowStat* rowstat = nullptr;
@@ -184,7 +186,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
                         int32_t nq, int32_t k, bool exact, hipStream_t s) {
   Workspace& ws = g->ws;
   const int32_t qpad = (int32_t)round_up(nq, TILE);
-  launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_bf16, ws.q_stat, g->dp, qpad, s);
+  launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_bf16, g->img_f16, ws.q_stat, g->dp, qpad, s);
   QueryState st = make_state(ws);
   const int64_t ntiles = g->npad / TILE;
   // bootstrap chunk: stored completely (no threshold yet); must hold >= K rows and fit the survivor buffer
@@ -219,6 +221,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       ScoreArgs a;
       a.gal_bf16 = g->gal_bf16;
       a.qry_bf16 = ws.q_bf16;
+      a.img_f16 = g->img_f16;
       a.nslices = g->dp / SLICE_K;
       a.tile0 = (int32_t)t;
       a.ntiles = (int32_t)cur;
@@ -389,11 +392,21 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
     if (e != hipSuccess) return cleanup(fail(MI_ERR_HIP, std::string("H2D copy: ") + hipGetErrorString(e)));
     src = staged;
   }
-  launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_bf16, g->rowstat, g->dp,
-                g->npad, g->stream);
-  launch_rowstat_max(g->rowstat, n, g->gstat3, g->stream);
-  hipError_t e = hipStreamSynchronize(g->stream);
-  if (e == hipSuccess) e = hipGetLastError();
+  g->img_f16 = g_default_img_f16;
+  hipError_t e = hipSuccess;
+  for (int pass = 0; pass < 2; ++pass) {
+    launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_bf16, g->img_f16, g->rowstat,
+                  g->dp, g->npad, g->stream);
+    launch_rowstat_max(g->rowstat, n, g->gstat3, g->stream);
+    e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess || !g->img_f16 || norm_mode != MI_NORM_NONE) break;
+    // raw (un-normalised) rows: fp16 only if they sit comfortably inside its range, otherwise re-ingest as bf16
+    float gs[3] = {0, 0, 0};
+    e = hipMemcpy(gs, g->gstat3, 12, hipMemcpyDeviceToHost);
+    if (e != hipSuccess || (gs[0] <= 4.0f && std::isfinite(gs[1]))) break;
+    g->img_f16 = 0;
+  }
   if (e != hipSuccess) return cleanup(fail(MI_ERR_HIP, std::string("ingest: ") + hipGetErrorString(e)));
   if (staged) (void)hipFree(staged);
   *out = g;
@@ -426,7 +439,7 @@ namespace {
 struct FileHeader {
   char magic[8];
   int64_t version, n, npad, row_offset;
-  int32_t d, dp, norm_mode, pad;
+  int32_t d, dp, norm_mode, img_f16;
 };
 int copy_dev_to_file(FILE* f, const void* dev, size_t bytes) {
   std::vector<char> buf(std::min<size_t>(bytes, (size_t)64 << 20));
@@ -462,6 +475,7 @@ int mi_gallery_save(const mi_gallery* g, const char* path) {
   h.d = g->d;
   h.dp = g->dp;
   h.norm_mode = g->norm_mode;
+  h.img_f16 = g->img_f16;
   int rc = MI_OK;
   if (fwrite(&h, sizeof h, 1, f) != 1) rc = fail(MI_ERR_IO, "short write");
   if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_f32, (size_t)g->n * g->dp * 4);
@@ -486,6 +500,7 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   g->n = h.n;
   g->d = h.d;
   g->norm_mode = h.norm_mode;
+  g->img_f16 = h.img_f16;
   g->row_offset = h.row_offset;
   int rc = gallery_alloc(g);
   if (rc == MI_OK && (g->dp != h.dp || g->npad != h.npad)) rc = fail(MI_ERR_IO, "inconsistent header");
@@ -759,7 +774,7 @@ int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t r
     const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
     const int32_t qpad = (int32_t)round_up(b, TILE);
     launch_ingest((const char*)q_src + (size_t)q0 * rs * esz, q_dtype, b, g->d, rs, cs, q_norm, ws.q_f32, ws.q_bf16,
-                  ws.q_stat, g->dp, qpad, s);
+                  g->img_f16, ws.q_stat, g->dp, qpad, s);
     ExactArgs a;
     a.gal_f32 = g->gal_f32;
     a.qry_f32 = ws.q_f32;
@@ -1001,6 +1016,14 @@ int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count) {
   HIPC(hipSetDevice(g->device));
   HIPC(hipDeviceSynchronize());
   HIPC(hipMemcpy(out_host, g->ws.dbg, (size_t)count * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_set_global_option(const char* name, double value) {
+  REQUIRE(name, "null");
+  const std::string n(name);
+  if (n == "image_dtype") g_default_img_f16 = value != 0;
+  else return fail(MI_ERR_INVALID, "unknown global option: " + n);
   return MI_OK;
 }
 

@@ -69,7 +69,7 @@ struct __attribute__((aligned(16))) SurvRec {
 };
 
 // sticky device-side flags
-enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u, FLAG_REC_OVERFLOW = 4u };
+enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u, FLAG_REC_OVERFLOW = 4u, FLAG_RANGE = 8u };
 
 constexpr uint32_t CNT_STRIDE = 32;   // one survivor counter per 128-byte line (atomics to one line serialise in L2)
 

@@ -22,12 +22,15 @@
 //    32 MFMAs of a slice, the other reads its fragments (12 ds_read_b128) -- the matrix pipe of every SIMD
 //    alternates between its two waves and stays busy;
 //  * the rings keep running across tile boundaries (no prologue/epilogue bubble per tile).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace mi {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -52,8 +55,9 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
-template <bool FIRST, int DBG>
+template <bool FIRST, int DBG, bool F16>
 __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
+  using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ring | record stage | thr[nqt * 256]  (ONE LDS object)
   float* thr_lds = reinterpret_cast<float*>(smem + RING_BYTES + STAGE_BYTES);
 
@@ -256,11 +260,11 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     const char* bbase = smem + b_rd * SLICE_BYTES;
     if (++a_rd == A_SLOTS) a_rd = 0;
     b_rd = (b_rd + 1) & (B_SLOTS - 1);
-    bf16x8 af[8], bfr[4];
+    frag_t af[8], bfr[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(bbase + b_off + nb * 1024);
+    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(abase + a_off + mb * 1024);
+    for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const frag_t*>(abase + a_off + mb * 1024);
     // DMA issue sits behind the 12 fragment reads: its ~60 cycles per piece overlap the LDS read latency instead
     // of stalling this wave's MFMAs (in the MFMA segment the partner wave cannot fill the matrix pipe).
     // group 0 issues A(S+4) into the slot of A(S-1), group 1 issues B(S+3) into the slot of B(S-1); both groups'
@@ -286,7 +290,10 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
       for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+          if constexpr (F16)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+          else
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
     } else {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) asm volatile("" ::"v"(af[mb]));
@@ -360,27 +367,30 @@ void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_
   hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(256), 0, stream, rec, rec_cnt, rec_cap, st);
 }
 
-template <bool FIRST, int DBG>
+template <bool FIRST, int DBG, bool F16>
 static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_select_kernel<FIRST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemm_select_kernel<FIRST, DBG, F16>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + (size_t)a.nqt * TILE * 4;
-  if (first) return launch_variant<true, 0>(a, lds, stream);
-  switch (a.debug) {
-    case 4: return launch_variant<false, 4>(a, lds, stream);
-    case 5: return launch_variant<false, 5>(a, lds, stream);
-    case 6: return launch_variant<false, 6>(a, lds, stream);
-    case 8: return launch_variant<false, 8>(a, lds, stream);
-    default: return launch_variant<false, 0>(a, lds, stream);
+  if (a.img_f16) {
+    if (first) return launch_variant<true, 0, true>(a, lds, stream);
+    switch (a.debug) {
+      case 4: return launch_variant<false, 4, true>(a, lds, stream);
+      case 5: return launch_variant<false, 5, true>(a, lds, stream);
+      case 8: return launch_variant<false, 8, true>(a, lds, stream);
+      default: return launch_variant<false, 0, true>(a, lds, stream);
+    }
   }
+  if (first) return launch_variant<true, 0, false>(a, lds, stream);
+  return launch_variant<false, 0, false>(a, lds, stream);
 }
 
 }  // namespace mi

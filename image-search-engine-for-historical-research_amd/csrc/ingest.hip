@@ -4,16 +4,30 @@
 // Restates the normalisation of matching_L2 (src/utils/nnsearch.py:693-698, no eps), of l2n
 // (src/layers/functional.py:129-130, eps 1e-6) and the tail of whitenapply (src/utils/whiten.py:10);
 // the reference redoes it on every call, here it is done once per gallery (HBM-bound, one-off).
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace mi {
 
+// 16-bit image element: fp16 (11-bit significand: 8x smaller rounding error, same MFMA rate) or bf16 (f32 range)
+__device__ __forceinline__ uint16_t cvt_img(float v, int f16, double& back) {
+  if (f16) {
+    const _Float16 h = (_Float16)v;
+    back = (double)(float)h;
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  const __hip_bfloat16 b = __float2bfloat16(v);
+  back = (double)__bfloat162float(b);
+  return __builtin_bit_cast(uint16_t, b);
+}
+
 template <typename InT>
 __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
                                                      int64_t rs, int64_t cs, int norm_mode,
                                                      float* __restrict__ out_f32,
-                                                     __hip_bfloat16* __restrict__ out_bf16,
+                                                     uint16_t* __restrict__ out_bf16, int img_f16,
                                                      RowStat* __restrict__ rowstat, int32_t dp,
                                                      int64_t npad) {
   __shared__ double tile[64][65];
@@ -83,13 +97,13 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src
       for (int half = 0; half < 2; ++half) {
         const uint32_t kcol = (uint32_t)(col0 + cj + half * 8);
         const uint32_t sl = kcol / SLICE_K, c = (kcol % SLICE_K) >> 3;
-        __hip_bfloat16* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
-        union { __hip_bfloat16 h[8]; uint4 u; } pk;
+        uint16_t* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+        union { uint16_t h[8]; uint4 u; } pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float v = (crow < n) ? vf[half * 8 + e] : 0.0f;
-          pk.h[e] = __float2bfloat16(v);
-          const double vb = (double)__bfloat162float(pk.h[e]);
+          double vb;
+          pk.h[e] = cvt_img(v, img_f16, vb);
           s_b += vb * vb;
           s_d += (vb - (double)v) * (vb - (double)v);
           s_g += (double)v * (double)v;
@@ -123,7 +137,7 @@ template <typename InT>
 __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
                                                              int64_t rs, int64_t cs, int norm_mode,
                                                              float* __restrict__ out_f32,
-                                                             __hip_bfloat16* __restrict__ out_bf16,
+                                                             uint16_t* __restrict__ out_bf16, int img_f16,
                                                              RowStat* __restrict__ rowstat, int32_t dp, int64_t npad) {
   __shared__ double red[3][4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -162,12 +176,12 @@ __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restri
       vf[e] = (valid && c < d) ? (float)((double)src[row * rs + (int64_t)c * cs] * scale) : 0.0f;
     }
     const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
-    __hip_bfloat16* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
-    union { __hip_bfloat16 h[8]; uint4 u; } pk;
+    uint16_t* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+    union { uint16_t h[8]; uint4 u; } pk;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      pk.h[e] = __float2bfloat16(vf[e]);
-      const double vb = (double)__bfloat162float(pk.h[e]);
+      double vb;
+      pk.h[e] = cvt_img(vf[e], img_f16, vb);
       s_b += vb * vb;
       s_d += (vb - (double)vf[e]) * (vb - (double)vf[e]);
       s_g += (double)vf[e] * (double)vf[e];
@@ -210,24 +224,24 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
 }
 
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
-                   float* out_f32, void* out_bf16, RowStat* rowstat, int32_t dp, int64_t npad,
+                   float* out_f32, void* out_bf16, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad,
                    hipStream_t stream) {
   if (npad <= 4096) {   // small batches (queries): one workgroup per row
     if (dtype == 0)
       hipLaunchKernelGGL(ingest_rowwise_kernel<float>, dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
-                         d, rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+                         d, rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
     else
       hipLaunchKernelGGL(ingest_rowwise_kernel<double>, dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
-                         n, d, rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+                         n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
     return;
   }
   const int64_t blocks = (npad + 63) / 64;
   if (dtype == 0)
     hipLaunchKernelGGL(ingest_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, n, d,
-                       rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+                       rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
   else
     hipLaunchKernelGGL(ingest_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)src, n,
-                       d, rs, cs, norm_mode, out_f32, (__hip_bfloat16*)out_bf16, rowstat, dp, npad);
+                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
 }
 
 void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream) {

@@ -6,7 +6,7 @@ namespace mi {
 
 // ingest.hip
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
-                   float* out_f32, void* out_bf16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream);
+                   float* out_f32, void* out_bf16, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream);
 void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream);
 
 // gemm_select.hip -- bf16 MFMA scoring of gallery tiles [tile0, tile0+ntiles) against nqt query tiles with the
@@ -14,6 +14,7 @@ void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStrea
 struct ScoreArgs {
   const void* gal_bf16;   // blocked image of the shard
   const void* qry_bf16;   // blocked image of the query batch
+  int32_t img_f16;        // 16-bit image element type: 1 = fp16, 0 = bf16
   int32_t nslices;        // dp / 32
   int32_t tile0, ntiles;  // gallery tiles of this launch
   int32_t nqt;            // query tiles (qpad / 256)

@@ -72,8 +72,15 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
     else
       eps = gamma * r.norm_f32 * g_f32;
     float margin = 2.0f * eps * 1.001f + 1e-30f;
+    float thr0 = -INFINITY;
     if (!(margin == margin)) margin = 0.f;   // NaN query (zero-norm): nothing will match anyway
-    st.thr[q] = -INFINITY;
+    if (use_bf16_terms && !isfinite(r.norm_bf16) && isfinite(r.norm_f32)) {
+      // the 16-bit image of this query overflowed (fp16 range): skip it here, the exact f32 path answers it
+      atomicOr(st.flags, FLAG_RANGE);
+      margin = 0.f;
+      thr0 = INFINITY;
+    }
+    st.thr[q] = thr0;
     st.margin[q] = margin;
     st.cnt[q * CNT_STRIDE] = first_cnt;
   } else {

@@ -166,6 +166,11 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
  * "force_exact" (score with the f32 kernel instead of bf16 MFMA). */
 int mi_set_option(mi_gallery* g, const char* name, double value);
 
+/* Process-wide defaults for galleries created afterwards.  "image_dtype": element type of the 16-bit tile-blocked image the
+ * MFMA kernel streams, 1 = fp16 (default: 2^-11 rounding, 8x tighter certificate than bf16 at the same MFMA rate;
+ * un-normalised galleries whose rows exceed its comfortable range are stored as bf16 automatically), 0 = bf16. */
+int mi_set_global_option(const char* name, double value);
+
 /* Diagnostics only: per-wave cycle sums written by the stamped build of the scoring kernel (option "debug"=8);
  * layout [workgroups*8][8] = {load, barrier1, mfma, barrier2, epilogue, slices, -, -}. */
 int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count);
