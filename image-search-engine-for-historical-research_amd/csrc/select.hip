@@ -99,27 +99,33 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // ------------------------------------------------------------------------------------------------
 // maintain: L = K-th largest approximate score among the survivors so far (a lower bound of the final
 // K-th largest); threshold <- L - margin; survivors below the new threshold are dropped.
-// LDS: entries[cap] (u64) | hist[256] | sh[4] | counter
+// Only the 4-byte keys live in LDS (cap * 4 + 1 KiB -> 3 workgroups per CU); the 8-byte entries stay in
+// registers between the read and the in-place compaction (all reads complete before the first write).
+constexpr int MAINT_THREADS = 512;
+constexpr int MAINT_PER_THREAD = 24;            // 512 * 24 = 12288 = largest survivor_cap
+
 template <int MODE>
-__global__ __launch_bounds__(512) void select_maintain_kernel(QueryState st, int32_t k, float* __restrict__ topvals,
-                                                              float* __restrict__ l_local,
-                                                              uint64_t* __restrict__ stats2) {
+__global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QueryState st, int32_t k,
+                                                                        float* __restrict__ topvals,
+                                                                        float* __restrict__ l_local,
+                                                                        uint64_t* __restrict__ stats2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t q = blockIdx.x;
   const uint32_t cap = st.cap;
-  uint64_t* ent = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
   uint32_t* hist = keys + cap;
   uint32_t* sh = hist + 256;
   const uint32_t n = min(st.cnt[q * CNT_STRIDE], cap);
   uint64_t* gsurv = st.surv + (uint64_t)q * cap;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint64_t e = gsurv[i];
-    ent[i] = e;
-    keys[i] = f2key(entry_score(e));
+  uint64_t ent[MAINT_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < MAINT_PER_THREAD; ++j) {
+    const uint32_t i = threadIdx.x + j * MAINT_THREADS;
+    ent[j] = (i < n) ? gsurv[i] : 0ull;
+    if (i < n) keys[i] = f2key(entry_score(ent[j]));
   }
-  if (threadIdx.x == 0) sh[2] = 0;
-  __syncthreads();
+  if (threadIdx.x == 0) { sh[2] = 0; sh[3] = 0; }
+  __syncthreads();                                  // all entries are in registers from here on
   float L = -INFINITY;
   uint32_t keyL = 0;
   if (n >= (uint32_t)k) {
@@ -127,30 +133,30 @@ __global__ __launch_bounds__(512) void select_maintain_kernel(QueryState st, int
     L = key2f(keyL);
   }
   const float thr_new = L - st.margin[q];
-  // compaction (order is irrelevant)
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint64_t e = ent[i];
-    if (entry_score(e) >= thr_new) {
-      const uint32_t pos = atomicAdd(&sh[2], 1u);
-      gsurv[pos] = e;
+  float* tv = topvals + (uint64_t)q * k;
+#pragma unroll
+  for (int j = 0; j < MAINT_PER_THREAD; ++j) {
+    const uint32_t i = threadIdx.x + j * MAINT_THREADS;
+    if (i < n) {
+      const float sc = entry_score(ent[j]);
+      if (sc >= thr_new) gsurv[atomicAdd(&sh[2], 1u)] = ent[j];          // compaction (order is irrelevant)
+      if (MODE == 1) {
+        // the K largest approximate values (unsorted): everything above L, ties of L filled in below
+        if (n >= (uint32_t)k) {
+          if (f2key(sc) > keyL) tv[atomicAdd(&sh[3], 1u)] = sc;
+        } else {
+          tv[i] = sc;
+        }
+      }
     }
-  }
-  if (MODE == 1) {
-    // the K largest approximate values (unsorted): everything above L plus copies of L for the ties
-    if (threadIdx.x == 0) sh[3] = 0;
-    __syncthreads();
-    float* tv = topvals + (uint64_t)q * k;
-    if (n >= (uint32_t)k) {
-      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-        if (keys[i] > keyL) tv[atomicAdd(&sh[3], 1u)] = entry_score(ent[i]);
-      __syncthreads();
-      for (uint32_t i = sh[3] + threadIdx.x; i < (uint32_t)k; i += blockDim.x) tv[i] = L;
-    } else {
-      for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) tv[i] = (i < n) ? entry_score(ent[i]) : -INFINITY;
-    }
-    if (threadIdx.x == 0) l_local[q] = L;
   }
   __syncthreads();
+  if (MODE == 1) {
+    const uint32_t have = (n >= (uint32_t)k) ? sh[3] : n;
+    const float fill = (n >= (uint32_t)k) ? L : -INFINITY;
+    for (uint32_t i = have + threadIdx.x; i < (uint32_t)k; i += blockDim.x) tv[i] = fill;
+    if (threadIdx.x == 0) l_local[q] = L;
+  }
   if (threadIdx.x == 0) {
     st.thr[q] = thr_new;
     st.cnt[q * CNT_STRIDE] = sh[2];
@@ -160,17 +166,13 @@ __global__ __launch_bounds__(512) void select_maintain_kernel(QueryState st, int
 
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, hipStream_t stream) {
-  const size_t lds = (size_t)st.cap * 12 + 256 * 4 + 16;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)select_maintain_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)select_maintain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;
   if (mode == 0)
-    hipLaunchKernelGGL(select_maintain_kernel<0>, dim3(nq), dim3(512), lds, stream, st, k, topvals, l_local, stats2);
+    hipLaunchKernelGGL(select_maintain_kernel<0>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
+                       stats2);
   else
-    hipLaunchKernelGGL(select_maintain_kernel<1>, dim3(nq), dim3(512), lds, stream, st, k, topvals, l_local, stats2);
+    hipLaunchKernelGGL(select_maintain_kernel<1>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
+                       stats2);
 }
 
 // ------------------------------------------------------------------------------------------------
