@@ -141,3 +141,45 @@ def test_massive_ties_fall_through_to_the_dense_path(lib):
     assert np.abs(sc[0] - 1.0).max() < 1e-6
     s = oracle.exact_scores_f64(g, q)
     assert oracle.check_topk_parity(idx, s, k, TAU) == []
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(1, 1, 1, 1), (3, 5, 2, 3), (257, 100, 3, 17), (1000, 33, 1, 1000),
+                                      (513, 2050, 2, 5), (5000, 64, 1500, 10)])
+def test_ragged_shapes(lib, n, d, nq, k):
+    """Rows / columns / queries that are not multiples of the tile sizes, D > 2048, Q > one batch of 1024,
+    K = N, single-row and single-column galleries."""
+    from isehr_amd.nnsearch import matching_HIP
+    g = synth_rows(100 + n, 0, n, d) + 0.25
+    q = synth_rows(200 + n, 0, nq, d) + 0.25
+    idx, _, sc = matching_HIP(k, g, q, return_scores=True)
+    assert idx.shape == (nq, k)
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
+    assert np.abs(np.take_along_axis(s, idx, 1) - sc).max() < 3e-7
+
+
+def test_degenerate_queries(lib):
+    """A zero query normalises to NaN in the reference (its ranking is then arbitrary); here the call must not
+    fail or disturb the other queries of the batch.  Huge magnitudes must not break the 16-bit image."""
+    from isehr_amd.nnsearch import matching_HIP
+    g = synth_rows(7, 0, 3000, 96)
+    q = synth_rows(8, 0, 4, 96)
+    q[1] = 0.0
+    q[2] *= 1e30
+    g[5] *= 1e-30
+    with np.errstate(all="ignore"):
+        idx, _ = matching_HIP(20, g, q)
+    qq = q.astype(np.float64)
+    qq[2] /= 1e30
+    s = oracle.exact_scores_f64(g.astype(np.float64) * np.where(np.arange(3000) == 5, 1e30, 1.0)[:, None], qq[[0, 2, 3]])
+    assert oracle.check_topk_parity(idx[[0, 2, 3]], s, 20, 1e-5) == []
+
+
+def test_unnormalised_gallery_with_large_values_uses_bf16_image(lib):
+    """MI_NORM_NONE rows far outside fp16's comfortable range: the image falls back to bf16 and results stay exact."""
+    from isehr_amd.nnsearch import ip_topk_hip
+    vecs = (synth_rows(9, 0, 2000, 80) * 3000.0).T.copy()
+    qv = (synth_rows(10, 0, 5, 80) * 2.0).T.copy()
+    ranks, scores = ip_topk_hip(vecs, qv, 30)
+    s64 = (vecs.astype(np.float64).T @ qv.astype(np.float64)).T
+    assert oracle.check_topk_parity(ranks.T, s64, 30, 1e-6 * float(np.abs(s64).max())) == []
