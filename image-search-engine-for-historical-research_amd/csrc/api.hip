@@ -42,7 +42,8 @@ struct Workspace {
   float* q_f32 = nullptr;
   void* q_bf16 = nullptr;
   RowStat* q_stat = nullptr;
-  float *thr = nullptr, *margin = nullptr;
+  float *thr = nullptr, *margin = nullptr, *thr2 = nullptr;
+  uint32_t* qflag = nullptr;
   uint32_t* cnt = nullptr;
   uint64_t* surv = nullptr;
   uint32_t* flags = nullptr;
@@ -71,7 +72,7 @@ struct mi_gallery {
   hipStream_t stream = nullptr;
   Workspace ws;
   // options
-  int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0;
+  int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0, speculative = 1;
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
   mi_search_stats stats{};
@@ -122,6 +123,8 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(q_stat, QB);
   A(thr, QB);
   A(margin, QB);
+  A(thr2, QB);
+  A(qflag, QB);
   A(cnt, (size_t)QB * CNT_STRIDE);
   A(surv, (size_t)QB * ws.cap);
   A(flags, 4);
@@ -149,6 +152,8 @@ static QueryState make_state(const Workspace& ws) {
   st.cnt = ws.cnt;
   st.surv = ws.surv;
   st.flags = ws.flags;
+  st.thr2 = ws.thr2;
+  st.qflag = ws.qflag;
   st.cap = ws.cap;
   return st;
 }
@@ -203,9 +208,9 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   int64_t bound = t0;
   int64_t t = 0, len = t0;
   bool first = true;
-  while (t < ntiles) {
-    const int64_t cur = std::min<int64_t>(len, ntiles - t);
-    const int64_t rows0 = t * TILE, rows1 = std::min<int64_t>(g->n, (t + cur) * TILE);
+  bool spec_next = false, spec_cur = false;     // speculative threshold for the next / the current scoring launch
+  auto score_launch = [&](int64_t tile_from, int64_t ntile, bool first_chunk, const uint32_t* cond, bool profile_it) {
+    const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
     if (exact) {
       ExactArgs a;
       a.gal_f32 = g->gal_f32;
@@ -216,38 +221,67 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       a.n = g->n;
       a.nq = nq;
       a.st = st;
-      launch_exact_select(a, first, s);
-    } else {
-      ScoreArgs a;
-      a.gal_bf16 = g->gal_bf16;
-      a.qry_bf16 = ws.q_bf16;
-      a.img_f16 = g->img_f16;
-      a.nslices = g->dp / SLICE_K;
-      a.tile0 = (int32_t)t;
-      a.ntiles = (int32_t)cur;
-      a.nqt = qpad / TILE;
-      a.n = g->n;
-      a.nq = nq;
-      a.debug = g->debug;
-      a.rec = ws.rec;
-      a.rec_cnt = ws.rec_cnt;
-      a.rec_cap = ws.rec_cap;
-      a.dbg = ws.dbg;
-      a.st = st;
-      size_t slot;
-      prof_begin(g, s, &slot);
-      launch_gemm_select(a, first, s);
-      prof_end(g, s, slot);
-      if (!first) launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, s);
-      if (g->profile) {
-        const double rows = (double)(rows1 - rows0);
-        g->stats.gemm_flops += 2.0 * nq * rows * g->d;
-        g->stats.gemm_bytes += rows * g->d * 2.0 + (double)nq * g->d * 2.0;
-      }
+      launch_exact_select(a, first_chunk, s);
+      return;
     }
+    ScoreArgs a;
+    a.gal_bf16 = g->gal_bf16;
+    a.qry_bf16 = ws.q_bf16;
+    a.img_f16 = g->img_f16;
+    a.nslices = g->dp / SLICE_K;
+    a.tile0 = (int32_t)tile_from;
+    a.ntiles = (int32_t)ntile;
+    a.nqt = qpad / TILE;
+    a.n = g->n;
+    a.nq = nq;
+    a.debug = g->debug;
+    a.rec = ws.rec;
+    a.rec_cnt = ws.rec_cnt;
+    a.rec_cap = ws.rec_cap;
+    a.cond = cond;
+    a.dbg = ws.dbg;
+    a.st = st;
+    size_t slot = (size_t)-1;
+    if (profile_it) prof_begin(g, s, &slot);
+    launch_gemm_select(a, first_chunk, s);
+    if (profile_it) prof_end(g, s, slot);
+    if (profile_it && g->profile) {
+      const double rows = (double)(rows1 - rows0);
+      g->stats.gemm_flops += 2.0 * nq * rows * g->d;
+      g->stats.gemm_bytes += rows * g->d * 2.0 + (double)nq * g->d * 2.0;
+    }
+    if (!first_chunk) launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s);
+  };
+  while (t < ntiles) {
+    int64_t cur = std::min<int64_t>(len, ntiles - t);
+    if (spec_next) cur = ntiles - t;            // one launch for everything that is left
+    spec_cur = spec_next;
+    score_launch(t, cur, first, nullptr, true);
     t += cur;
     const bool last = (t >= ntiles);
-    launch_select_maintain(st, nq, k, last ? 1 : 0, ws.topvals, ws.L, ws.stats2, s);
+    if (last) {
+      launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, spec_cur ? 1 : 0, 0, nullptr, s);
+      if (spec_cur) {
+        // repair pass for queries whose speculative threshold failed verification: conditional on the device word
+        // flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip
+        const uint32_t* cond = ws.flags + 1;
+        score_launch(0, ntiles, false, cond, false);
+        launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s);
+      }
+    } else {
+      // Speculative threshold for the rest?  With n_s rows seen, the shard's K-th largest score sits near sample rank
+      // lambda = K * n_s / N.  The r-th largest sample score with r = lambda + 5 sqrt(lambda) + 6 lies below it except
+      // with probability ~1e-6 per query (Poisson tail), and keeps the expected survivors at r * N / n_s.
+      int32_t spec_r = 0;
+      const int64_t n_seen = std::min<int64_t>(g->n, t * TILE);
+      if (g->speculative && !exact && g->n / n_seen <= 160) {
+        const double lambda = (double)k * (double)n_seen / (double)g->n;
+        const int32_t r = (int32_t)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 6.0);
+        if (r < k) spec_r = r;
+      }
+      spec_next = spec_r > 0;
+      launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, spec_r, 0, 0, nullptr, s);
+    }
     first = false;
     if (gr == 1) {
       len = t0;
@@ -1006,6 +1040,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   } else if (n == "exact_fallback") g->exact_fallback = value != 0;
   else if (n == "force_exact") g->force_exact = value != 0;
   else if (n == "debug") g->debug = (int)value;
+  else if (n == "speculative") g->speculative = value != 0;
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
   return MI_OK;
 }

@@ -69,7 +69,7 @@ struct __attribute__((aligned(16))) SurvRec {
 };
 
 // sticky device-side flags
-enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u, FLAG_REC_OVERFLOW = 4u, FLAG_RANGE = 8u };
+enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u, FLAG_REC_OVERFLOW = 4u, FLAG_RANGE = 8u, FLAG_SPEC_FAIL = 16u };
 
 constexpr uint32_t CNT_STRIDE = 32;   // one survivor counter per 128-byte line (atomics to one line serialise in L2)
 
@@ -78,7 +78,9 @@ struct QueryState {       // all arrays sized for qpad queries
   float* margin;          // 2 * eps_q  (rigorous |approx - exact| bound, both sides)
   uint32_t* cnt;          // survivors appended: counter of query q at cnt[q * CNT_STRIDE]
   uint64_t* surv;         // [qpad][cap]
-  uint32_t* flags;        // [1]
+  uint32_t* flags;        // [0] sticky error flags, [1] 'repair needed' word of the current batch (speculative threshold)
+  float* thr2;            // fallback (looser) speculative threshold per query
+  uint32_t* qflag;        // per query: 1 = its speculative threshold failed verification, repair it
   uint32_t cap;
 };
 

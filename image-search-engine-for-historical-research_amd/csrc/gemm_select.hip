@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // ---- work assignment.  Blocks b, b+8, ... share an XCD (round-robin dispatch; speed only).  XCD label x
   // owns gallery tiles tl = x (mod 8); its virtual list v -> (tl = (v / nqt) * 8 + x, qt = v % nqt) is dealt
   // round-robin to the nwg blocks of that label, so concurrently running blocks share gallery tiles.
+  if (p.cond && *p.cond == 0) return;                           // repair pass that is not needed
   const uint32_t b = blockIdx.x, nwg = gridDim.x >> 3;
   const uint32_t xcd = b & 7u, j = b >> 3;
   const uint32_t nqt = (uint32_t)p.nqt;
@@ -358,7 +359,8 @@ unsigned gemm_select_grid() { return persistent_grid(); }
 
 __global__ __launch_bounds__(256) void scatter_records_kernel(const SurvRec* __restrict__ rec,
                                                               const uint32_t* __restrict__ rec_cnt, uint32_t rec_cap,
-                                                              QueryState st) {
+                                                              QueryState st, const uint32_t* __restrict__ cond) {
+  if (cond && *cond == 0) return;
   const uint32_t seg = blockIdx.x;
   const uint32_t n = rec_cnt[seg];
   const SurvRec* r = rec + (uint64_t)seg * rec_cap;
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const SurvRec* __r
 }
 
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
-                            QueryState st, hipStream_t stream) {
-  hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(256), 0, stream, rec, rec_cnt, rec_cap, st);
+                            QueryState st, const uint32_t* cond, hipStream_t stream) {
+  hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(256), 0, stream, rec, rec_cnt, rec_cap, st, cond);
 }
 
 template <bool FIRST, int DBG, bool F16>

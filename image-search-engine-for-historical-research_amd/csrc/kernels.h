@@ -24,6 +24,7 @@ struct ScoreArgs {
   SurvRec* rec;           // [grid * 8 waves][rec_cap] wave-private survivor records of this launch
   uint32_t* rec_cnt;      // [grid * 8]
   uint32_t rec_cap;
+  const uint32_t* cond;   // non-null: the whole launch is skipped when *cond == 0 (repair pass)
   unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
@@ -31,7 +32,7 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
 // buckets the wave-private records of the last scoring launch into the per-query survivor buffers
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
-                            QueryState st, hipStream_t stream);
+                            QueryState st, const uint32_t* cond, hipStream_t stream);
 
 // exact_score.hip -- f32 FMA scoring with the same filter (fallback / force_exact)
 struct ExactArgs {
@@ -53,7 +54,8 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // mode 0: maintain (threshold <- K-th largest - margin, compact survivors)
 // mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
-                            uint64_t* stats2, hipStream_t stream);
+                            uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
+                            hipStream_t stream);
 void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_t* cand_rows, uint32_t* cand_cnt,
                               uint32_t rcap, uint64_t* stats2, hipStream_t stream);
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,

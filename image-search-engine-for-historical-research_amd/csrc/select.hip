@@ -60,7 +60,7 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
                                         int32_t nq, int32_t qpad, float gamma, int use_bf16_terms,
                                         uint32_t first_cnt, QueryState st) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q == 0) st.flags[0] = 0;
+  if (q == 0) st.flags[1] = 0;          // flags[0] is sticky across batches (read and cleared by the host)
   if (q >= qpad) return;
   if (q < nq) {
     const RowStat r = qstat[q];
@@ -81,10 +81,14 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
       thr0 = INFINITY;
     }
     st.thr[q] = thr0;
+    st.thr2[q] = thr0;
+    st.qflag[q] = 0;
     st.margin[q] = margin;
     st.cnt[q * CNT_STRIDE] = first_cnt;
   } else {
     st.thr[q] = INFINITY;
+    st.thr2[q] = INFINITY;
+    st.qflag[q] = 0;
     st.margin[q] = 0.f;
     st.cnt[q * CNT_STRIDE] = 0;
   }
@@ -104,18 +108,32 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 constexpr int MAINT_THREADS = 512;
 constexpr int MAINT_PER_THREAD = 24;            // 512 * 24 = 12288 = largest survivor_cap
 
+// MODE 0 (after the bootstrap chunk).  spec_r > 0: SPECULATIVE threshold for the single remaining scoring launch =
+//   the spec_r-th largest sample score (>= K rows above it exist in the whole shard with probability 1 - 1e-6, see
+//   api.hip), and thr2 = the (4*spec_r)-th largest as the looser threshold of the repair pass.  A speculative
+//   threshold needs no error margin: it is verified after the scan (MODE 1).
+// MODE 1 (after the last launch): topvals / L, and with spec != 0 the verification: the survivors are ALL rows with
+//   approximate score >= thr, so if there are >= K of them L is the true K-th largest approximate score, and if also
+//   L - margin >= thr every candidate row is among them.  Otherwise the query is flagged for the repair pass
+//   (device-side, conditional launches, no host round trip); a query failing again raises FLAG_SPEC_FAIL.
+//   repair != 0: only flagged queries are processed.  cond: skip the launch when *cond == 0.
 template <int MODE>
 __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QueryState st, int32_t k,
                                                                         float* __restrict__ topvals,
                                                                         float* __restrict__ l_local,
-                                                                        uint64_t* __restrict__ stats2) {
+                                                                        uint64_t* __restrict__ stats2, int32_t spec_r,
+                                                                        int32_t spec, int32_t repair,
+                                                                        const uint32_t* __restrict__ cond) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (cond && *cond == 0) return;
   const uint32_t q = blockIdx.x;
+  if (MODE == 1 && repair && st.qflag[q] == 0) return;
   const uint32_t cap = st.cap;
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
   uint32_t* hist = keys + cap;
   uint32_t* sh = hist + 256;
   const uint32_t n = min(st.cnt[q * CNT_STRIDE], cap);
+  if (MODE == 1 && st.cnt[q * CNT_STRIDE] > cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
   uint64_t* gsurv = st.surv + (uint64_t)q * cap;
   uint64_t ent[MAINT_PER_THREAD];
 #pragma unroll
@@ -132,12 +150,23 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     keyL = block_kth_largest(keys, n, (uint32_t)k, hist, sh);
     L = key2f(keyL);
   }
-  const float thr_new = L - st.margin[q];
+  float thr_new = L - st.margin[q];
+  float thr2 = thr_new;
+  if (MODE == 0 && spec_r > 0 && n >= (uint32_t)k) {
+    if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest(keys, n, (uint32_t)spec_r, hist, sh)));
+    if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(block_kth_largest(keys, n, (uint32_t)(4 * spec_r), hist, sh)));
+  }
+  bool failed = false;
+  if (MODE == 1 && spec) {
+    const float used = st.thr[q];
+    failed = (used > -INFINITY) && !(n >= (uint32_t)k && L - st.margin[q] >= used);
+    if (failed) thr_new = st.thr2[q];
+  }
   float* tv = topvals + (uint64_t)q * k;
 #pragma unroll
   for (int j = 0; j < MAINT_PER_THREAD; ++j) {
     const uint32_t i = threadIdx.x + j * MAINT_THREADS;
-    if (i < n) {
+    if (i < n && !failed) {
       const float sc = entry_score(ent[j]);
       if (sc >= thr_new) gsurv[atomicAdd(&sh[2], 1u)] = ent[j];          // compaction (order is irrelevant)
       if (MODE == 1) {
@@ -158,21 +187,41 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     if (threadIdx.x == 0) l_local[q] = L;
   }
   if (threadIdx.x == 0) {
-    st.thr[q] = thr_new;
-    st.cnt[q * CNT_STRIDE] = sh[2];
-    if (MODE == 1 && stats2) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)sh[2]);
+    if (MODE == 0) {
+      st.thr[q] = thr_new;
+      st.thr2[q] = thr2;
+      st.cnt[q * CNT_STRIDE] = sh[2];
+    } else if (spec) {
+      if (failed && !repair) {
+        st.thr[q] = thr_new;                       // = thr2: the repair pass re-scans every tile for this query
+        st.cnt[q * CNT_STRIDE] = 0;
+        st.qflag[q] = 1;
+        atomicOr(&st.flags[1], 1u);
+      } else {
+        if (failed) atomicOr(st.flags, FLAG_SPEC_FAIL);
+        st.thr[q] = INFINITY;                      // verified: invisible to a repair pass
+        st.qflag[q] = 0;
+        st.cnt[q * CNT_STRIDE] = sh[2];
+      }
+    } else {
+      st.thr[q] = thr_new;
+      st.cnt[q * CNT_STRIDE] = sh[2];
+    }
+    if (MODE == 1 && stats2 && !failed)
+      atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)sh[2]);
   }
 }
 
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
-                            uint64_t* stats2, hipStream_t stream) {
+                            uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
+                            hipStream_t stream) {
   const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;
   if (mode == 0)
     hipLaunchKernelGGL(select_maintain_kernel<0>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
-                       stats2);
+                       stats2, spec_r, spec, repair, cond);
   else
     hipLaunchKernelGGL(select_maintain_kernel<1>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
-                       stats2);
+                       stats2, spec_r, spec, repair, cond);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -183,3 +183,27 @@ def test_unnormalised_gallery_with_large_values_uses_bf16_image(lib):
     ranks, scores = ip_topk_hip(vecs, qv, 30)
     s64 = (vecs.astype(np.float64).T @ qv.astype(np.float64)).T
     assert oracle.check_topk_parity(ranks.T, s64, 30, 1e-6 * float(np.abs(s64).max())) == []
+
+
+@pytest.mark.parametrize("ndup,expect_fallback", [(0, False), (30, False), (90, True)])
+def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallback):
+    """The single-launch schedule uses a speculative threshold taken from the bootstrap sample (rows 0..8191) and
+    verifies it afterwards.  Near-duplicates of the query planted INSIDE the sample make that threshold too high:
+    30 of them -> the device-side repair pass (looser threshold) must fix the query; 90 of them -> the repair fails
+    too and the host API falls back to the rigorous schedule.  Results must be exact in every case."""
+    from isehr_amd._lib import Gallery
+    n, d, nq, k = 200000, 64, 6, 100
+    g = synth_rows(71, 0, n, d)
+    q = synth_rows(72, 0, nq, d)
+    rng = np.random.default_rng(3)
+    rows = rng.choice(8192, size=ndup, replace=False)
+    for j, r in enumerate(rows):
+        g[r] = q[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
+    G = Gallery.from_host(g)
+    idx, sc, _ = G.search(q, k)
+    st = G.status()
+    G.close()
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
+    assert set(rows) <= set(idx[0])
+    assert (st["overflow_batches"] >= 1) == expect_fallback
