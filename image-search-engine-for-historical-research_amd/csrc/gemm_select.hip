@@ -39,9 +39,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int A_SLOTS = 5, B_SLOTS = 4;
 constexpr int A_RING = 0, B_RING = A_SLOTS * SLICE_BYTES;                 // byte offsets in LDS
 constexpr int RING_BYTES = (A_SLOTS + B_SLOTS) * SLICE_BYTES;             // 144 KiB
-constexpr int HIT_SLOTS = 8;                                // per-wave filter scratch: 8 lanes x 32 scores + meta
-constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1152 B
-constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 9 KiB per workgroup
+constexpr int HIT_SLOTS = 12;                               // per-wave filter scratch: 12 (lane, block) pairs x 32 scores + meta
+constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1728 B
+constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 13.5 KiB per workgroup
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* ldst) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)ldst, 16, 0, 0);
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // ---- per-tile filter of the accumulators (+ reset).  Called by group 1 right after its last MFMA segment of
   // the tile and by group 0 ONE INTERVAL LATER (before its first MFMA segment of the next tile), so that both
   // groups filter in the same barrier interval instead of stalling each other in two different ones.
+  unsigned long long d_e1 = 0, d_e2 = 0, d_hits = 0;
   auto tile_epilogue = [&](uint32_t gt, uint32_t qt) {
       // ---- tile finished: filter.  C layout of 16x16x32: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
     const uint32_t row_base = gt * TILE + wr * 128 + lq * 4;          // + mb*16 + reg
@@ -185,58 +186,77 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
         thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
         thr_qt = qt;
       }
-      // Filter.  The common case (no score of this lane reaches its query's threshold) is branch-free VALU:
-      // a 32-value max per (lane, query block).  Lanes that hit dump their 32 scores into a small LDS scratch
-      // and a ROLLED loop scans them -- the unrolled code stays tiny (a fully unrolled compare+append per
-      // accumulator was measured 17 % slower: instruction fetch and taken branches, not the stores).
+      // Filter.  The common case (no score of this lane reaches its query's threshold) is branch-free VALU: a
+      // 32-value max per (lane, query block), for all four query blocks first.  Then ALL hit (lane, block) pairs
+      // dump their 32 scores into the per-wave LDS scratch in one burst and ONE rolled loop scans them: one LDS
+      // write->read latency chain per tile instead of one per query block (the partner wave group saturates the
+      // LDS with fragment reads meanwhile, so every dependent LDS round trip costs hundreds of cycles), and the
+      // unrolled code stays small (a fully unrolled compare+append per accumulator was measured 17 % slower).
+      unsigned long long te0 = 0, te1 = 0, te2 = 0;
+      if (DBG & 8) te0 = stamp();
+      float thr4[4];
+      unsigned long long hm[4];
+      uint32_t base[5];
+      base[0] = 0;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
-        const uint32_t q = ql_base + nb * 16;
-        const float thr = thr_w[nb * 16 + l15];      // +inf for padded queries
+        thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
         float m = acc[0][nb][0];
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
-        const bool hit = m >= thr;
-        unsigned long long hitmask = __ballot(hit);
-        bool pending = hit;
-        while (hitmask) {
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask, 0u));
-          const bool take = pending && rank < HIT_SLOTS;
-          if (take) {
-            float4* dst = reinterpret_cast<float4*>(sc_val + rank * 32);
+        hm[nb] = __ballot(m >= thr4[nb]);
+        base[nb + 1] = base[nb] + (uint32_t)__popcll(hm[nb]);
+      }
+      const uint32_t total = base[4];
+      if (DBG & 8) te1 = stamp();
+      for (uint32_t r0 = 0; r0 < total; r0 += HIT_SLOTS) {          // almost always zero or one round
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          if (hm[nb] == 0) continue;                                  // wave-uniform: no write burst for this block
+          const uint32_t rank = base[nb] + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[nb] >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)hm[nb], 0u));
+          const bool mine = (hm[nb] >> lane) & 1ull;
+          if (mine && rank >= r0 && rank < r0 + HIT_SLOTS) {
+            float4* dst = reinterpret_cast<float4*>(sc_val + (rank - r0) * 32);
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb)
               dst[mb] = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
-            sc_meta[rank] = make_uint4(__float_as_uint(thr), q, row_base, 0u);
-            pending = false;
+            sc_meta[rank - r0] = make_uint4(__float_as_uint(thr4[nb]), ql_base + nb * 16, row_base, 0u);
           }
-          const uint32_t nslots = min((uint32_t)__popcll(hitmask), (uint32_t)HIT_SLOTS);
-          hitmask = __ballot(pending);
-          // rolled scan of nslots x 32 scores: entry e -> slot e >> 5, value index i = e & 31 = mb * 4 + r
-          for (uint32_t e0 = 0; e0 < nslots * 32; e0 += 64) {      // wave-uniform trip count (my_cnt stays uniform)
-            const uint32_t e = e0 + lane;
-            const bool valid = e < nslots * 32;
-            const uint4 mt = sc_meta[valid ? (e >> 5) : 0];
-            const float v = sc_val[valid ? e : 0];
-            const uint32_t i = e & 31u;
-            const uint32_t row = mt.z + (i >> 2) * 16 + (i & 3u);
-            const bool keep = valid && v >= __uint_as_float(mt.x) && row < (uint64_t)p.n;
-            const unsigned long long km = __ballot(keep);
-            if (km) {
-              // (an LDS record stage flushed by one wide store per 32 records was measured slower than these
-              // direct stores: c1 332 vs 290 us, main chunk 2427 vs 2392 us)
-              const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-              if (keep && pos < p.rec_cap)
-                reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(v), row, mt.y, 0u);
-              my_cnt += (uint32_t)__popcll(km);
-            }
+        }
+        const uint32_t nslots = min(total - r0, (uint32_t)HIT_SLOTS);
+        // scan of nslots x 32 scores (entry e -> slot e >> 5, value index e & 31 = mb * 4 + r): all LDS reads of the
+        // round are issued before the first ballot, so the round pays ONE read latency, not one per 64 entries
+        constexpr int SCAN = HIT_SLOTS * 32 / 64;
+        uint4 mt[SCAN];
+        float vv[SCAN];
+#pragma unroll
+        for (int it = 0; it < SCAN; ++it) {
+          const uint32_t e = it * 64 + lane;
+          const bool valid = e < nslots * 32;
+          mt[it] = sc_meta[valid ? (e >> 5) : 0];
+          vv[it] = sc_val[valid ? e : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < SCAN; ++it) {
+          if ((uint32_t)(it * 64) >= nslots * 32) break;              // wave-uniform
+          const uint32_t e = it * 64 + lane;
+          const uint32_t i = e & 31u;
+          const uint32_t row = mt[it].z + (i >> 2) * 16 + (i & 3u);
+          const bool keep = e < nslots * 32 && vv[it] >= __uint_as_float(mt[it].x) && row < (uint64_t)p.n;
+          const unsigned long long km = __ballot(keep);
+          if (km) {
+            const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            if (keep && pos < p.rec_cap)
+              reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(vv[it]), row, mt[it].y, 0u);
+            my_cnt += (uint32_t)__popcll(km);
           }
         }
       }
+      if (DBG & 8) { te2 = stamp(); d_e1 += te1 - te0; d_e2 += te2 - te1; d_hits += total; }
     }
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb)
@@ -261,6 +281,9 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
 
   uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding slice S
+  unsigned long long t_abs0 = 0, t_abs2 = 0;
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (DBG & 8) { clk0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   unsigned long long d_load = 0, d_b1 = 0, d_mfma = 0, d_b2 = 0, d_epi = 0, tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0, tt4 = 0;
   for (uint32_t S = 0; S < T_total; ++S) {
     if (DBG & 8) tt0 = stamp();
@@ -318,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     if (DBG & 8) {
       tt4 = stamp();
       d_load += tt1 - tt0; d_b1 += tt2 - tt1; d_mfma += tt3 - tt2; d_b2 += tt4 - tt3;
+      if (S == 200) { t_abs0 = tt0; t_abs2 = tt2; }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the stagger barrier
   if ((DBG & 8) && lane == 0) {
     unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
-    dbgp[0] = d_load; dbgp[1] = d_b1; dbgp[2] = d_mfma; dbgp[3] = d_b2; dbgp[4] = d_epi; dbgp[5] = T_total;
+    dbgp[0] = d_load; dbgp[1] = d_b1; dbgp[2] = d_mfma; dbgp[3] = d_b2; dbgp[4] = d_epi; dbgp[5] = T_total; dbgp[6] = (p.debug & 16) ? (stamp() - clk0) : d_e1; dbgp[7] = (p.debug & 16) ? (__builtin_amdgcn_s_memrealtime() - rt0) : d_e2 + (d_hits << 40);
   }
   if (!FIRST && lane == 0) {
     p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
@@ -395,7 +419,7 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
     switch (a.debug) {
       case 4: return launch_variant<false, 4, true>(a, lds, stream);
       case 5: return launch_variant<false, 5, true>(a, lds, stream);
-      case 8: return launch_variant<false, 8, true>(a, lds, stream);
+      case 8: case 24: return launch_variant<false, 8, true>(a, lds, stream);
       default: return launch_variant<false, 0, true>(a, lds, stream);
     }
   }

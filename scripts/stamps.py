@@ -22,4 +22,15 @@ ok = sl > 0
 for grp, name in ((0, "group0 (A loader)"), (1, "group1 (B loader)")):
     m = ok.copy(); m &= ((np.arange(len(c)) % 8) // 4 == grp)
     per = c[m, :5].sum(0) / sl[m].sum()
+    e2 = (c[m, 7].astype(np.uint64) & np.uint64((1 << 40) - 1)).astype(np.float64); hits = (c[m, 7].astype(np.uint64) >> np.uint64(40)).astype(np.float64)
+    tiles = sl[m].sum() / 64
+    print(name, "per TILE: filter decide=%.0f hit-path=%.0f cycles, hit (lane,block) pairs=%.1f" % (c[m, 6].sum() / tiles, e2.sum() / tiles, hits.sum() / tiles))
     print(name, "cycles per slice: load=%.0f barrier1=%.0f mfma+vmwait=%.0f barrier2=%.0f epilogue(per slice)=%.0f total=%.0f" % (*per, per.sum()))
+
+g.set_option("debug", 24)
+g.search_device(q.data_ptr(), nq, k, idx.data_ptr(), sc.data_ptr(), None, s)
+torch.cuda.synchronize()
+c = g.debug_cycles()
+dc = c[:, 6].astype(np.float64); dr = c[:, 7].astype(np.float64)
+ok = dr > 0
+print("shader clock during the final scoring launch: %.0f MHz (median over waves; s_memtime / s_memrealtime x 100 MHz)" % np.median(dc[ok] / dr[ok] * 100.0))
