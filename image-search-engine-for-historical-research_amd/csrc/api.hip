@@ -241,6 +241,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.cond = cond;
     a.dbg = ws.dbg;
     a.st = st;
+    profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
     size_t slot = (size_t)-1;
     if (profile_it) prof_begin(g, s, &slot);
     launch_gemm_select(a, first_chunk, s);

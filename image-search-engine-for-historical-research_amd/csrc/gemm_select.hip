@@ -55,7 +55,9 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
-template <bool FIRST, int DBG, bool F16>
+// REPAIR: the conditional second pass of the speculative schedule (its own instantiation, so that profiles of the
+// main launch are not diluted by repair launches that exit immediately)
+template <bool FIRST, int DBG, bool F16, bool REPAIR = false>
 __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // rings | per-wave scratch | per-wave thresholds  (ONE LDS object)
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // ---- work assignment.  Blocks b, b+8, ... share an XCD (round-robin dispatch; speed only).  XCD label x
   // owns gallery tiles tl = x (mod 8); its virtual list v -> (tl = (v / nqt) * 8 + x, qt = v % nqt) is dealt
   // round-robin to the nwg blocks of that label, so concurrently running blocks share gallery tiles.
-  if (p.cond && *p.cond == 0) return;                           // repair pass that is not needed
+  if (REPAIR && *p.cond == 0) return;                           // repair pass that is not needed
   const uint32_t b = blockIdx.x, nwg = gridDim.x >> 3;
   const uint32_t xcd = b & 7u, j = b >> 3;
   const uint32_t nqt = (uint32_t)p.nqt;
@@ -401,19 +403,21 @@ void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_
   hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(256), 0, stream, rec, rec_cnt, rec_cap, st, cond);
 }
 
-template <bool FIRST, int DBG, bool F16>
+template <bool FIRST, int DBG, bool F16, bool REPAIR = false>
 static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_select_kernel<FIRST, DBG, F16>,
+    (void)hipFuncSetAttribute((const void*)gemm_select_kernel<FIRST, DBG, F16, REPAIR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * 64 * 4;
+  if (a.cond) return a.img_f16 ? launch_variant<false, 0, true, true>(a, lds, stream)
+                               : launch_variant<false, 0, false, true>(a, lds, stream);
   if (a.img_f16) {
     if (first) return launch_variant<true, 0, true>(a, lds, stream);
     switch (a.debug) {

@@ -4,13 +4,14 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
-shutil.copy(glob.glob(f"{go}/{tag}_trace/*/*kernel_stats.csv")[0], f"{pr}/{tag}_kernel_stats.csv")
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+shutil.copy(newest(f"{go}/{tag}_trace/*/*kernel_stats.csv"), f"{pr}/{tag}_kernel_stats.csv")
 bench = [l for l in open(f"{go}/{tag}_bench.json") if l.startswith("{")][-1]
 open(f"{pr}/{tag}_bench.json", "w").write(bench)
 out = {"bench": json.loads(bench)}
 def counters(sub):
     agg = collections.defaultdict(list)
-    for f in glob.glob(f"{go}/{tag}_{sub}/*/*counter_collection.csv"):
+    for f in [newest(f"{go}/{tag}_{sub}/*/*counter_collection.csv")] if glob.glob(f"{go}/{tag}_{sub}/*/*counter_collection.csv") else []:
         for r in csv.DictReader(open(f)):
             agg[(r["Kernel_Name"].split("(")[0].replace("void mi::", "").replace("mi::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
     return agg
@@ -19,17 +20,24 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     for (k, c), v in counters(sub).items():
         pm.setdefault(k, {})[c] = {"launches": len(v), "sum": sum(v), "max": max(v)}
 out["pmc"] = pm
-# HBM traffic of the dominant kernel per launch (largest launch = the final chunk), gfx950 corrections from
-# MI355X_MICROARCH.md: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream -> x2; WRITE_SIZE exact.
-g = pm.get("gemm_select_kernel<false, 0>", {})
-if "FETCH_SIZE" in g:
-    n = g["FETCH_SIZE"]["launches"]
-    fetch = g["FETCH_SIZE"]["sum"] * 1024 * 2 / n
-    write = g.get("WRITE_SIZE", {"sum": 0})["sum"] * 1024 / max(1, g.get("WRITE_SIZE", {"launches": 1})["launches"])
-    out["gemm_select_hbm_bytes_per_launch"] = fetch + write
-    out["gemm_select_hbm_bytes_per_batch"] = (fetch + write) * 3      # three filtered launches per batch
-    if "TCC_HIT_sum" in g:
-        out["gemm_select_l2_hit_rate"] = g["TCC_HIT_sum"]["sum"] / (g["TCC_HIT_sum"]["sum"] + g["TCC_MISS_sum"]["sum"])
+# HBM traffic of the dominant kernel, per launch = the big filtered scoring launch of a batch (conditional repair
+# launches that exit immediately are ignored).  gfx950 corrections from MI355X_MICROARCH.md: FETCH_SIZE is in KiB and
+# reads exactly half of a wide coalesced stream -> x2; WRITE_SIZE (KiB) exact.
+def per_launch_values(sub, counter):
+    vals = []
+    for f in [newest(f"{go}/{tag}_{sub}/*/*counter_collection.csv")] if glob.glob(f"{go}/{tag}_{sub}/*/*counter_collection.csv") else []:
+        for r in csv.DictReader(open(f)):
+            if ("gemm_select_kernel<false, 0, true, false>" in r["Kernel_Name"] or "gemm_select_kernel<false, 0, false, false>" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    return vals
+fv, wv = per_launch_values("pmc_fetch", "FETCH_SIZE"), per_launch_values("pmc_write", "WRITE_SIZE")
+if fv:
+    big_f = [v for v in fv if v > 0.5 * max(fv)]
+    big_w = [v for v in wv if v > 0.5 * max(wv)] if wv else [0.0]
+    out["gemm_select_hbm_bytes_per_launch"] = sum(big_f) / len(big_f) * 1024 * 2 + sum(big_w) / len(big_w) * 1024
+    hv, mv = per_launch_values("pmc_l2", "TCC_HIT_sum"), per_launch_values("pmc_l2", "TCC_MISS_sum")
+    if hv and mv:
+        out["gemm_select_l2_hit_rate"] = sum(hv) / (sum(hv) + sum(mv))
 json.dump(out, open(f"{pr}/{tag}_pmc_summary.json", "w"), indent=1)
 json.dump({"gemm_select_hbm_bytes_per_launch": out.get("gemm_select_hbm_bytes_per_launch"), "source": f"profiles/{tag}_pmc_summary.json"},
           open(f"{pr}/pmc_traffic.json", "w"))
