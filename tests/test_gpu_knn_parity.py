@@ -207,3 +207,26 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
     assert oracle.check_topk_parity(idx, s, k, TAU) == []
     assert set(rows) <= set(idx[0])
     assert (st["overflow_batches"] >= 1) == expect_fallback
+
+
+def test_bf16_image_path_gives_the_same_answers(lib, golden_dir):
+    """The image element type only changes the width of the error margin, never the result."""
+    from isehr_amd import _lib
+    n, d, nq, k = 30000, 256, 40, 100
+    g = synth_rows(81, 0, n, d)
+    q = synth_rows(82, 0, nq, d)
+    res = {}
+    try:
+        for name, flag in (("f16", 1), ("bf16", 0)):
+            _lib.set_global_option("image_dtype", flag)
+            G = _lib.Gallery.from_host(g)
+            idx, sc, _ = G.search(q, k)
+            st = G.status()
+            G.close()
+            res[name] = (idx, sc, st["candidates"] / st["queries"])
+    finally:
+        _lib.set_global_option("image_dtype", 1)
+    assert np.array_equal(res["f16"][0], res["bf16"][0]) and np.array_equal(res["f16"][1], res["bf16"][1])
+    assert res["f16"][2] < res["bf16"][2]            # tighter certificate -> fewer rows re-scored
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(res["bf16"][0], s, k, TAU) == []
