@@ -1032,7 +1032,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "chunk_growth") { REQUIRE(value >= 1, "chunk_growth >= 1"); g->chunk_growth = (int)value; }
   else if (n == "survivor_cap") {
     const uint32_t v = (uint32_t)value;
-    REQUIRE(v >= 1024 && v <= 12288 && (v % 256) == 0, "survivor_cap: multiple of 256 in [1024, 12288]");
+    REQUIRE(v >= 1024 && v <= 16384 && (v % 256) == 0, "survivor_cap: multiple of 256 in [1024, 16384]");
     g->surv_cap = v;
   } else if (n == "rescore_cap") {
     const uint32_t v = (uint32_t)value;

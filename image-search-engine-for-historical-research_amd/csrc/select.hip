@@ -106,7 +106,7 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // Only the 4-byte keys live in LDS (cap * 4 + 1 KiB -> 3 workgroups per CU); the 8-byte entries stay in
 // registers between the read and the in-place compaction (all reads complete before the first write).
 constexpr int MAINT_THREADS = 512;
-constexpr int MAINT_PER_THREAD = 24;            // 512 * 24 = 12288 = largest survivor_cap
+constexpr int MAINT_PER_THREAD = 32;            // 512 * 32 = 16384 = largest survivor_cap
 
 // MODE 0 (after the bootstrap chunk).  spec_r > 0: SPECULATIVE threshold for the single remaining scoring launch =
 //   the spec_r-th largest sample score (>= K rows above it exist in the whole shard with probability 1 - 1e-6, see
@@ -153,8 +153,38 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
   float thr_new = L - st.margin[q];
   float thr2 = thr_new;
   if (MODE == 0 && spec_r > 0 && n >= (uint32_t)k) {
-    if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest(keys, n, (uint32_t)spec_r, hist, sh)));
-    if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(block_kth_largest(keys, n, (uint32_t)(4 * spec_r), hist, sh)));
+    // the spec_r-th and (4 spec_r)-th largest lie among the keys >= keyL (spec_r, 4 spec_r < k): gather those (k plus
+    // ties, normally ~k) into the histogram scratch and rank them by counting instead of two more full radix selects
+    __syncthreads();
+    if (threadIdx.x == 0) sh[3] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+      if (keys[i] >= keyL) {
+        const uint32_t pos = atomicAdd(&sh[3], 1u);
+        if (pos < 256) hist[pos] = keys[i];
+      }
+    __syncthreads();
+    const uint32_t m = sh[3];
+    uint32_t want[2] = {(uint32_t)spec_r, (uint32_t)(4 * spec_r)};
+    __syncthreads();
+    if (m <= 256) {
+      if (threadIdx.x < m) {
+        const uint32_t me = hist[threadIdx.x];
+        uint32_t gt = 0, ge = 0;
+        for (uint32_t j = 0; j < m; ++j) { gt += hist[j] > me; ge += hist[j] >= me; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (want[t] < (uint32_t)k && gt < want[t] && want[t] <= ge) sh[4 + t] = me;
+      }
+      __syncthreads();
+      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(sh[4]));
+      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(sh[5]));
+    } else {                                        // a crowd of ties at the K-th score: plain selects
+      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest(keys, n, (uint32_t)spec_r, hist, sh)));
+      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(block_kth_largest(keys, n, (uint32_t)(4 * spec_r), hist, sh)));
+    }
+    if (threadIdx.x == 0) sh[3] = 0;
+    __syncthreads();
   }
   bool failed = false;
   if (MODE == 1 && spec) {
@@ -215,7 +245,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream) {
-  const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;
+  const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;      // keys | hist[256] | sh[8]
   if (mode == 0)
     hipLaunchKernelGGL(select_maintain_kernel<0>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
                        stats2, spec_r, spec, repair, cond);
