@@ -61,6 +61,8 @@ SIGNATURES = {
                                 C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_f64p]),
     "mi_knn_dense_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_rank_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
+                              C.c_void_p, c_f64p]),
     "mi_diffusion_offline": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -229,6 +231,21 @@ class Gallery:
                                              idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
                                              C.byref(secs)))
         return idx, sc, secs.value
+
+    def rank_all(self, queries, query_norm=-1, return_scores=False):
+        """Full-length ranking: -> (idx int64 [Q,N][, scores float32 [Q,N]], seconds)."""
+        a, code, rs, cs = _strided(queries)
+        if a.shape[1] != self.d:
+            raise ValueError("query dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        nq = a.shape[0]
+        idx = np.empty((nq, self.n), dtype=np.int64)
+        sc = np.empty((nq, self.n), dtype=np.float32) if return_scores else None
+        secs = C.c_double()
+        with self._lock:
+            check(load().mi_rank_all(self._h, C.c_void_p(_base_pointer(a)), nq, code, rs, cs, query_norm,
+                                     idx.ctypes.data_as(C.c_void_p),
+                                     sc.ctypes.data_as(C.c_void_p) if return_scores else None, C.byref(secs)))
+        return (idx, sc, secs.value) if return_scores else (idx, secs.value)
 
     def diffusion_offline(self, n_trunc, kd, alpha=0.99, gamma=3, maxiter=20, tol=1e-6, return_sims=False):
         """-> (ids int64 [N,n_trunc], vals float32 [N,n_trunc][, knn sims float32 [N,n_trunc]])."""

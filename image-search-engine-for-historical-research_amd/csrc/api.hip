@@ -864,6 +864,63 @@ int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int
   return MI_OK;
 }
 
+int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                int query_norm, int64_t* out_idx, float* out_score, double* out_seconds) {
+  REQUIRE(g && q && out_idx, "null pointer");
+  REQUIRE(nq >= 1, "no queries");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  REQUIRE(query_norm >= -1 && query_norm <= 2, "query_norm: -1 (as the gallery) or an mi_norm value");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  const int qn = query_norm < 0 ? g->norm_mode : query_norm;
+  int64_t elems;
+  int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  if ((rc = ws_ensure(g, 1)) != MI_OK) return rc;
+  Workspace& ws = g->ws;
+  hipStream_t s = g->stream;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  const int64_t n = g->n;
+  const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(128, ((int64_t)1 << 28) / n));
+  TmpAlloc tmp;
+  char* qd = tmp.get<char>((size_t)elems * esz);
+  float* dense = tmp.get<float>((size_t)round_up(qb, 64) * n);
+  uint32_t* ka = tmp.get<uint32_t>((size_t)qb * n);
+  uint32_t* ia = tmp.get<uint32_t>((size_t)qb * n);
+  uint32_t* kb = tmp.get<uint32_t>((size_t)qb * n);
+  uint32_t* ib = tmp.get<uint32_t>((size_t)qb * n);
+  int64_t* oi = tmp.get<int64_t>((size_t)qb * n);
+  float* os = out_score ? tmp.get<float>((size_t)qb * n) : nullptr;
+  if (!qd || !dense || !ka || !ia || !kb || !ib || !oi || (out_score && !os)) return fail(MI_ERR_NOMEM, "rank_all buffers");
+  HIPC(hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice));
+  for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+    const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
+    const int32_t qpad = (int32_t)round_up(b, TILE);
+    launch_ingest(qd + (size_t)q0 * row_stride * esz, dtype, b, g->d, row_stride, col_stride, qn, ws.q_f32, ws.q_bf16,
+                  g->img_f16, ws.q_stat, g->dp, qpad, s);
+    ExactArgs a;
+    a.gal_f32 = g->gal_f32;
+    a.qry_f32 = ws.q_f32;
+    a.dp = g->dp;
+    a.row0 = 0;
+    a.row1 = n;
+    a.n = n;
+    a.nq = b;
+    a.st = make_state(ws);
+    a.dense_out = dense;
+    a.dense_ld = n;
+    launch_exact_select(a, false, s);
+    launch_rank_all(dense, n, n, b, ka, ia, kb, ib, g->row_offset, oi, os, s);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s));
+    HIPC(hipMemcpy(out_idx + q0 * n, oi, (size_t)b * n * 8, hipMemcpyDeviceToHost));
+    if (out_score) HIPC(hipMemcpy(out_score + q0 * n, os, (size_t)b * n * 4, hipMemcpyDeviceToHost));
+  }
+  if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return MI_OK;
+}
+
 int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
                     const double* m, const double* P, int32_t dims, double eps, int device, double* out) {
   REQUIRE(X && m && P && out, "null pointer");

@@ -124,6 +124,117 @@ __global__ __launch_bounds__(512) void dense_topk_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Full-length ranking: `np.argsort(-scores, axis=0)` over ALL rows (src/main_retrieve.py:176,
+// src/utils/Reranking.py:207, --mode mAP of src/test_rOP1m.py:144-149).  One 1024-thread workgroup per query runs a
+// stable LSD radix sort (4 passes of 8 bits) on key = ~f2key(score) with the row index as payload, so the result is
+// (score descending, index ascending; NaN last).  Every wave owns a contiguous segment of the array: per-wave digit
+// histograms -> offsets ordered (digit, wave) -> each wave scatters its own segment in order, ranking equal digits
+// inside a 64-element step with ballots.  Waves never touch each other's offsets, so no sync inside the scatter.
+constexpr int RANK_THREADS = 1024, RANK_WAVES = 16;
+
+__global__ __launch_bounds__(RANK_THREADS) void rank_all_kernel(const float* __restrict__ scores, int64_t ld, uint32_t n,
+                                                                 uint32_t* __restrict__ keys_a, uint32_t* __restrict__ idx_a,
+                                                                 uint32_t* __restrict__ keys_b, uint32_t* __restrict__ idx_b,
+                                                                 int64_t row_offset, int64_t* __restrict__ out_idx,
+                                                                 float* __restrict__ out_score) {
+  __shared__ uint32_t hist[RANK_WAVES][256];
+  __shared__ uint32_t total[256];
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* row = scores + (uint64_t)q * ld;
+  uint32_t* ka = keys_a + (uint64_t)q * n;
+  uint32_t* ia = idx_a + (uint64_t)q * n;
+  uint32_t* kb = keys_b + (uint64_t)q * n;
+  uint32_t* ib = idx_b + (uint64_t)q * n;
+  const uint32_t seg = (n + RANK_WAVES - 1) / RANK_WAVES;
+  const uint32_t s0 = min(n, w * seg), s1 = min(n, s0 + seg);
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    const uint32_t* ksrc = (pass & 1) ? kb : ka;
+    const uint32_t* isrc = (pass & 1) ? ib : ia;
+    uint32_t* kdst = (pass & 1) ? ka : kb;
+    uint32_t* idst = (pass & 1) ? ia : ib;
+    for (uint32_t i = lane; i < 256; i += 64) hist[w][i] = 0;
+    __syncthreads();
+    for (uint32_t i = s0 + lane; i < s1; i += 64) {
+      const uint32_t key = pass == 0 ? ~f2key(row[i]) : ksrc[i];
+      atomicAdd(&hist[w][(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // offsets in (digit, wave) order: thread d < 256 owns digit d
+    if (threadIdx.x < 256) {
+      uint32_t t = 0;
+      for (int ww = 0; ww < RANK_WAVES; ++ww) t += hist[ww][threadIdx.x];
+      total[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                 // exclusive scan of 256 totals by one wave (4 per lane)
+      const uint32_t t0 = total[4 * lane], t1 = total[4 * lane + 1], t2 = total[4 * lane + 2], t3 = total[4 * lane + 3];
+      uint32_t sum = t0 + t1 + t2 + t3, inc = sum;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+      }
+      const uint32_t ex = inc - sum;
+      total[4 * lane] = ex;
+      total[4 * lane + 1] = ex + t0;
+      total[4 * lane + 2] = ex + t0 + t1;
+      total[4 * lane + 3] = ex + t0 + t1 + t2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      uint32_t run = total[threadIdx.x];
+      for (int ww = 0; ww < RANK_WAVES; ++ww) {
+        const uint32_t c = hist[ww][threadIdx.x];
+        hist[ww][threadIdx.x] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    // stable scatter of this wave's segment
+    for (uint32_t base = s0; base < s1; base += 64) {
+      const uint32_t i = base + lane;
+      const bool valid = i < s1;
+      uint32_t key = 0, id = 0;
+      if (valid) {
+        key = pass == 0 ? ~f2key(row[i]) : ksrc[i];
+        id = pass == 0 ? i : isrc[i];
+      }
+      const uint32_t d = (key >> shift) & 255u;
+      unsigned long long same = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        same &= ((d >> b) & 1u) ? m : ~m;
+      }
+      if (valid) {
+        const uint32_t rank = (uint32_t)__popcll(same & lt);
+        const uint32_t pos = hist[w][d] + rank;
+        kdst[pos] = key;
+        idst[pos] = id;
+      }
+      // the last lane of every digit group advances that digit's offset (after all lanes of the wave have read it)
+      if (valid && (same >> lane) == 1ull) hist[w][d] += (uint32_t)__popcll(same);
+    }
+    __syncthreads();
+  }
+  // 4 passes: the result is back in the A buffers
+  for (uint32_t i = threadIdx.x; i < n; i += RANK_THREADS) {
+    const uint32_t id = ia[i];
+    out_idx[(uint64_t)q * n + i] = row_offset + (int64_t)id;
+    if (out_score) out_score[(uint64_t)q * n + i] = row[id];
+  }
+}
+
+void launch_rank_all(const float* scores, int64_t ld, int64_t n, int32_t nq, uint32_t* keys_a, uint32_t* idx_a,
+                     uint32_t* keys_b, uint32_t* idx_b, int64_t row_offset, int64_t* out_idx, float* out_score,
+                     hipStream_t stream) {
+  hipLaunchKernelGGL(rank_all_kernel, dim3(nq), dim3(RANK_THREADS), 0, stream, scores, ld, (uint32_t)n, keys_a, idx_a,
+                     keys_b, idx_b, row_offset, out_idx, out_score);
+}
+
 void launch_dense_topk(const float* scores, int64_t ld, int64_t n, int32_t nq, int32_t k, int64_t row_offset,
                        int64_t* out_idx, float* out_score, hipStream_t stream) {
   uint32_t k2 = 2;

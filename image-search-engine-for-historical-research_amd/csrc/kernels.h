@@ -72,6 +72,10 @@ void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, in
 void launch_dense_topk(const float* scores, int64_t ld, int64_t n, int32_t nq, int32_t k, int64_t row_offset,
                        int64_t* out_idx, float* out_score, hipStream_t stream);
 
+void launch_rank_all(const float* scores, int64_t ld, int64_t n, int32_t nq, uint32_t* keys_a, uint32_t* idx_a,
+                     uint32_t* keys_b, uint32_t* idx_b, int64_t row_offset, int64_t* out_idx, float* out_score,
+                     hipStream_t stream);
+
 // diffusion.hip
 void launch_affinity(const int64_t* ids, const float* sims, int64_t ld, int64_t n, int32_t kd, int32_t gamma,
                      float alpha, float* lap, float* dinv, float* diag, hipStream_t stream);

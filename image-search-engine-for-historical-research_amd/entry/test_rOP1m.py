@@ -28,12 +28,12 @@ parser.add_argument("--gpu-id", "-g", default="0")
 
 def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0):
     n = vecs.shape[1]
-    K = min(n, 2048) if mode == "mAP" else int(mode)      # full-length ranking: SURVEY.md §8 f-3
+    K = n if mode == "mAP" else int(mode)                 # 'mAP' ranks the whole database (src/test_rOP1m.py:144-149)
     match_idx, time_per_query = matching_HIP(K, vecs.T, qvecs.T, device=device)
     ranks = match_idx.T
     print(">> {}: average matching time: {}".format(dataset, time_per_query))
     res = {"map": evaluate.compute_map_and_print(dataset, ranks, gnd)}
-    res["qge"] = QGE_hip(ranks, qvecs, vecs, dataset, gnd, K=K, device=device)
+    res["qge"] = QGE_hip(ranks, qvecs, vecs, dataset, gnd, K=min(K, 2048), device=device)
     return res
 
 

@@ -22,6 +22,8 @@ import numpy as np
 from . import _lib
 from ._lib import Gallery, NORM_L2, NORM_NONE, NORM_L2_EPS  # noqa: F401
 
+TOPK_PATH_MAX_K = 2048      # beyond this the full-length ranking path is used
+
 _cache = {}
 _cache_lock = threading.Lock()
 
@@ -80,7 +82,15 @@ def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=Non
     num_test = np.shape(embedded_features_test)[0]
     g = get_gallery(embedded_features_train, dataset, ifgenerate, NORM_L2, device)
     try:
-        idx, scores, _ = g.search(embedded_features_test, int(K))
+        if int(K) > TOPK_PATH_MAX_K:
+            # deep / full-length ranking (--mode mAP ranks the whole database, src/test_rOP1m.py:144-149):
+            # dense exact scores + per-query radix sort, then the first K columns
+            idx, scores, _ = g.rank_all(embedded_features_test, return_scores=True)
+            if int(K) > idx.shape[1]:
+                raise RuntimeError("mi355_retrieval error 1: k > number of gallery rows")
+            idx, scores = np.ascontiguousarray(idx[:, :int(K)]), np.ascontiguousarray(scores[:, :int(K)])
+        else:
+            idx, scores, _ = g.search(embedded_features_test, int(K))
     finally:
         if dataset is None:
             g.close()
@@ -94,6 +104,17 @@ def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=Non
 def matching_L2_hip(K, embedded_features_train, embedded_features_test):
     """Same signature as matching_L2 (src/utils/nnsearch.py:687)."""
     return matching_HIP(K, embedded_features_train, embedded_features_test)
+
+
+def ip_rank_hip(vecs, qvecs, dataset=None, ifgenerate=False, device=0, return_scores=False):
+    """`ranks = np.argsort(-(vecs.T @ qvecs), axis=0)` in full (src/main_retrieve.py:175-176): int64 [N,Q]."""
+    g = get_gallery(np.asarray(vecs).T, dataset, ifgenerate, NORM_NONE, device)
+    try:
+        out = g.rank_all(np.asarray(qvecs).T, return_scores=return_scores)
+    finally:
+        if dataset is None:
+            g.close()
+    return (out[0].T, out[1].T) if return_scores else out[0].T
 
 
 def ip_topk_hip(vecs, qvecs, K, dataset=None, ifgenerate=False, device=0):

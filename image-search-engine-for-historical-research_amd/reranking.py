@@ -33,10 +33,21 @@ def feature_enhancement_hip(k, ranks, vecs, w, K, dataset=None, ifgenerate=False
     return qx.T, idx.T
 
 
-def qge1_hip(ranks, qvec, vecs, K, dataset=None, ifgenerate=False, device=0):
+def qge1_hip(ranks, qvec, vecs, K, dataset=None, ifgenerate=False, device=0, full=False):
     """Online single-query re-ranking: k = 3, w = 4.0, one pass (src/utils/Reranking.py:302-305).
-    Returns ranks_aqe[:K] (int64 [K,Q]); `qvec` is unused, as in the reference."""
-    return feature_enhancement_hip(3, ranks, vecs, 8.0 / 2, K, dataset, ifgenerate, device)[1]
+    Returns ranks_aqe[:K] (int64 [K,Q]); `qvec` is unused, as in the reference.  full=True returns the
+    reference's complete [N,Q] ranking (full-length radix-sort path)."""
+    if not full:
+        return feature_enhancement_hip(3, ranks, vecs, 8.0 / 2, K, dataset, ifgenerate, device)[1]
+    g = get_gallery(np.asarray(vecs).T, dataset, ifgenerate, NORM_NONE, device)
+    try:
+        kq = min(int(K), 16) if K else 16
+        _, _, qx, _ = g.aqe_search(np.asarray(ranks)[:3], 3, 8.0 / 2, kq, eps=1e-6, return_qexp=True)
+        idx, _ = g.rank_all(qx, query_norm=NORM_NONE)          # the expanded query is used as is
+    finally:
+        if dataset is None:
+            g.close()
+    return idx.T
 
 
 def QGE_hip(ranks, qvecs, vecs, dataset, gnd, cache_dir=None, gnd_path2=None, AQE=True, K=None, device=0,

@@ -127,6 +127,13 @@ int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int
                         int64_t col_stride, int32_t k, int64_t* out_idx, float* out_score,
                         double* out_seconds);
 
+/* ---- full-length ranking: `np.argsort(-scores, axis=0)` over ALL rows (src/main_retrieve.py:176,
+ * src/utils/Reranking.py:207; --mode mAP of src/test_rOP1m.py:144-149).  Exact f32 inner products, stable radix sort:
+ * out_idx [nq][n] (score desc, idx asc, NaN last), out_score [nq][n] (may be NULL).  query_norm: -1 = normalise the
+ * queries like the gallery, otherwise an mi_norm value (MI_NORM_NONE for an already expanded query). */
+int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                int query_norm, int64_t* out_idx, float* out_score, double* out_seconds);
+
 /* ---- truncated graph diffusion: Diffusion.get_offline_results (src/utils/diffusion.py:52-84 with :15-19, :87-116)
  * on a MI_NORM_NONE gallery of the features.  out_ids [n][n_trunc] (the kNN lists = columns of the sparse
  * `offline` matrix), out_vals [n][n_trunc] f32 (its values), out_knn_sims (may be NULL).  The result also stays

@@ -210,3 +210,48 @@ def test_whitenapply_golden(golden_dir):
     got = whitenapply_hip(Xb, mb, Pb, 200)
     ref = oracle.whitenapply(Xb.astype(np.float64), mb, Pb, 200)
     assert got.shape == (200, 700) and np.abs(got - ref).max() < 1e-12
+
+
+def test_full_length_ranking_vs_reference_golden(golden_dir):
+    """f-3: the complete argsort(-(vecs.T @ qvecs), axis=0) -- every one of the N positions."""
+    from isehr_amd.nnsearch import ip_rank_hip, matching_HIP
+    z = np.load(os.path.join(golden_dir, "ip_rank.npz"))
+    seed, n, d, nq = (int(v) for v in z["meta"])
+    vecs, qv = _setup(seed, n, d, nq)
+    ranks, scores = ip_rank_hip(vecs, qv, return_scores=True)
+    assert ranks.shape == (n, nq) and ranks.dtype == np.int64
+    assert all(np.array_equal(np.sort(ranks[:, j]), np.arange(n)) for j in range(nq))      # a permutation
+    s64 = vecs.astype(np.float64).T @ qv.astype(np.float64)                                 # [N,Q]
+    got = np.take_along_axis(s64, ranks, 0)
+    tol = 2e-6 * float(np.abs(s64).max())
+    assert (np.diff(got, axis=0) <= tol).all()                                              # sorted up to f32 near-ties
+    assert (ranks[:200] == z["ranks_top"]).mean() > 0.99
+    ref_ranks, _ = oracle.ip_rank(vecs, qv)
+    assert (ranks == ref_ranks).mean() > 0.98
+    # matching_HIP with K = N (the --mode mAP case) goes through the same path
+    idx, _ = matching_HIP(n, vecs.T, qv.T)
+    sc = oracle.exact_scores_f64(vecs.T, qv.T)
+    assert oracle.check_topk_parity(idx, sc, n, TAU) == []
+
+
+def test_full_length_ranking_ties_and_qge1_full():
+    from isehr_amd._lib import Gallery, NORM_NONE
+    from isehr_amd.reranking import qge1_hip
+    g = synth_rows(91, 0, 3000, 48)
+    g[100:140] = g[7]                      # 41 exact ties
+    q = g[[7, 2500]].copy()
+    G = Gallery.from_host(g, norm_mode=NORM_NONE)
+    idx, sc, _ = G.rank_all(q, return_scores=True)
+    G.close()
+    tie_block = np.concatenate([[7], np.arange(100, 140)])
+    pos = np.flatnonzero(np.isin(idx[0], tie_block))
+    assert np.array_equal(idx[0, pos], tie_block) and pos.max() - pos.min() == 40          # contiguous, index order
+    assert (np.diff(sc, axis=1) <= 0).all()
+    vecs = np.ascontiguousarray((g / np.linalg.norm(g, axis=1, keepdims=True)).T)
+    qv = vecs[:, [5, 9]]
+    base = np.argsort(-(vecs.T @ qv), axis=0)[:10]
+    full = qge1_hip(base, qv, vecs, 10, full=True)
+    ref = oracle.qge1(base, qv, vecs, 10)
+    assert full.shape == ref.shape == (3000, 2)
+    assert (full == ref).mean() > 0.97
+    assert np.array_equal(full[:10], qge1_hip(base, qv, vecs, 10))
