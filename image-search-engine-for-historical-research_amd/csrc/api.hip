@@ -54,7 +54,7 @@ struct Workspace {
   SurvRec* rec = nullptr;
   uint32_t* rec_cnt = nullptr;
   unsigned long long* dbg = nullptr;
-  uint32_t rec_cap = 2048, nseg = 0;
+  uint32_t rec_cap = 4096, nseg = 0;
   std::vector<void*> allocs;
 };
 }  // namespace
@@ -134,7 +134,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cand_cnt, QB);
   A(cand_score, (size_t)QB * ws.rcap);
   A(stats2, 4);
-  ws.rec_cap = 2048;
+  ws.rec_cap = 4096;          // records per wave segment and launch (K = 1000 at 1M rows needs ~1800)
   ws.nseg = gemm_select_grid() * 8;
   A(rec, (size_t)ws.nseg * ws.rec_cap);
   A(rec_cnt, ws.nseg);
