@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--option", action="append", default=[], help="name=value passed to mi_set_option")
     ap.add_argument("--image-dtype", default="f16", choices=["f16", "bf16"],
                     help="element type of the streamed 16-bit operand image (MFMA input type)")
+    ap.add_argument("--with-aqe", action="store_true",
+                    help="BASELINE configs[4]: every step = search + alpha-QE (k=3, w=4) re-search of the expanded queries")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -135,15 +137,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_step(qb):
+        idx_, sc_ = sg.search(qb, k)
+        if args.with_aqe:
+            # ranks[K,Q] view of the [Q,K] result, like `ranks = match_idx.T` (src/test_rOP1m.py:157) -> QGE (N >= 120000)
+            idx_, sc_, _ = sg.aqe_search(idx_.t(), 3, 4.0, k)
+        return idx_, sc_
+
     for i in range(args.warmup):
-        sg.search(pool[i % len(pool)], k)
+        one_step(pool[i % len(pool)])
     barrier()
     gal.status(reset=True)
     gal.profile(True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        idx, sc = sg.search(pool[i % len(pool)], k)
+        idx, sc = one_step(pool[i % len(pool)])
     barrier()
     elapsed = time.perf_counter() - t0
     gal.profile(False)
@@ -187,7 +196,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
                        "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
-                       "parallelism": "row-shard x%d" % world, "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
+                       "parallelism": "row-shard x%d" % world, "alpha_qe": bool(args.with_aqe), "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        "ingest_s": round(ingest_s, 3),
                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                        "survivors_per_query": st["survivors"] / max(1, st["queries"])},

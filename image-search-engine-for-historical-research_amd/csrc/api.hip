@@ -73,6 +73,7 @@ struct mi_gallery {
   Workspace ws;
   // options
   int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0, speculative = 1;
+  int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
   mi_search_stats stats{};
@@ -644,8 +645,8 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   REQUIRE(g && q_dev && out_idx_dev, "null pointer");
   REQUIRE(nq >= 1, "no queries");
   HIPC(hipSetDevice(g->device));
-  return search_device(g, q_dev, MI_F32, g->d, 1, g->norm_mode, nq, k, out_idx_dev, out_score_dev, out_score64_dev,
-                       g->force_exact != 0, (hipStream_t)stream);
+  return search_device(g, q_dev, MI_F32, g->d, 1, g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode, nq, k,
+                       out_idx_dev, out_score_dev, out_score64_dev, g->force_exact != 0, (hipStream_t)stream);
 }
 
 int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t k, float* out_approx_dev,
@@ -660,7 +661,8 @@ int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   if (rc != MI_OK) return rc;
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = phase1_batch(g, q_dev, MI_F32, g->d, 1, g->norm_mode, (int32_t)nq, kl, g->force_exact != 0, s)) != MI_OK)
+  if ((rc = phase1_batch(g, q_dev, MI_F32, g->d, 1, g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode,
+                         (int32_t)nq, kl, g->force_exact != 0, s)) != MI_OK)
     return rc;
   if (kl == k) {
     HIPC(hipMemcpyAsync(out_approx_dev, g->ws.topvals, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
@@ -1099,6 +1101,10 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "force_exact") g->force_exact = value != 0;
   else if (n == "debug") g->debug = (int)value;
   else if (n == "speculative") g->speculative = value != 0;
+  else if (n == "query_norm_override") {
+    REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
+    g->qnorm_override = (int)value;
+  }
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
   return MI_OK;
 }

@@ -61,9 +61,21 @@ class ShardedGallery:
                 osc=torch.empty((nq, k), dtype=torch.float32, device=device))
         return self._buf[key]
 
-    def search(self, q, k):
+    def search(self, q, k, query_norm_none=False):
         """q: [Q, D] float32 cuda tensor (same on every rank), Q <= 1024.
-        Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank."""
+        Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.
+        query_norm_none: use the queries as they are (expanded queries of alpha-QE)."""
+        import torch
+        nq = q.shape[0]
+        if query_norm_none:
+            self.g.set_option("query_norm_override", _lib.NORM_NONE)
+        try:
+            return self._search(q, k)
+        finally:
+            if query_norm_none:
+                self.g.set_option("query_norm_override", -1)
+
+    def _search(self, q, k):
         import torch
         nq = q.shape[0]
         b = self._buffers(nq, k, q.device)
@@ -81,3 +93,25 @@ class ShardedGallery:
         _lib.topk_merge_device(g_sc.data_ptr(), g_idx.data_ptr(), self.world, nq, k, b["oidx"].data_ptr(),
                                b["osc"].data_ptr(), stream)
         return b["oidx"], b["osc"]
+
+    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6):
+        """alpha-QE across shards (src/utils/Reranking.py:195-208): every rank adds the rows it owns into a
+        float64 partial sum [Q, D] (`mi_aqe_partial_device`), the partials are all-reduced (8 MiB at Q = 1024,
+        D = 2048, f64: the rows of one query may live on any shard), every rank normalises redundantly
+        (`mi_aqe_finish_device`) and the expanded queries go through the sharded search as they are (no second
+        normalisation).  ranks: int64 cuda tensor [K_in, Q] of GLOBAL row ids (any strides).
+        Returns (idx [Q,k], score [Q,k], q_exp float32 [Q,D])."""
+        import torch
+        import torch.distributed as dist
+        nq = ranks.shape[1]
+        d = self.g.d
+        stream = torch.cuda.current_stream().cuda_stream
+        part = torch.empty((nq, d), dtype=torch.float64, device=ranks.device)
+        self.g.aqe_partial_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, w, part.data_ptr(),
+                                  stream)
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        qx = torch.empty((nq, d), dtype=torch.float32, device=ranks.device)
+        _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)
+        idx, sc = self.search(qx, k, query_norm_none=True)
+        return idx, sc, qx

@@ -170,7 +170,9 @@ typedef struct mi_search_stats {
 int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches with hipEvents */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
 /* Tunables: "chunk0_tiles", "chunk_growth", "survivor_cap", "rescore_cap", "exact_fallback",
- * "force_exact" (score with the f32 kernel instead of bf16 MFMA). */
+ * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
+ * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
+ * already normalised expanded queries of alpha-QE). */
 int mi_set_option(mi_gallery* g, const char* name, double value);
 
 /* Process-wide defaults for galleries created afterwards.  "image_dtype": element type of the 16-bit tile-blocked image the

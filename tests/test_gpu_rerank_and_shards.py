@@ -255,3 +255,43 @@ def test_full_length_ranking_ties_and_qge1_full():
     assert full.shape == ref.shape == (3000, 2)
     assert (full == ref).mean() > 0.97
     assert np.array_equal(full[:10], qge1_hip(base, qv, vecs, 10))
+
+
+def test_alpha_qe_across_shards_equals_single_shard():
+    """e: per-shard partial sums of the gathered rows (f64) add up to the single-shard expanded query, and the
+    re-search of the expanded queries over the shards equals the single-shard alpha-QE result."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import shard_bounds, ShardedGallery
+    n, d, nq, k = 20000, 128, 17, 50
+    g = synth_rows(55, 0, n, d)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    qh = synth_rows(56, 0, nq, d)
+    single = _lib.Gallery.from_host(g, norm_mode=_lib.NORM_NONE)
+    base, _, _ = single.search(qh / np.linalg.norm(qh, axis=1, keepdims=True), 10)
+    ranks_h = np.ascontiguousarray(base.T)                                   # [10, Q]
+    ref_idx, ref_sc, ref_qx, _ = single.aqe_search(ranks_h, 3, 4.0, k, return_qexp=True)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    ranks = torch.from_numpy(ranks_h).to(dev)
+    nsh = 3
+    shards = [_lib.Gallery.from_host(g[lo:hi], norm_mode=_lib.NORM_NONE, row_offset=lo)
+              for lo, hi in (shard_bounds(n, nsh, r) for r in range(nsh))]
+    total = torch.zeros((nq, d), dtype=torch.float64, device=dev)
+    for sh in shards:
+        part = torch.empty((nq, d), dtype=torch.float64, device=dev)
+        sh.aqe_partial_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, 3, 4.0, part.data_ptr(), stream)
+        total += part                                                      # == all-reduce(SUM)
+    qx = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    qx64 = torch.empty((nq, d), dtype=torch.float64, device=dev)
+    _lib.aqe_finish_device(total.data_ptr(), nq, d, 1e-6, qx.data_ptr(), qx64.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.abs(qx64.cpu().numpy() - ref_qx).max() < 1e-15
+    # world-size-1 ShardedGallery.aqe_search on the single shard: same code path as the multi-rank one minus the collective
+    sg = ShardedGallery(single)
+    idx, sc, _ = sg.aqe_search(ranks, 3, 4.0, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), ref_idx) and np.array_equal(sc.cpu().numpy(), ref_sc)
+    for sh in shards:
+        sh.close()
+    single.close()
