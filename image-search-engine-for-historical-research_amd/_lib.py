@@ -37,6 +37,12 @@ SIGNATURES = {
     "mi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mi_gallery_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_int,
                                     C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "mi_gallery_create_empty": (C.c_int, [C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "mi_gallery_append_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mi_desc_tail_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_desc_ms_accumulate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "mi_desc_ms_finish_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "mi_gallery_destroy": (C.c_int, [C.c_void_p]),
     "mi_gallery_info": (C.c_int, [C.c_void_p, c_i64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), c_i64p, c_i64p]),
@@ -162,6 +168,19 @@ class Gallery:
         check(load().mi_gallery_create(C.c_void_p(ptr), n, d, dtype, d if row_stride is None else row_stride,
                                        col_stride, MI_DEVICE, norm_mode, device, row_offset, C.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def empty(cls, capacity, d, norm_mode=NORM_L2, device=0, row_offset=0):
+        """Appendable gallery: `capacity` rows allocated, filled by append_device()."""
+        h = C.c_void_p()
+        check(load().mi_gallery_create_empty(capacity, d, norm_mode, device, row_offset, C.byref(h)))
+        return cls(h.value)
+
+    def append_device(self, rows_ptr, m, stream=None):
+        """rows_ptr: device pointer to [m, d] float32 (C order)."""
+        with self._lock:
+            check(load().mi_gallery_append_device(self._h, C.c_void_p(rows_ptr), m, C.c_void_p(stream)))
+            self.n += m
 
     @classmethod
     def load(cls, path, device=0):
@@ -345,6 +364,21 @@ def whiten_apply(rows, m, P, dims, eps=1e-6, device=0):
                                  m.ctypes.data_as(C.c_void_p), Pd.ctypes.data_as(C.c_void_p), dims, float(eps), device,
                                  out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def desc_tail_device(feat_ptr, b, c, hw, p, eps, w_ptr, b_ptr, c_out, scratch_ptr, out_ptr, stream=None):
+    check(load().mi_desc_tail_device(C.c_void_p(feat_ptr), b, c, hw, float(p), float(eps), C.c_void_p(w_ptr),
+                                     C.c_void_p(b_ptr), c_out, C.c_void_p(scratch_ptr), C.c_void_p(out_ptr),
+                                     C.c_void_p(stream)))
+
+
+def desc_ms_accumulate_device(acc_ptr, desc_ptr, count, msp, first, stream=None):
+    check(load().mi_desc_ms_accumulate_device(C.c_void_p(acc_ptr), C.c_void_p(desc_ptr), count, float(msp),
+                                              1 if first else 0, C.c_void_p(stream)))
+
+
+def desc_ms_finish_device(acc_ptr, b, d, nscales, msp, stream=None):
+    check(load().mi_desc_ms_finish_device(C.c_void_p(acc_ptr), b, d, nscales, float(msp), C.c_void_p(stream)))
 
 
 def set_global_option(name, value):

@@ -40,7 +40,7 @@ struct Workspace {
   int32_t qcap = 0, kcap = 0;
   uint32_t cap = 0, rcap = 0;
   float* q_f32 = nullptr;
-  void* q_bf16 = nullptr;
+  void* q_img = nullptr;
   RowStat* q_stat = nullptr;
   float *thr = nullptr, *margin = nullptr, *thr2 = nullptr;
   uint32_t* qflag = nullptr;
@@ -62,10 +62,11 @@ struct Workspace {
 struct mi_gallery {
   int device = 0;
   int64_t n = 0, npad = 0, row_offset = 0;
+  int64_t cap = 0;          // allocated rows (== n unless created with mi_gallery_create_empty)
   int32_t d = 0, dp = 0, norm_mode = 0;
   int img_f16 = 1;          // 16-bit image element type of the gallery AND of the query batches searched on it
   float* gal_f32 = nullptr;
-  void* gal_bf16 = nullptr;
+  void* gal_img = nullptr;
   RowStat* rowstat = nullptr;
   float* gstat3 = nullptr;
   int64_t hbm_bytes = 0;
@@ -119,7 +120,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   {
     __hip_bfloat16* tmp = nullptr;
     if ((rc = dev_alloc(ws, &tmp, (size_t)QB * g->dp)) != MI_OK) return rc;
-    ws.q_bf16 = tmp;
+    ws.q_img = tmp;
   }
   A(q_stat, QB);
   A(thr, QB);
@@ -192,7 +193,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
                         int32_t nq, int32_t k, bool exact, hipStream_t s) {
   Workspace& ws = g->ws;
   const int32_t qpad = (int32_t)round_up(nq, TILE);
-  launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_bf16, g->img_f16, ws.q_stat, g->dp, qpad, s);
+  launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, qpad, s);
   QueryState st = make_state(ws);
   const int64_t ntiles = g->npad / TILE;
   // bootstrap chunk: stored completely (no threshold yet); must hold >= K rows and fit the survivor buffer
@@ -226,8 +227,8 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       return;
     }
     ScoreArgs a;
-    a.gal_bf16 = g->gal_bf16;
-    a.qry_bf16 = ws.q_bf16;
+    a.gal_img = g->gal_img;
+    a.qry_img = ws.q_img;
     a.img_f16 = g->img_f16;
     a.nslices = g->dp / SLICE_K;
     a.tile0 = (int32_t)tile_from;
@@ -369,7 +370,7 @@ int mi_gallery_destroy(mi_gallery* g) {
     (void)hipEventDestroy(e.second);
   }
   (void)hipFree(g->gal_f32);
-  (void)hipFree(g->gal_bf16);
+  (void)hipFree(g->gal_img);
   (void)hipFree(g->rowstat);
   (void)hipFree(g->gstat3);
   (void)hipFree(g->dif_ids);
@@ -382,14 +383,16 @@ int mi_gallery_destroy(mi_gallery* g) {
 static int gallery_alloc(mi_gallery* g) {
   g->dp = (int32_t)round_up(g->d, BK);
   g->npad = round_up(g->n, TILE);
+  if (g->cap < g->n) g->cap = g->n;
+  const int64_t cap_pad = round_up(g->cap, TILE);
   HIPC(hipSetDevice(g->device));
   HIPC(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-  const size_t f32_bytes = (size_t)g->n * g->dp * 4, bf_bytes = (size_t)g->npad * g->dp * 2;
+  const size_t f32_bytes = (size_t)g->cap * g->dp * 4, bf_bytes = (size_t)cap_pad * g->dp * 2;
   HIPC(hipMalloc((void**)&g->gal_f32, f32_bytes + 256));
-  HIPC(hipMalloc(&g->gal_bf16, bf_bytes + 256));
-  HIPC(hipMalloc((void**)&g->rowstat, (size_t)g->npad * sizeof(RowStat)));
+  HIPC(hipMalloc(&g->gal_img, bf_bytes + 256));
+  HIPC(hipMalloc((void**)&g->rowstat, (size_t)cap_pad * sizeof(RowStat)));
   HIPC(hipMalloc((void**)&g->gstat3, 16));
-  g->hbm_bytes = (int64_t)(f32_bytes + bf_bytes + (size_t)g->npad * sizeof(RowStat));
+  g->hbm_bytes = (int64_t)(f32_bytes + bf_bytes + (size_t)cap_pad * sizeof(RowStat));
   return MI_OK;
 }
 
@@ -431,7 +434,7 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
   g->img_f16 = g_default_img_f16;
   hipError_t e = hipSuccess;
   for (int pass = 0; pass < 2; ++pass) {
-    launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_bf16, g->img_f16, g->rowstat,
+    launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat,
                   g->dp, g->npad, g->stream);
     launch_rowstat_max(g->rowstat, n, g->gstat3, g->stream);
     e = hipStreamSynchronize(g->stream);
@@ -446,6 +449,78 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
   if (e != hipSuccess) return cleanup(fail(MI_ERR_HIP, std::string("ingest: ") + hipGetErrorString(e)));
   if (staged) (void)hipFree(staged);
   *out = g;
+  return MI_OK;
+}
+
+int mi_gallery_create_empty(int64_t capacity, int32_t d, int norm_mode, int device, int64_t row_offset,
+                            mi_gallery** out) {
+  REQUIRE(out, "null pointer");
+  REQUIRE(capacity >= 1 && capacity < ((int64_t)1 << 32) && d >= 1, "bad sizes");
+  REQUIRE(norm_mode >= 0 && norm_mode <= 2, "bad norm_mode");
+  mi_gallery* g = new mi_gallery();
+  g->device = device;
+  g->n = 0;
+  g->cap = capacity;
+  g->d = d;
+  g->norm_mode = norm_mode;
+  g->row_offset = row_offset;
+  g->img_f16 = (norm_mode == MI_NORM_NONE) ? 0 : g_default_img_f16;   // raw rows of unknown range: bf16 image
+  int rc = gallery_alloc(g);
+  if (rc == MI_OK) {
+    hipError_t e = hipMemset(g->gal_img, 0, (size_t)round_up(capacity, TILE) * g->dp * 2);
+    if (e == hipSuccess) e = hipMemset(g->gstat3, 0, 12);
+    if (e != hipSuccess) rc = fail(MI_ERR_HIP, std::string("memset: ") + hipGetErrorString(e));
+  }
+  if (rc != MI_OK) {
+    mi_gallery_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return MI_OK;
+}
+
+int mi_gallery_append_device(mi_gallery* g, const float* rows_dev, int64_t m, void* stream) {
+  REQUIRE(g && rows_dev, "null pointer");
+  REQUIRE(m >= 1, "nothing to append");
+  REQUIRE(g->n + m <= g->cap, "gallery capacity exceeded");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  hipStream_t s = (hipStream_t)stream;
+  // rows [n, n+m): normalise like the gallery, write f32 rows + 16-bit image + rounding norms at their final place
+  launch_ingest(rows_dev, MI_F32, m, g->d, g->d, 1, g->norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat, g->dp, m,
+                s, g->n);
+  launch_rowstat_max(g->rowstat + g->n, m, g->gstat3, s, /*reset=*/false);
+  HIPC(hipGetLastError());
+  g->n += m;
+  g->npad = round_up(g->n, TILE);
+  return MI_OK;
+}
+
+int mi_desc_tail_device(const float* feat_dev, int32_t b, int32_t c, int32_t hw, float p, float eps,
+                        const float* whiten_w_dev, const float* whiten_b_dev, int32_t c_out, float* scratch_dev,
+                        float* out_dev, void* stream) {
+  REQUIRE(feat_dev && out_dev, "null pointer");
+  REQUIRE(b >= 1 && c >= 1 && hw >= 1, "bad sizes");
+  REQUIRE(!whiten_w_dev || (scratch_dev && c_out >= 1), "whitening needs a [b][c] scratch buffer and c_out");
+  REQUIRE(!whiten_w_dev || (size_t)8 * c * 4 <= 160 * 1024 - 1024, "c too large for the whitening kernel");
+  launch_desc_tail(feat_dev, b, c, hw, p, eps, whiten_w_dev, whiten_b_dev, c_out, scratch_dev, out_dev,
+                   (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_desc_ms_accumulate_device(float* acc_dev, const float* desc_dev, int64_t count, float msp, int first,
+                                 void* stream) {
+  REQUIRE(acc_dev && desc_dev && count >= 1, "bad arguments");
+  launch_ms_accumulate(acc_dev, desc_dev, count, msp, first, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_desc_ms_finish_device(float* acc_dev, int32_t b, int32_t d, int32_t nscales, float msp, void* stream) {
+  REQUIRE(acc_dev && b >= 1 && d >= 1 && nscales >= 1, "bad arguments");
+  launch_ms_finish(acc_dev, b, d, nscales, msp, (hipStream_t)stream);
+  HIPC(hipGetLastError());
   return MI_OK;
 }
 
@@ -515,7 +590,7 @@ int mi_gallery_save(const mi_gallery* g, const char* path) {
   int rc = MI_OK;
   if (fwrite(&h, sizeof h, 1, f) != 1) rc = fail(MI_ERR_IO, "short write");
   if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_f32, (size_t)g->n * g->dp * 4);
-  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_bf16, (size_t)g->npad * g->dp * 2);
+  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_img, (size_t)g->npad * g->dp * 2);
   if (rc == MI_OK) rc = copy_dev_to_file(f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
   if (rc == MI_OK) rc = copy_dev_to_file(f, g->gstat3, 12);
   if (fclose(f) != 0 && rc == MI_OK) rc = fail(MI_ERR_IO, "close failed");
@@ -541,7 +616,7 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   int rc = gallery_alloc(g);
   if (rc == MI_OK && (g->dp != h.dp || g->npad != h.npad)) rc = fail(MI_ERR_IO, "inconsistent header");
   if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_f32, (size_t)g->n * g->dp * 4);
-  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_bf16, (size_t)g->npad * g->dp * 2);
+  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_img, (size_t)g->npad * g->dp * 2);
   if (rc == MI_OK) rc = copy_file_to_dev(f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
   if (rc == MI_OK) rc = copy_file_to_dev(f, g->gstat3, 12);
   fclose(f);
@@ -810,7 +885,7 @@ int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t r
   for (int64_t q0 = 0; q0 < nq; q0 += qb) {
     const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
     const int32_t qpad = (int32_t)round_up(b, TILE);
-    launch_ingest((const char*)q_src + (size_t)q0 * rs * esz, q_dtype, b, g->d, rs, cs, q_norm, ws.q_f32, ws.q_bf16,
+    launch_ingest((const char*)q_src + (size_t)q0 * rs * esz, q_dtype, b, g->d, rs, cs, q_norm, ws.q_f32, ws.q_img,
                   g->img_f16, ws.q_stat, g->dp, qpad, s);
     ExactArgs a;
     a.gal_f32 = g->gal_f32;
@@ -899,7 +974,7 @@ int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row
   for (int64_t q0 = 0; q0 < nq; q0 += qb) {
     const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
     const int32_t qpad = (int32_t)round_up(b, TILE);
-    launch_ingest(qd + (size_t)q0 * row_stride * esz, dtype, b, g->d, row_stride, col_stride, qn, ws.q_f32, ws.q_bf16,
+    launch_ingest(qd + (size_t)q0 * row_stride * esz, dtype, b, g->d, row_stride, col_stride, qn, ws.q_f32, ws.q_img,
                   g->img_f16, ws.q_stat, g->dp, qpad, s);
     ExactArgs a;
     a.gal_f32 = g->gal_f32;

@@ -6,32 +6,24 @@
 
 namespace mi {
 
-// ---- geometry of the tile-blocked bf16 images streamed by the MFMA kernel -------------------
+// ---- geometry of the tile-blocked 16-bit (fp16 | bf16) images streamed by the MFMA kernel ----
 // A matrix X[rows][dp] (dp = d rounded up to 64) is stored as
-//   blocked[tile = row / 256][slice = k / 32][row % 256][32]     (bf16, 16 KiB per (tile, slice) block)
+//   blocked[tile = row / 256][slice = k / 32][row % 256][32]     (16-bit elements, 16 KiB per (tile, slice) block)
 // with the four 16-byte chunks of each 64-byte row permuted: physical chunk = c ^ ((-(row >> 2)) & 3).
 // One (tile, slice) block is exactly the LDS image of one K-slice of one operand, so the global->LDS
-// DMA is a linear copy and the `ds_read_b128` fragment reads of v_mfma_f32_16x16x32_bf16 (lane l: row
+// DMA is a linear copy and the `ds_read_b128` fragment reads of v_mfma_f32_16x16x32_{f16,bf16} (lane l: row
 // l & 15, chunk l >> 4) hit 16 distinct 16-byte slots in each of the instruction's four lane groups,
 // i.e. they are bank-conflict free (derivation in DESIGN.md "LDS image").
 constexpr int TILE = 256;     // gallery rows / queries per workgroup tile
 constexpr int BK = 64;        // column padding granule of dp
-constexpr int SLICE_K = 32;   // K-depth of one slice = one v_mfma_f32_16x16x32_bf16
-constexpr int SLICE_ELEMS = TILE * SLICE_K;          // 8192 bf16 = 16 KiB
+constexpr int SLICE_K = 32;   // K-depth of one slice = one v_mfma_f32_16x16x32_{f16,bf16}
+constexpr int SLICE_ELEMS = TILE * SLICE_K;          // 8192 elements = 16 KiB
 constexpr int SLICE_BYTES = SLICE_ELEMS * 2;
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 __host__ __device__ __forceinline__ uint32_t swz_chunk(uint32_t row, uint32_t c) {
   return c ^ ((0u - (row >> 2)) & 3u);
-}
-
-// element offset of (row, k) inside the blocked image (nslices = dp / 32)
-__host__ __device__ __forceinline__ int64_t blocked_offset(int64_t row, int32_t k, int32_t nslices) {
-  const int64_t tile = row / TILE;
-  const uint32_t r = (uint32_t)(row % TILE);
-  const uint32_t sl = (uint32_t)k / SLICE_K, kk = (uint32_t)k % SLICE_K;
-  return ((tile * nslices + sl) * (int64_t)SLICE_ELEMS) + (int64_t)r * SLICE_K + (swz_chunk(r, kk >> 3) << 3) + (kk & 7);
 }
 
 // float <-> order-preserving uint32 key (larger float -> larger key); NaN maps below -inf
@@ -52,11 +44,11 @@ __device__ __forceinline__ uint64_t pack_entry(float s, uint32_t row) {
 __device__ __forceinline__ float entry_score(uint64_t e) { return __uint_as_float((uint32_t)(e >> 32)); }
 __device__ __forceinline__ uint32_t entry_row(uint64_t e) { return (uint32_t)e; }
 
-// per-row rounding statistics produced by ingest (norms of the stored f32 row, of its bf16 image and
+// per-row rounding statistics produced by ingest (norms of the stored f32 row, of its 16-bit image and
 // of their difference) -- inputs of the rigorous error margin, DESIGN.md "Exactness certificate"
 struct RowStat {
   float norm_f32;    // ||g||      (stored f32 row)
-  float norm_bf16;   // ||g_hat||  (bf16 image)
+  float norm_img;    // ||g_hat||  (16-bit image row)
   float norm_diff;   // ||g_hat - g||
 };
 

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   auto pf_set = [&](uint32_t i) {
     uint32_t gt, qt;
     tile_of(i < my_tiles ? i : my_tiles - 1, gt, qt);     // past the end: harmless re-load of the last tile
-    pf = (grp == 0 ? (const char*)p.gal_bf16 + (int64_t)gt * KSL * SLICE_BYTES
-                   : (const char*)p.qry_bf16 + (int64_t)qt * KSL * SLICE_BYTES) + (w & 3) * 4096 + lane * 16;
+    pf = (grp == 0 ? (const char*)p.gal_img + (int64_t)gt * KSL * SLICE_BYTES
+                   : (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES) + (w & 3) * 4096 + lane * 16;
   };
   pf_set(0);
   constexpr bool dbg_nodma = DBG & 1, dbg_nomfma = DBG & 2;

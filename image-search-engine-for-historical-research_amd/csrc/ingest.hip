@@ -27,7 +27,7 @@ template <typename InT>
 __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
                                                      int64_t rs, int64_t cs, int norm_mode,
                                                      float* __restrict__ out_f32,
-                                                     uint16_t* __restrict__ out_bf16, int img_f16,
+                                                     uint16_t* __restrict__ out_img, int img_f16,
                                                      RowStat* __restrict__ rowstat, int32_t dp,
                                                      int64_t npad) {
   __shared__ double tile[64][65];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src
       for (int half = 0; half < 2; ++half) {
         const uint32_t kcol = (uint32_t)(col0 + cj + half * 8);
         const uint32_t sl = kcol / SLICE_K, c = (kcol % SLICE_K) >> 3;
-        uint16_t* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+        uint16_t* blk = out_img + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
         union { uint16_t h[8]; uint4 u; } pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src
     RowStat rsd;
     // round the norms UP a little so that they stay upper bounds after the f32 conversion
     rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
-    rsd.norm_bf16 = (float)(sqrt(s_b) * (1.0 + 1e-6));
+    rsd.norm_img = (float)(sqrt(s_b) * (1.0 + 1e-6));
     rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
     rowstat[crow] = rsd;
   }
@@ -137,8 +137,9 @@ template <typename InT>
 __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
                                                              int64_t rs, int64_t cs, int norm_mode,
                                                              float* __restrict__ out_f32,
-                                                             uint16_t* __restrict__ out_bf16, int img_f16,
-                                                             RowStat* __restrict__ rowstat, int32_t dp, int64_t npad) {
+                                                             uint16_t* __restrict__ out_img, int img_f16,
+                                                             RowStat* __restrict__ rowstat, int32_t dp, int64_t npad,
+                                                             int64_t row_base) {
   __shared__ double red[3][4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int64_t row = blockIdx.x;
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restri
   }
   double s_g = 0.0, s_b = 0.0, s_d = 0.0;
   const int nslices = dp / SLICE_K;
-  const int64_t tileidx = row / TILE;
-  const uint32_t r = (uint32_t)(row % TILE);
+  const int64_t orow = row_base + row;          // output row (gallery append: source row 0 <-> row_base)
+  const int64_t tileidx = orow / TILE;
+  const uint32_t r = (uint32_t)(orow % TILE);
   for (int c0 = t * 8; c0 < dp; c0 += 2048) {
     float vf[8];
 #pragma unroll
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restri
       vf[e] = (valid && c < d) ? (float)((double)src[row * rs + (int64_t)c * cs] * scale) : 0.0f;
     }
     const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
-    uint16_t* blk = out_bf16 + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+    uint16_t* blk = out_img + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
     union { uint16_t h[8]; uint4 u; } pk;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restri
     }
     *reinterpret_cast<uint4*>(blk + (swz_chunk(r, ch) << 3)) = pk.u;
     if (valid) {
-      float4* o = reinterpret_cast<float4*>(out_f32 + row * dp + c0);
+      float4* o = reinterpret_cast<float4*>(out_f32 + orow * dp + c0);
       o[0] = make_float4(vf[0], vf[1], vf[2], vf[3]);
       o[1] = make_float4(vf[4], vf[5], vf[6], vf[7]);
     }
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restri
   if (t == 0) {
     RowStat rsd;
     rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
-    rsd.norm_bf16 = (float)(sqrt(s_b) * (1.0 + 1e-6));
+    rsd.norm_img = (float)(sqrt(s_b) * (1.0 + 1e-6));
     rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
-    rowstat[row] = rsd;
+    rowstat[orow] = rsd;
   }
 }
 
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
   float m0 = 0.f, m1 = 0.f, m2 = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const RowStat r = rowstat[i];
-    if (isfinite(r.norm_f32) && isfinite(r.norm_bf16) && isfinite(r.norm_diff)) {
-      m0 = fmaxf(m0, r.norm_f32); m1 = fmaxf(m1, r.norm_bf16); m2 = fmaxf(m2, r.norm_diff);
+    if (isfinite(r.norm_f32) && isfinite(r.norm_img) && isfinite(r.norm_diff)) {
+      m0 = fmaxf(m0, r.norm_f32); m1 = fmaxf(m1, r.norm_img); m2 = fmaxf(m2, r.norm_diff);
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -224,28 +226,28 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
 }
 
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
-                   float* out_f32, void* out_bf16, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad,
-                   hipStream_t stream) {
-  if (npad <= 4096) {   // small batches (queries): one workgroup per row
+                   float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad,
+                   hipStream_t stream, int64_t row_base) {
+  if (npad <= 4096 || row_base != 0) {   // small batches (queries): one workgroup per row
     if (dtype == 0)
       hipLaunchKernelGGL(ingest_rowwise_kernel<float>, dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
-                         d, rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
+                         d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base);
     else
       hipLaunchKernelGGL(ingest_rowwise_kernel<double>, dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
-                         n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
+                         n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base);
     return;
   }
   const int64_t blocks = (npad + 63) / 64;
   if (dtype == 0)
     hipLaunchKernelGGL(ingest_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, n, d,
-                       rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
+                       rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad);
   else
     hipLaunchKernelGGL(ingest_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)src, n,
-                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_bf16, img_f16, rowstat, dp, npad);
+                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad);
 }
 
-void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream) {
-  hipMemsetAsync(out3, 0, 3 * sizeof(float), stream);
+void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream, bool reset) {
+  if (reset) hipMemsetAsync(out3, 0, 3 * sizeof(float), stream);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;

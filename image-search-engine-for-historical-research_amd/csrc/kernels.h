@@ -6,14 +6,15 @@ namespace mi {
 
 // ingest.hip
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
-                   float* out_f32, void* out_bf16, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream);
-void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream);
+                   float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream,
+                   int64_t row_base = 0);   // row_base: output rows start here (gallery append); src row 0 <-> row_base
+void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream, bool reset = true);
 
-// gemm_select.hip -- bf16 MFMA scoring of gallery tiles [tile0, tile0+ntiles) against nqt query tiles with the
+// gemm_select.hip -- fp16/bf16 MFMA scoring of gallery tiles [tile0, tile0+ntiles) against nqt query tiles with the
 // fused survivor filter.  first != 0: store every score of the chunk (rows tile0*256.. at position row).
 struct ScoreArgs {
-  const void* gal_bf16;   // blocked image of the shard
-  const void* qry_bf16;   // blocked image of the query batch
+  const void* gal_img;   // blocked image of the shard
+  const void* qry_img;   // blocked image of the query batch
   int32_t img_f16;        // 16-bit image element type: 1 = fp16, 0 = bf16
   int32_t nslices;        // dp / 32
   int32_t tile0, ntiles;  // gallery tiles of this launch
@@ -50,7 +51,7 @@ void launch_exact_select(const ExactArgs& a, bool first, hipStream_t stream);
 
 // select.hip
 void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t nq, int32_t qpad, float gamma,
-                             int use_bf16_terms, uint32_t first_cnt, QueryState st, hipStream_t stream);
+                             int use_img_terms, uint32_t first_cnt, QueryState st, hipStream_t stream);
 // mode 0: maintain (threshold <- K-th largest - margin, compact survivors)
 // mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
@@ -89,6 +90,12 @@ void launch_diffusion_combine(const int64_t* nn_idx, const float* nn_sims, int32
 // whiten.hip
 void launch_whiten(const void* X, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, const double* m,
                    const double* P, int32_t dims, double eps, double* Y, hipStream_t stream);
+
+// desc_tail.hip
+void launch_desc_tail(const float* feat, int32_t b, int32_t c, int32_t hw, float p, float eps, const float* W,
+                      const float* bias, int32_t c_out, float* pooled, float* out, hipStream_t stream);
+void launch_ms_accumulate(float* acc, const float* desc, int64_t count, float msp, int first, hipStream_t stream);
+void launch_ms_finish(float* acc, int32_t b, int32_t d, int32_t nscales, float msp, hipStream_t stream);
 
 // aqe.hip
 void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,

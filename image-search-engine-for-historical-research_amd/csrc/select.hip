@@ -57,7 +57,7 @@ __device__ uint32_t block_kth_largest(const uint32_t* keys, uint32_t n, uint32_t
 
 // ------------------------------------------------------------------------------------------------
 __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const float* __restrict__ gstat3,
-                                        int32_t nq, int32_t qpad, float gamma, int use_bf16_terms,
+                                        int32_t nq, int32_t qpad, float gamma, int use_img_terms,
                                         uint32_t first_cnt, QueryState st) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q == 0) st.flags[1] = 0;          // flags[0] is sticky across batches (read and cleared by the host)
@@ -67,14 +67,14 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
     const float g_f32 = gstat3[0], g_bf = gstat3[1], g_diff = gstat3[2];
     // |approx - exact| <= gamma*|q^||g^| + |q^||g^ - g| + |q^ - q||g|   (Cauchy-Schwarz)
     float eps;
-    if (use_bf16_terms)
-      eps = gamma * r.norm_bf16 * g_bf + r.norm_bf16 * g_diff + r.norm_diff * g_f32;
+    if (use_img_terms)
+      eps = gamma * r.norm_img * g_bf + r.norm_img * g_diff + r.norm_diff * g_f32;
     else
       eps = gamma * r.norm_f32 * g_f32;
     float margin = 2.0f * eps * 1.001f + 1e-30f;
     float thr0 = -INFINITY;
     if (!(margin == margin)) margin = 0.f;   // NaN query (zero-norm): nothing will match anyway
-    if (use_bf16_terms && !isfinite(r.norm_bf16) && isfinite(r.norm_f32)) {
+    if (use_img_terms && !isfinite(r.norm_img) && isfinite(r.norm_f32)) {
       // the 16-bit image of this query overflowed (fp16 range): skip it here, the exact f32 path answers it
       atomicOr(st.flags, FLAG_RANGE);
       margin = 0.f;
@@ -95,9 +95,9 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
 }
 
 void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t nq, int32_t qpad, float gamma,
-                             int use_bf16_terms, uint32_t first_cnt, QueryState st, hipStream_t stream) {
+                             int use_img_terms, uint32_t first_cnt, QueryState st, hipStream_t stream) {
   hipLaunchKernelGGL(init_query_state_kernel, dim3((qpad + 255) / 256), dim3(256), 0, stream, qstat, gstat3, nq,
-                     qpad, gamma, use_bf16_terms, first_cnt, st);
+                     qpad, gamma, use_img_terms, first_cnt, st);
 }
 
 // ------------------------------------------------------------------------------------------------

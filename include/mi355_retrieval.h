@@ -60,6 +60,12 @@ int mi_device_count(int* count);
 int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t row_stride,
                       int64_t col_stride, int memspace, int norm_mode, int device,
                       int64_t row_offset, mi_gallery** out);
+/* Appendable gallery (offline pipeline): capacity rows are allocated, rows arrive from the device
+ * (descriptors straight out of the extractor tail) and are normalised / imaged / measured in place.  Appends and
+ * searches on one handle must be serialised by the caller; `stream` orders the append against the producer. */
+int mi_gallery_create_empty(int64_t capacity, int32_t d, int norm_mode, int device, int64_t row_offset,
+                            mi_gallery** out);
+int mi_gallery_append_device(mi_gallery* g, const float* rows_dev /*[m][d] f32*/, int64_t m, void* stream);
 int mi_gallery_destroy(mi_gallery* g);
 int mi_gallery_info(const mi_gallery* g, int64_t* n, int32_t* d, int32_t* norm_mode, int32_t* device,
                     int64_t* row_offset, int64_t* hbm_bytes);
@@ -147,6 +153,17 @@ int mi_diffusion_set_offline(mi_gallery* g, const int64_t* ids, const float* val
 int mi_diffusion_online(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride,
                         int64_t col_stride, int32_t k_query, int32_t gamma, int32_t trunc,
                         int64_t* out_ranks, float* out_scores);
+
+/* ---- descriptor tail of the extractor (src/networks/imageretrievalnet.py:183-187, 464-479; src/layers/functional.py:
+ * 20-22, 129-130): GeM pooling of the last feature map feat[b][c][hw] (p, eps), L2N (eps 1e-6), optional whitening
+ * Linear(c -> c_out, bias) + L2N (scratch_dev: [b][c] floats), into out_dev [b][c_out or c].  Multi-scale: accumulate
+ * desc^msp per scale (first != 0 overwrites), then finish = (acc / nscales)^(1/msp) / ||.||. */
+int mi_desc_tail_device(const float* feat_dev, int32_t b, int32_t c, int32_t hw, float p, float eps,
+                        const float* whiten_w_dev, const float* whiten_b_dev, int32_t c_out, float* scratch_dev,
+                        float* out_dev, void* stream);
+int mi_desc_ms_accumulate_device(float* acc_dev, const float* desc_dev, int64_t count, float msp, int first,
+                                 void* stream);
+int mi_desc_ms_finish_device(float* acc_dev, int32_t b, int32_t d, int32_t nscales, float msp, void* stream);
 
 /* ---- whitenapply (src/utils/whiten.py:4-12): out[n][dims] = P[:dims] (x_n - m), rows divided by (||.|| + eps)
  * (eps < 0: no normalisation).  X: n images x d, strided (the reference's [D,N] array is passed with

@@ -64,8 +64,9 @@ def import_reference():
     sys.dont_write_bytecode = True
     sys.meta_path.insert(0, _StubFinder())
     # the LoFTR / adalam sub-packages are vendored nets that Reranking.py imports at top level
+    # (torch.utils.tensorboard is imported by src/utils/general.py:5 at module import; tensorboard is absent)
     for name in ("src.utils.src.utils.plotting", "src.utils.src.loftr", "src.utils.adalam",
-                 "src.utils.dataset"):
+                 "src.utils.dataset", "torch.utils.tensorboard"):
         m = _Inert(name)
         m.__path__ = []
         sys.modules[name] = m
@@ -175,6 +176,54 @@ def main():
             res[f"{name}_aps_{'_'.join(okk)}"] = aps
         res[f"{name}_map_EMH"] = np.array(vals)
     np.savez_compressed(os.path.join(GOLD, "map.npz"), meta=np.array([41, 1200, 64, 12]), **res)
+    # ---- f-2: descriptor tail (GeM -> L2N -> whiten Linear -> L2N), multi-scale average, SOA block -- the reference's
+    # own layer functions / classes on seeded feature maps and weights
+    import src.networks.networks as rnet
+    import src.networks.imageretrievalnet as rirn
+    B, Cc, Co = 3, 64, 48
+    Wt = torch.from_numpy(synth_rows(51, 0, Co, Cc)) / 8.0
+    bt = torch.from_numpy(synth_rows(52, 0, 1, Co)[0]) / 8.0
+
+    def ref_tail(feat, p=3.0):
+        o = LF.l2n(LF.gem(feat, p=p, eps=1e-6)).squeeze(-1).squeeze(-1)
+        return LF.l2n(torch.nn.functional.linear(o, Wt, bt))
+
+    feats = [torch.from_numpy(synth_rows(60 + i, 0, B * Cc, h * w).reshape(B, Cc, h, w)) for i, (h, w) in
+             enumerate(((5, 7), (7, 10), (4, 5)))]
+    tail_ss = ref_tail(feats[0]).numpy()
+    tail_ss_nowhiten = LF.l2n(LF.gem(feats[0], p=2.5, eps=1e-6)).squeeze(-1).squeeze(-1).numpy()
+
+    class FakeNet:                              # extract_ms only needs meta['outputdim'] and __call__
+        meta = {"outputdim": Co}
+
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, x):
+            self.calls += 1
+            return ref_tail(feats[self.calls - 1][:1])
+
+    # ms = [1, 1, 1] keeps extract_ms from interpolating; the three "scales" are the three seeded feature maps
+    v_ms1 = rirn.extract_ms(FakeNet(), torch.zeros(1, 3, 8, 8), [1, 1, 1], 1.0).numpy()
+    v_ms2 = rirn.extract_ms(FakeNet(), torch.zeros(1, 3, 8, 8), [1, 1, 1], 2.0).numpy()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        soa = rnet.SOABlock(in_ch=32, k=4)
+    soa.eval()
+    sd = soa.state_dict()
+    for i, (kname, t) in enumerate(sorted(sd.items())):
+        if t.dtype.is_floating_point and t.numel() > 0:
+            vals = synth_rows(70 + i, 0, 1, t.numel())[0].reshape(tuple(t.shape)) / 4.0
+            if kname.endswith("running_var"):
+                vals = np.abs(vals) + 0.5
+            sd[kname] = torch.from_numpy(vals.astype(np.float32))
+    soa.load_state_dict(sd)
+    xs = torch.from_numpy(synth_rows(90, 0, 2 * 32, 6 * 5).reshape(2, 32, 6, 5))
+    with torch.no_grad():
+        z_soa, _ = soa(xs)
+    np.savez_compressed(os.path.join(GOLD, "extractor_tail.npz"), tail_ss=tail_ss, tail_ss_nowhiten=tail_ss_nowhiten,
+                        v_ms1=v_ms1, v_ms2=v_ms2, z_soa=z_soa.numpy(),
+                        soa_keys=np.array(sorted(sd.keys())))
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print("  ", f, os.path.getsize(os.path.join(GOLD, f)))
