@@ -74,6 +74,9 @@ SIGNATURES = {
     "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mi_diffusion_online": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_gather_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+    "mi_column_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "mi_whiten_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_double, C.c_int, C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -295,6 +298,17 @@ class Gallery:
                                              trunc, ranks.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         return ranks, sc
 
+    def gather_weighted(self, ranks, weights):
+        """ranks int64 [k, Q] (global ids), weights [k] -> float64 [Q, D] = sum_j weights[j] * row(ranks[j, q])."""
+        r = np.ascontiguousarray(ranks, dtype=np.int64)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        out = np.empty((r.shape[1], self.d), dtype=np.float64)
+        with self._lock:
+            check(load().mi_gather_weighted(self._h, r.ctypes.data_as(C.c_void_p), r.strides[0] // 8, r.strides[1] // 8,
+                                            r.shape[1], r.shape[0], w.ctypes.data_as(C.c_void_p),
+                                            out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def get_rows(self, row0, nrows):
         out = np.empty((nrows, self.d), dtype=np.float32)
         check(load().mi_gallery_get_rows(self._h, row0, nrows, out.ctypes.data_as(C.c_void_p)))
@@ -352,6 +366,15 @@ def aqe_finish_device(sum_ptr, nq, d, eps, out_q_ptr, out_q64_ptr=None, stream=N
 
 def synth_fill_device(dst_ptr, seed, row0, nrows, d, stream=None):
     check(load().mi_synth_fill_device(C.c_void_p(dst_ptr), seed, row0, nrows, d, C.c_void_p(stream)))
+
+
+def column_sum(rows, device=0):
+    """float64 column sums of a 2-D float array (any strides), computed on the device."""
+    a, code, rs, cs = _strided(rows)
+    out = np.empty(a.shape[1], dtype=np.float64)
+    check(load().mi_column_sum(C.c_void_p(_base_pointer(a)), a.shape[0], a.shape[1], code, rs, cs, device,
+                               out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def whiten_apply(rows, m, P, dims, eps=1e-6, device=0):

@@ -787,7 +787,7 @@ int mi_aqe_partial_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_
   REQUIRE(nq >= 1 && k_qe >= 1, "bad sizes");
   HIPC(hipSetDevice(g->device));
   launch_aqe_partial(g->gal_f32, g->dp, g->d, g->n, g->row_offset, ranks_dev, rank_stride_j, rank_stride_q, nq, k_qe,
-                     w, out_sum_dev, (hipStream_t)stream);
+                     w, nullptr, out_sum_dev, (hipStream_t)stream);
   HIPC(hipGetLastError());
   return MI_OK;
 }
@@ -839,7 +839,7 @@ int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, in
     return done(fail(MI_ERR_HIP, "H2D ranks copy failed"));
   hipStream_t s = g->stream;
   launch_aqe_partial(g->gal_f32, g->dp, g->d, g->n, g->row_offset, ranks_d, rank_stride_j, rank_stride_q, nq, k_qe, w,
-                     sum_d, s);
+                     nullptr, sum_d, s);
   launch_aqe_finish(sum_d, nq, g->d, eps, q_d, q64_d, s);
   // the expanded query is used as is (no second normalisation), like `np.dot(vecs.T, qvecs_qe)`
   rc = search_sync(g, q_d, MI_F32, g->d, 1, MI_NORM_NONE, nq, k, idx_d, sc_d, nullptr);
@@ -995,6 +995,57 @@ int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row
     if (out_score) HIPC(hipMemcpy(out_score + q0 * n, os, (size_t)b * n * 4, hipMemcpyDeviceToHost));
   }
   if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return MI_OK;
+}
+
+int mi_gather_weighted(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, int64_t rank_stride_q, int64_t nq,
+                       int32_t k, const double* weights, double* out_sum) {
+  REQUIRE(g && ranks && weights && out_sum, "null pointer");
+  REQUIRE(nq >= 1 && k >= 1, "bad sizes");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  int64_t elems;
+  int rc = strided_extent(k, nq, rank_stride_j, rank_stride_q, &elems);
+  if (rc != MI_OK) return rc;
+  for (int64_t j = 0; j < k; ++j)
+    for (int64_t q = 0; q < nq; ++q) {
+      const int64_t v = ranks[j * rank_stride_j + q * rank_stride_q] - g->row_offset;
+      if (v < 0 || v >= g->n) return fail(MI_ERR_INVALID, "rank id outside the gallery");
+    }
+  TmpAlloc tmp;
+  int64_t* rd = tmp.get<int64_t>((size_t)elems);
+  double* wd = tmp.get<double>((size_t)k);
+  double* sd = tmp.get<double>((size_t)nq * g->d);
+  if (!rd || !wd || !sd) return fail(MI_ERR_NOMEM, "gather buffers");
+  HIPC(hipMemcpy(rd, ranks, (size_t)elems * 8, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(wd, weights, (size_t)k * 8, hipMemcpyHostToDevice));
+  launch_aqe_partial(g->gal_f32, g->dp, g->d, g->n, g->row_offset, rd, rank_stride_j, rank_stride_q, nq, k, 0.0, wd, sd,
+                     g->stream);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(g->stream));
+  HIPC(hipMemcpy(out_sum, sd, (size_t)nq * g->d * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_column_sum(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride, int device,
+                  double* out) {
+  REQUIRE(X && out, "null pointer");
+  REQUIRE(n >= 1 && d >= 1, "bad sizes");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  HIPC(hipSetDevice(device));
+  int64_t elems;
+  int rc = strided_extent(n, d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  char* xd = tmp.get<char>((size_t)elems * esz);
+  double* od = tmp.get<double>((size_t)d);
+  if (!xd || !od) return fail(MI_ERR_NOMEM, "column sum buffers");
+  HIPC(hipMemcpy(xd, X, (size_t)elems * esz, hipMemcpyHostToDevice));
+  launch_column_sum(xd, dtype, n, d, row_stride, col_stride, od, nullptr);
+  HIPC(hipGetLastError());
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpy(out, od, (size_t)d * 8, hipMemcpyDeviceToHost));
   return MI_OK;
 }
 

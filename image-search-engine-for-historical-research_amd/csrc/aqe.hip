@@ -3,6 +3,8 @@
 // The reference's f64 weight array promotes the sum to f64; here the gathered f32 rows are accumulated
 // in f64 as well.  `partial` adds only the rows this shard owns (the sum is all-reduced across shards by
 // the host); `finish` normalises.  HBM-bound gather of k rows per query (k = 3 or 10).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -11,14 +13,15 @@ namespace mi {
 __global__ __launch_bounds__(256) void aqe_partial_kernel(const float* __restrict__ gal, int32_t dp, int32_t d,
                                                           int64_t n, int64_t row_offset,
                                                           const int64_t* __restrict__ ranks, int64_t sj, int64_t sq,
-                                                          int32_t k_qe, double w, double* __restrict__ out_sum) {
+                                                          int32_t k_qe, double w, const double* __restrict__ weights,
+                                                          double* __restrict__ out_sum) {
   const int64_t q = blockIdx.x;
   for (int c = threadIdx.x; c < d; c += blockDim.x) {
     double acc = 0.0;
     for (int j = 0; j < k_qe; ++j) {
       const int64_t gid = ranks[j * sj + q * sq] - row_offset;
       if (gid < 0 || gid >= n) continue;
-      const double wt = pow((double)(k_qe - j) / (double)k_qe, w);
+      const double wt = weights ? weights[j] : pow((double)(k_qe - j) / (double)k_qe, w);
       acc += (double)gal[gid * dp + c] * wt;
     }
     out_sum[q * d + c] = acc;
@@ -48,14 +51,42 @@ __global__ __launch_bounds__(256) void aqe_finish_kernel(const double* __restric
 
 void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,
                         const int64_t* ranks, int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, double w,
-                        double* out_sum, hipStream_t stream) {
+                        const double* weights, double* out_sum, hipStream_t stream) {
   hipLaunchKernelGGL(aqe_partial_kernel, dim3((unsigned)nq), dim3(256), 0, stream, gal_f32, dp, d, n, row_offset,
-                     ranks, sj, sq, k_qe, w, out_sum);
+                     ranks, sj, sq, k_qe, w, weights, out_sum);
 }
 
 void launch_aqe_finish(const double* sum, int64_t nq, int32_t d, double eps, float* out_q, double* out_q64,
                        hipStream_t stream) {
   hipLaunchKernelGGL(aqe_finish_kernel, dim3((unsigned)nq), dim3(256), 0, stream, sum, d, eps, out_q, out_q64);
+}
+
+// column means of a strided [n][d] matrix in float64 (centring step of AQE / DBA, src/utils/Reranking.py:315-318)
+template <typename InT>
+__global__ __launch_bounds__(256) void column_sum_kernel(const InT* __restrict__ X, int64_t n, int32_t d, int64_t rs,
+                                                         int64_t cs, double* __restrict__ out) {
+  // block (bx, by): columns bx*64.., row slab by; 4 row-lanes x 64 column-lanes
+  __shared__ double red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int64_t slab = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * slab, r1 = min(n, r0 + slab);
+  double acc = 0.0;
+  if (col < d)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += (double)X[r * rs + (int64_t)col * cs];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < d) atomicAdd(&out[col], red[0][col & 63] + red[1][col & 63] + red[2][col & 63] + red[3][col & 63]);
+}
+
+void launch_column_sum(const void* X, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, double* out,
+                       hipStream_t stream) {
+  hipMemsetAsync(out, 0, (size_t)d * 8, stream);
+  dim3 grid((d + 63) / 64, (unsigned)std::min<int64_t>(256, (n + 255) / 256));
+  if (dtype == 0)
+    hipLaunchKernelGGL(column_sum_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, n, d, rs, cs, out);
+  else
+    hipLaunchKernelGGL(column_sum_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, n, d, rs, cs, out);
 }
 
 }  // namespace mi

@@ -71,3 +71,61 @@ def QGE_hip(ranks, qvecs, vecs, dataset, gnd, cache_dir=None, gnd_path2=None, AQ
         return out
     from . import diffusion
     return diffusion.qge_small_hip(ranks, qvecs, vecs, dataset, gnd, AQE=AQE, K=K, device=device, quiet=quiet)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f-4: average query expansion / database augmentation (src/utils/Reranking.py:314-432).  Compositions of the exact
+# kNN path: centring (device column sums + the f64 whitening GEMM with P = I, eps = 0), exact top-k on the centred,
+# normalised vectors, float64 weighted gathers of the ORIGINAL vectors, and matching_HIP on the augmented features.
+def _centre_normalise_hip(q, r, device=0):
+    from . import _lib
+    c = (_lib.column_sum(q, device) + _lib.column_sum(r, device)) / (q.shape[0] + r.shape[0])
+    eye = np.eye(q.shape[1])
+    qn = _lib.whiten_apply(q, c, eye, q.shape[1], eps=0.0, device=device)
+    rn = _lib.whiten_apply(r, c, eye, r.shape[1], eps=0.0, device=device)
+    if not (np.isfinite(qn).all() and np.isfinite(rn).all()):
+        raise RuntimeError("a vector coincides with the centre (zero norm after centring): the reference leaves the "
+                           "whole matrix un-normalised in that case (src/utils/Reranking.py:321-324); not supported")
+    return qn, rn
+
+
+def _neighbours_hip(q, r, k, device=0):
+    from ._lib import Gallery
+    qn, rn = _centre_normalise_hip(q, r, device)
+    g = Gallery.from_host(rn, norm_mode=NORM_NONE, device=device)
+    try:
+        idx, _, _ = g.search(qn, k)
+    finally:
+        g.close()
+    return idx
+
+
+def average_query_expansion_hip(qvecs, vecs, K, top_k=3, device=0):
+    """average_query_expansion (src/utils/Reranking.py:314-365) -> ranks int64 [K,Q] (the reference prints mAP)."""
+    from ._lib import Gallery
+    from .nnsearch import matching_HIP
+    q, r = np.ascontiguousarray(np.asarray(qvecs).T), np.ascontiguousarray(np.asarray(vecs).T)
+    orig = Gallery.from_host(r, norm_mode=NORM_NONE, device=device)
+    try:
+        w = np.full(top_k, 1.0 / top_k)
+        q_new = np.concatenate([q, orig.gather_weighted(_neighbours_hip(q, r, top_k, device).T, w)], axis=1)
+        nb = _neighbours_hip(r, r, top_k + 1, device)[:, 1:]                     # positions 1..top_k: skip itself
+        r_new = np.concatenate([r, orig.gather_weighted(nb.T, w)], axis=1)
+    finally:
+        orig.close()
+    return matching_HIP(K, r_new, q_new, device=device)[0].T
+
+
+def database_augmentation_hip(qvecs, vecs, K, top_k=3, device=0):
+    """database_augmentation (src/utils/Reranking.py:375-432) -> ranks int64 [K,Q]."""
+    from ._lib import Gallery
+    from .nnsearch import matching_HIP
+    q, r = np.ascontiguousarray(np.asarray(qvecs).T), np.ascontiguousarray(np.asarray(vecs).T)
+    w = np.logspace(0, -2., top_k + 1)
+    orig = Gallery.from_host(r, norm_mode=NORM_NONE, device=device)
+    try:
+        q_new = w[0] * q + orig.gather_weighted(_neighbours_hip(q, r, top_k, device).T, w[1:])
+        r_new = orig.gather_weighted(_neighbours_hip(r, r, top_k + 1, device).T, w)
+    finally:
+        orig.close()
+    return matching_HIP(K, r_new, q_new, device=device)[0].T

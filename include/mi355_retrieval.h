@@ -165,6 +165,14 @@ int mi_desc_ms_accumulate_device(float* acc_dev, const float* desc_dev, int64_t 
                                  void* stream);
 int mi_desc_ms_finish_device(float* acc_dev, int32_t b, int32_t d, int32_t nscales, float msp, void* stream);
 
+/* ---- building blocks of average_query_expansion / database_augmentation (src/utils/Reranking.py:314-432):
+ * out_sum[q][:] = sum_j weights[j] * row(ranks[j,q]) in float64 (means / logspace-weighted sums of neighbours), and
+ * column sums of a strided matrix (the centring step). */
+int mi_gather_weighted(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, int64_t rank_stride_q, int64_t nq,
+                       int32_t k, const double* weights, double* out_sum);
+int mi_column_sum(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride, int device,
+                  double* out);
+
 /* ---- whitenapply (src/utils/whiten.py:4-12): out[n][dims] = P[:dims] (x_n - m), rows divided by (||.|| + eps)
  * (eps < 0: no normalisation).  X: n images x d, strided (the reference's [D,N] array is passed with
  * row_stride 1, col_stride N); m f64 [d]; P f64 row-major [dims][d] (the first dims rows of the reference's P).

@@ -176,6 +176,24 @@ def main():
             res[f"{name}_aps_{'_'.join(okk)}"] = aps
         res[f"{name}_map_EMH"] = np.array(vals)
     np.savez_compressed(os.path.join(GOLD, "map.npz"), meta=np.array([41, 1200, 64, 12]), **res)
+    # ---- f-4: average_query_expansion / database_augmentation.  They print and return None; the ranks are captured by
+    # replacing the module-level compute_map_and_print2 they call last (src/utils/Reranking.py:361,428)
+    captured = {}
+    orig = rr.compute_map_and_print2
+    rr.compute_map_and_print2 = lambda dataset, ranks, gnd, *a, **k: captured.__setitem__(dataset, ranks.copy())
+    import contextlib, io
+    va = synth_rows(95, 0, 700, 40).astype(np.float64)
+    ca = synth_rows(96, 0, 9, 40).astype(np.float64)
+    va = 0.7 * va + 1.2 * ca[np.arange(700) % 9] + 0.3
+    va /= np.linalg.norm(va, axis=1, keepdims=True)
+    qa = va[:11] + 0.1 * synth_rows(97, 0, 11, 40)
+    qa /= np.linalg.norm(qa, axis=1, keepdims=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rr.average_query_expansion(qa.T.copy(), va.T.copy(), 50, "aqe", None)
+        rr.database_augmentation(qa.T.copy(), va.T.copy(), 50, "dba", None)
+    rr.compute_map_and_print2 = orig
+    np.savez_compressed(os.path.join(GOLD, "aqe_dba.npz"), ranks_aqe=captured["aqe"], ranks_dba=captured["dba"])
+
     # ---- f-2: descriptor tail (GeM -> L2N -> whiten Linear -> L2N), multi-scale average, SOA block -- the reference's
     # own layer functions / classes on seeded feature maps and weights
     import src.networks.networks as rnet

@@ -11,7 +11,7 @@ __all__ = [
     "matching_l2", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
     "extract_ms_tail", "knn_flat_ip", "compute_ap2", "compute_map2", "compute_map_revisited",
     "get_affinity", "get_laplacian", "diffusion_offline", "diffusion_online", "qge_small",
-    "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
+    "average_query_expansion", "database_augmentation", "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
 ]
 
 
@@ -244,6 +244,47 @@ def qge_small(ranks, qvecs, vecs, AQE=True, truncation_number=2000, k_gallery=20
     qs = qx.T if AQE else qvecs.T
     ranks_dfs, _ = diffusion_online(qs, feats, off, k_query, truncation_number)
     return qx, ranks_aqe, ranks_dfs
+
+
+# --------------------------------------------------------------------------- f-4
+def _centre_normalise(q, r):
+    """src/utils/Reranking.py:315-336 (identical copy :376-402): subtract the mean of the concatenated rows, then divide
+    every row by its norm -- unless ANY norm of that matrix is zero, in which case it is returned un-normalised."""
+    c = np.mean(np.concatenate([q, r], axis=0), axis=0)
+
+    def l2(v):
+        nrm = np.expand_dims(np.linalg.norm(v, axis=1), axis=1)
+        return v if np.any(nrm == 0) else v / nrm
+    return l2(q - c), l2(r - c)
+
+
+def _dist_rank(q, r):
+    qn, rn = _centre_normalise(q, r)
+    return np.argsort(2 - 2 * np.dot(qn, rn.T), axis=1)
+
+
+def average_query_expansion(qvecs, vecs, K, top_k=3):
+    """f-4: src/utils/Reranking.py:314-365.  Queries and gallery rows are extended by the mean of their top-3
+    neighbours (gallery: positions 1..3, skipping itself) found on centred + normalised vectors; the 2D-dim
+    concatenations are matched with matching_L2.  Returns ranks [K,Q]."""
+    q, r = qvecs.T, vecs.T
+    idx = _dist_rank(q, r)
+    qn = np.concatenate([q, np.mean(r[idx[:, :top_k], :], axis=1)], axis=1)
+    idx = _dist_rank(r, r)
+    rn = np.concatenate([r, np.mean(r[idx[:, 1:top_k + 1], :], axis=1)], axis=1)
+    return matching_l2(K, rn, qn).T
+
+
+def database_augmentation(qvecs, vecs, K, top_k=3):
+    """f-4: src/utils/Reranking.py:375-432.  weights = logspace(0, -2, 4); query' = w0 q + sum_j w_j r_j (top-3),
+    row' = sum_j w_j r_j over its top-4 (itself first); matching_L2 on the augmented vectors."""
+    q, r = qvecs.T, vecs.T
+    w = np.logspace(0, -2., top_k + 1)
+    idx = _dist_rank(q, r)
+    qn = np.tensordot(w, np.concatenate([np.expand_dims(q, 1), r[idx[:, :top_k], :]], axis=1), axes=(0, 1))
+    idx = _dist_rank(r, r)
+    rn = np.tensordot(w, r[idx[:, :top_k + 1], :], axes=(0, 1))
+    return matching_l2(K, rn, qn).T
 
 
 # --------------------------------------------------------------------------- checkers

@@ -295,3 +295,20 @@ def test_alpha_qe_across_shards_equals_single_shard():
     for sh in shards:
         sh.close()
     single.close()
+
+
+def test_aqe_and_dba_vs_reference_golden(golden_dir):
+    """f-4: average_query_expansion / database_augmentation against ranks captured from the reference functions."""
+    from isehr_amd.reranking import average_query_expansion_hip, database_augmentation_hip
+    z = np.load(os.path.join(golden_dir, "aqe_dba.npz"))
+    va = synth_rows(95, 0, 700, 40).astype(np.float64)
+    ca = synth_rows(96, 0, 9, 40).astype(np.float64)
+    va = 0.7 * va + 1.2 * ca[np.arange(700) % 9] + 0.3
+    va /= np.linalg.norm(va, axis=1, keepdims=True)
+    qa = va[:11] + 0.1 * synth_rows(97, 0, 11, 40)
+    qa /= np.linalg.norm(qa, axis=1, keepdims=True)
+    qv, vecs = qa.T.copy(), va.T.copy()
+    for fn, key in ((average_query_expansion_hip, "ranks_aqe"), (database_augmentation_hip, "ranks_dba")):
+        got = fn(qv, vecs, 50)
+        assert got.shape == (50, 11) and (got == z[key]).mean() > 0.97, (key, (got == z[key]).mean())
+        assert (got[0] == z[key][0]).all()

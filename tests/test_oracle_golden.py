@@ -108,3 +108,20 @@ def test_synth_generator_is_stable():
     ref = synth_rows(1234, 0, 7, 8)[5:7]
     assert np.array_equal(v, ref)
     assert abs(float(synth_rows(7, 0, 512, 512).std()) - 1.1547) < 0.01
+
+
+def _aqe_dba_inputs():
+    va = synth_rows(95, 0, 700, 40).astype(np.float64)
+    ca = synth_rows(96, 0, 9, 40).astype(np.float64)
+    va = 0.7 * va + 1.2 * ca[np.arange(700) % 9] + 0.3
+    va /= np.linalg.norm(va, axis=1, keepdims=True)
+    qa = va[:11] + 0.1 * synth_rows(97, 0, 11, 40)
+    qa /= np.linalg.norm(qa, axis=1, keepdims=True)
+    return qa.T.copy(), va.T.copy()
+
+
+def test_aqe_and_dba(golden_dir):
+    z = _load(golden_dir, "aqe_dba.npz")
+    qv, vecs = _aqe_dba_inputs()
+    assert np.array_equal(oracle.average_query_expansion(qv, vecs, 50), z["ranks_aqe"])
+    assert np.array_equal(oracle.database_augmentation(qv, vecs, 50), z["ranks_dba"])
