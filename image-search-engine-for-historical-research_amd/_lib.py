@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mi_debug_read_cycles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi_debug_sample_source_row": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "mi_set_global_option": (C.c_int, [C.c_char_p, C.c_double]),
     "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
 }
@@ -406,6 +407,13 @@ def desc_ms_finish_device(acc_ptr, b, d, nscales, msp, stream=None):
 
 def set_global_option(name, value):
     check(load().mi_set_global_option(name.encode(), float(value)))
+
+
+def sample_source_rows(n, n_s=8192):
+    """Diagnostics: gallery rows the bootstrap sample image of an n-row shard is drawn from."""
+    import numpy as np
+    f = load().mi_debug_sample_source_row
+    return np.array([f(i, n, n_s) for i in range(n_s)], dtype=np.int64)
 
 
 def device_count():

@@ -69,6 +69,9 @@ struct mi_gallery {
   void* gal_img = nullptr;
   RowStat* rowstat = nullptr;
   float* gstat3 = nullptr;
+  // bootstrap sample image of the speculative schedule (built lazily, rebuilt when rows were appended)
+  void* samp_img = nullptr;
+  int64_t samp_tiles = 0, samp_for_n = -1;
   int64_t hbm_bytes = 0;
   hipStream_t stream = nullptr;
   Workspace ws;
@@ -188,6 +191,21 @@ static void prof_collect(mi_gallery* g) {
   g->ev_used = 0;
 }
 
+// (re)build the bootstrap sample image for the current number of rows
+static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
+  if (g->samp_img && g->samp_tiles == tiles && g->samp_for_n == g->n) return MI_OK;
+  if (!g->samp_img || g->samp_tiles != tiles) {
+    (void)hipFree(g->samp_img);
+    g->samp_img = nullptr;
+    HIPC(hipMalloc(&g->samp_img, (size_t)tiles * TILE * g->dp * 2 + 256));
+    g->samp_tiles = tiles;
+  }
+  launch_build_sample(g->gal_img, g->samp_img, g->n, tiles * TILE, g->dp, s);
+  HIPC(hipGetLastError());
+  g->samp_for_n = g->n;
+  return MI_OK;
+}
+
 // ---- phase 1 for one batch (nq <= QB): query ingest, chunked scoring + threshold maintenance ----------
 static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                         int32_t nq, int32_t k, bool exact, hipStream_t s) {
@@ -200,7 +218,23 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   int64_t t0 = std::max<int64_t>(g->chunk0_tiles, (2 * (int64_t)k + TILE - 1) / TILE);
   t0 = std::min<int64_t>(t0, ws.cap / TILE);
   t0 = std::min<int64_t>(t0, ntiles);
-  const uint32_t first_cnt = (uint32_t)std::min<int64_t>(g->n, t0 * TILE);
+  // Single-launch schedule?  The speculative threshold is an order statistic of the scores of a SAMPLE: t0 * 256
+  // rows drawn evenly (one hashed draw per stratum) into their own small image, so that the order in which the shard
+  // was ingested cannot bias it.  With n_s sampled rows the shard's K-th largest score sits near sample rank
+  // lambda = K * n_s / N; the r-th largest sample score with r = lambda + 5 sqrt(lambda) + 6 lies below it except with
+  // probability ~1e-6 per query (Poisson tail) and keeps the expected survivors at r * N / n_s.  The sample entries
+  // are dropped once the threshold is taken (the scoring launch visits every tile, sample rows included).
+  int32_t samp_r = 0;
+  if (g->speculative && !exact && ntiles >= 2 * t0 && g->n / (t0 * TILE) <= 160) {
+    const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
+    const int32_t r = (int32_t)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 6.0);
+    if (r < k) samp_r = r;
+  }
+  if (samp_r > 0) {
+    const int rc = ensure_sample(g, t0, s);
+    if (rc != MI_OK) return rc;
+  }
+  const uint32_t first_cnt = (uint32_t)(samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
   const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
   launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
   // chunk boundaries (cumulative tiles): t0, t0*g, then x max(2, g/2) per step (thresholds keep tightening as the
@@ -210,8 +244,8 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   int64_t bound = t0;
   int64_t t = 0, len = t0;
   bool first = true;
-  bool spec_next = false, spec_cur = false;     // speculative threshold for the next / the current scoring launch
-  auto score_launch = [&](int64_t tile_from, int64_t ntile, bool first_chunk, const uint32_t* cond, bool profile_it) {
+  auto score_launch = [&](int64_t tile_from, int64_t ntile, bool first_chunk, const uint32_t* cond, bool profile_it,
+                          bool on_sample = false) {
     const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
     if (exact) {
       ExactArgs a;
@@ -227,14 +261,14 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       return;
     }
     ScoreArgs a;
-    a.gal_img = g->gal_img;
+    a.gal_img = on_sample ? g->samp_img : g->gal_img;
     a.qry_img = ws.q_img;
     a.img_f16 = g->img_f16;
     a.nslices = g->dp / SLICE_K;
     a.tile0 = (int32_t)tile_from;
     a.ntiles = (int32_t)ntile;
     a.nqt = qpad / TILE;
-    a.n = g->n;
+    a.n = on_sample ? ntile * TILE : g->n;
     a.nq = nq;
     a.debug = g->debug;
     a.rec = ws.rec;
@@ -255,26 +289,36 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     }
     if (!first_chunk) launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s);
   };
+  if (samp_r > 0) {
+    score_launch(0, t0, true, nullptr, false, true);                           // bootstrap on the sample image
+    launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
+    score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
+    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 0, nullptr, s);
+    // repair pass for queries whose speculative threshold failed verification: conditional on the device word
+    // flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip
+    const uint32_t* cond = ws.flags + 1;
+    score_launch(0, ntiles, false, cond, false);
+    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s);
+    HIPC(hipGetLastError());
+    return MI_OK;
+  }
+  // chunk schedule (shards too small or too large for the sample-based single launch): thresholds come from the rows
+  // scored and kept so far; once those are >= 1/160 of the shard the rest goes out as one speculative launch
+  bool spec_next = false, spec_cur = false;
   while (t < ntiles) {
     int64_t cur = std::min<int64_t>(len, ntiles - t);
-    if (spec_next) cur = ntiles - t;            // one launch for everything that is left
+    if (spec_next) cur = ntiles - t;
     spec_cur = spec_next;
     score_launch(t, cur, first, nullptr, true);
     t += cur;
-    const bool last = (t >= ntiles);
-    if (last) {
+    if (t >= ntiles) {
       launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, spec_cur ? 1 : 0, 0, nullptr, s);
       if (spec_cur) {
-        // repair pass for queries whose speculative threshold failed verification: conditional on the device word
-        // flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip
         const uint32_t* cond = ws.flags + 1;
         score_launch(0, ntiles, false, cond, false);
         launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s);
       }
     } else {
-      // Speculative threshold for the rest?  With n_s rows seen, the shard's K-th largest score sits near sample rank
-      // lambda = K * n_s / N.  The r-th largest sample score with r = lambda + 5 sqrt(lambda) + 6 lies below it except
-      // with probability ~1e-6 per query (Poisson tail), and keeps the expected survivors at r * N / n_s.
       int32_t spec_r = 0;
       const int64_t n_seen = std::min<int64_t>(g->n, t * TILE);
       if (g->speculative && !exact && g->n / n_seen <= 160) {
@@ -371,6 +415,7 @@ int mi_gallery_destroy(mi_gallery* g) {
   }
   (void)hipFree(g->gal_f32);
   (void)hipFree(g->gal_img);
+  (void)hipFree(g->samp_img);
   (void)hipFree(g->rowstat);
   (void)hipFree(g->gstat3);
   (void)hipFree(g->dif_ids);
@@ -1233,6 +1278,11 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   }
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
   return MI_OK;
+}
+
+int64_t mi_debug_sample_source_row(int64_t i, int64_t n, int64_t n_s) {
+  if (i < 0 || n_s <= 0 || n < n_s || i >= n_s) return -1;
+  return sample_source_row_host(i, n, n_s);
 }
 
 int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count) {

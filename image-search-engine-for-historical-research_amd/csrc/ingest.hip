@@ -254,4 +254,43 @@ void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStrea
   hipLaunchKernelGGL(rowstat_max_kernel, dim3(blocks), dim3(256), 0, stream, rowstat, n, out3);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Bootstrap sample image: n_s rows drawn one per stratum of N / n_s consecutive rows at a hashed offset, copied
+// from the tile-blocked gallery image into a small tile-blocked image of its own.  The speculative threshold of the
+// single-launch schedule is an order statistic of the scores of THESE rows, so the draw has to be representative
+// of the whole shard whatever order the rows were ingested in (the reference's 1M gallery is [rOxford | distractors],
+// src/test_rOP1m.py:136-139: a sample made of the first rows would contain every true positive of a query).
+__host__ __device__ inline int64_t sample_source_row(int64_t i, int64_t n, int64_t n_s) {
+  const int64_t lo = i * n / n_s, hi = (i + 1) * n / n_s;             // stratum [lo, hi), never empty for n >= n_s
+  uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 32;
+  return lo + (int64_t)(h % (uint64_t)(hi - lo));
+}
+
+__global__ __launch_bounds__(256) void build_sample_kernel(const uint16_t* __restrict__ gal_img,
+                                                           uint16_t* __restrict__ samp_img, int64_t n, int64_t n_s,
+                                                           int32_t nslices) {
+  const int64_t i = blockIdx.x;                                        // sample row
+  const int64_t r = sample_source_row(i, n, n_s);
+  const uint32_t ri = (uint32_t)(i % TILE), rr = (uint32_t)(r % TILE);
+  const uint16_t* src = gal_img + (r / TILE) * nslices * (int64_t)SLICE_ELEMS + (int64_t)rr * SLICE_K;
+  uint16_t* dst = samp_img + (i / TILE) * nslices * (int64_t)SLICE_ELEMS + (int64_t)ri * SLICE_K;
+  for (uint32_t j = threadIdx.x; j < (uint32_t)nslices * 4u; j += blockDim.x) {
+    const uint32_t sl = j >> 2, c = j & 3u;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)sl * SLICE_ELEMS + (swz_chunk(rr, c) << 3));
+    *reinterpret_cast<uint4*>(dst + (int64_t)sl * SLICE_ELEMS + (swz_chunk(ri, c) << 3)) = v;
+  }
+}
+
+void launch_build_sample(const void* gal_img, void* samp_img, int64_t n, int64_t n_s, int32_t dp, hipStream_t stream) {
+  hipLaunchKernelGGL(build_sample_kernel, dim3((uint32_t)n_s), dim3(256), 0, stream,
+                     reinterpret_cast<const uint16_t*>(gal_img), reinterpret_cast<uint16_t*>(samp_img), n, n_s,
+                     dp / SLICE_K);
+}
+
+int64_t sample_source_row_host(int64_t i, int64_t n, int64_t n_s) { return sample_source_row(i, n, n_s); }
+
 }  // namespace mi

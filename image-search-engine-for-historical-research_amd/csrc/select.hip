@@ -196,7 +196,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
 #pragma unroll
   for (int j = 0; j < MAINT_PER_THREAD; ++j) {
     const uint32_t i = threadIdx.x + j * MAINT_THREADS;
-    if (i < n && !failed) {
+    if (i < n && !failed && !(MODE == 0 && spec)) {
       const float sc = entry_score(ent[j]);
       if (sc >= thr_new) gsurv[atomicAdd(&sh[2], 1u)] = ent[j];          // compaction (order is irrelevant)
       if (MODE == 1) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     if (MODE == 0) {
       st.thr[q] = thr_new;
       st.thr2[q] = thr2;
-      st.cnt[q * CNT_STRIDE] = sh[2];
+      st.cnt[q * CNT_STRIDE] = spec ? 0u : sh[2];   // spec (MODE 0): entries came from the sample image, drop them
     } else if (spec) {
       if (failed && !repair) {
         st.thr[q] = thr_new;                       // = thr2: the repair pass re-scans every tile for this query

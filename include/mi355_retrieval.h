@@ -209,6 +209,10 @@ int mi_set_global_option(const char* name, double value);
  * layout [workgroups*8][8] = {load, barrier1, mfma, barrier2, epilogue, slices, -, -}. */
 int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count);
 
+/* Diagnostics only: the gallery row that sample row i of the bootstrap sample image is drawn from (shard of n rows, sample
+ * of n_s rows: one hashed draw per stratum of n / n_s consecutive rows).  Tests use it to plant rows inside the sample. */
+int64_t mi_debug_sample_source_row(int64_t i, int64_t n, int64_t n_s);
+
 /* ---- synthetic data (bench / tests): device twin of synth.synth_rows. */
 int mi_synth_fill_device(float* dst_dev, uint64_t seed, int64_t row0, int64_t nrows, int32_t d,
                          void* stream);

@@ -1,8 +1,7 @@
-timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --with-aqe 2>&1 | python -c "
+for rows in 1005994 502997 251499 125750; do timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --rows $rows 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         j=json.loads(l); r=j['roofline']
-        print('with alpha-QE', 'ms/step=%.3f'%j['ms_per_step'], 'q/s=%.0f'%j['value'], 'gemm TF=%.0f'%r['achieved'], 'launches', r['launches'])
-    elif 'rror' in l or 'invalid' in l: print(l.strip()[:300])
-"
+        print('rows=$rows', 'ms/step=%.3f'%j['ms_per_step'], 'gemm ms=%.3f'%(r['avg_launch_ms']), 'share=%.2f'%r['kernel_share_of_step'], 'cand/q=%.0f'%j['config']['candidates_per_query'])
+"; done

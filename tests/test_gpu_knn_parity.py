@@ -187,8 +187,8 @@ def test_unnormalised_gallery_with_large_values_uses_bf16_image(lib):
 
 @pytest.mark.parametrize("ndup,expect_fallback", [(0, False), (30, False), (90, True)])
 def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallback):
-    """The single-launch schedule uses a speculative threshold taken from the bootstrap sample (rows 0..8191) and
-    verifies it afterwards.  Near-duplicates of the query planted INSIDE the sample make that threshold too high:
+    """The single-launch schedule uses a speculative threshold taken from the bootstrap sample (32 tiles of 256 rows
+    worth of rows drawn evenly from the gallery) and verifies it afterwards.  Near-duplicates of the query planted INSIDE the sample make that threshold too high:
     30 of them -> the device-side repair pass (looser threshold) must fix the query; 90 of them -> the repair fails
     too and the host API falls back to the rigorous schedule.  Results must be exact in every case."""
     from isehr_amd._lib import Gallery
@@ -196,7 +196,9 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
     g = synth_rows(71, 0, n, d)
     q = synth_rows(72, 0, nq, d)
     rng = np.random.default_rng(3)
-    rows = rng.choice(8192, size=ndup, replace=False)
+    sample_rows = lib.sample_source_rows(n)                 # one hashed draw per stratum of n / 8192 rows
+    assert len(set(sample_rows)) == 8192 and sample_rows.min() >= 0 and sample_rows.max() < n
+    rows = rng.choice(sample_rows, size=ndup, replace=False)
     for j, r in enumerate(rows):
         g[r] = q[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
     G = Gallery.from_host(g)
@@ -207,6 +209,28 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
     assert oracle.check_topk_parity(idx, s, k, TAU) == []
     assert set(rows) <= set(idx[0])
     assert (st["overflow_batches"] >= 1) == expect_fallback
+
+
+def test_ordered_gallery_keeps_the_fast_path(lib):
+    """The reference's 1M gallery is [rOxford | distractors] (src/test_rOP1m.py:136-139): every true positive of a
+    query sits in the first rows.  The bootstrap sample is drawn evenly from the whole shard, so that such an ordering
+    neither pushes the speculative threshold up nor costs a fallback; the answers are exact either way."""
+    from isehr_amd._lib import Gallery
+    n, d, nq, k = 150000, 128, 12, 100
+    g = synth_rows(75, 0, n, d)
+    q = synth_rows(76, 0, nq, d)
+    for qi in range(nq):                                    # 150 positives per query, all inside rows 0..1799
+        for j in range(150):
+            g[qi * 150 + j] = q[qi] + (0.3 + 0.004 * j) * synth_rows(77, qi * 150 + j, 1, d)[0]
+    G = Gallery.from_host(g)
+    idx, sc, _ = G.search(q, k)
+    st = G.status()
+    G.close()
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
+    assert all(set(idx[qi]) <= set(range(qi * 150, qi * 150 + 150)) for qi in range(nq))
+    assert st["overflow_batches"] == 0
+    assert st["survivors"] / st["queries"] < 4096           # the filter stayed selective
 
 
 def test_bf16_image_path_gives_the_same_answers(lib, golden_dir):
