@@ -77,6 +77,7 @@ struct mi_gallery {
   Workspace ws;
   // options
   int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0, speculative = 1;
+  int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -271,6 +272,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.n = on_sample ? ntile * TILE : g->n;
     a.nq = nq;
     a.debug = g->debug;
+    a.small_batch_kernel = g->small_batch_kernel;
     a.rec = ws.rec;
     a.rec_cnt = ws.rec_cnt;
     a.rec_cap = ws.rec_cap;
@@ -1272,6 +1274,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "force_exact") g->force_exact = value != 0;
   else if (n == "debug") g->debug = (int)value;
   else if (n == "speculative") g->speculative = value != 0;
+  else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
     g->qnorm_override = (int)value;

@@ -25,6 +25,7 @@ struct ScoreArgs {
   int64_t n;              // valid gallery rows in the shard
   int32_t nq;             // valid queries
   int32_t debug;          // diagnostics only: bit0 skip DMA, bit1 skip MFMA, bit2 skip filter (results invalid)
+  int32_t small_batch_kernel;   // 1: launches with <= STREAM_MAX_QUERIES queries go to stream_select.hip
   SurvRec* rec;           // [grid * 8 waves][rec_cap] wave-private survivor records of this launch
   uint32_t* rec_cnt;      // [grid * 8]
   uint32_t rec_cap;
@@ -32,6 +33,10 @@ struct ScoreArgs {
   unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
+// stream_select.hip: the scoring + filter launch for small query batches (HBM-bound; same records and thresholds)
+constexpr int STREAM_MAX_QUERIES = 128;
+bool stream_select_applies(const ScoreArgs& a);
+void launch_stream_select(const ScoreArgs& a, hipStream_t stream);
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
 // buckets the wave-private records of the last scoring launch into the per-query survivor buffers

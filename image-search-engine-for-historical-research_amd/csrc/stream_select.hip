@@ -1,0 +1,212 @@
+// Small-batch scoring kernel with fused survivor filter (gfx950 / CDNA4): Q <= 128 queries per launch.
+//
+// The reference's online stage scores ONE query image against the whole database and its test sets have 70
+// queries (src/online.py:132-147, src/test_rOP1m.py:144-149).  With so few queries the contraction is bound by
+// streaming the 16-bit gallery image from HBM (2 * D bytes per row), not by the matrix pipe: the 256 x 256-tile
+// kernel of gemm_select.hip paces itself by 32 MFMAs per wave and slice whatever the batch, which caps it at
+// ~5.1 TB/s.  This kernel keeps the gallery side of that design (tile-blocked image, 16 KiB K-slices moved by
+// global_load_lds_dwordx4 into an LDS ring that never drains, counted vmcnt, raw s_barrier) and narrows the
+// query side to NQB blocks of 16 queries:
+//  * persistent grid, one 512-thread workgroup per CU; workgroup b owns gallery tiles b, b + grid, ...;
+//  * 8 waves x 32 gallery rows, every wave against all NQB * 16 queries: 2 x NQB MFMAs (16x16x32) per slice;
+//  * ONE ring of 6 slots, 5 slices (80 KiB of gallery per CU) in flight, one barrier per slice: the barrier that
+//    publishes slice S also retires every wave's reads of slice S-1, whose slot the next DMA pieces then reuse;
+//  * per slice a wave issues 2 gallery pieces (1 KiB each) and, waves 0..NQB-1, one query piece;
+//  * the filter is the one of the big kernel without its LDS scratch (the matrix pipe is idle most of the time
+//    here): ballot/popcount positions into wave-private record segments, no returning atomics.
+// Records, thresholds and flags are shared with gemm_select.hip (scatter_records_kernel runs afterwards).
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+constexpr int SS_DEPTH = 6;                                   // ring slots; SS_DEPTH - 1 slices in flight
+constexpr int GAL_AUX = 2;                                    // gallery pieces are read once per launch: nt (aux = 2)
+
+template <int NQB, bool F16, bool REPAIR>
+__global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
+  using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BQ_BYTES = NQB * 1024;                        // NQB * 16 query rows of 64 B per slice
+  constexpr int B_RING0 = SS_DEPTH * SLICE_BYTES;
+  constexpr int THR0 = B_RING0 + SS_DEPTH * BQ_BYTES;
+  if (REPAIR && *p.cond == 0) return;
+  const uint32_t b = blockIdx.x, nwg = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t ntiles = (uint32_t)p.ntiles;
+  if (b >= ntiles) {
+    if (lane == 0) p.rec_cnt[b * 8 + w] = 0;
+    return;
+  }
+  const uint32_t my_tiles = (ntiles - b + nwg - 1) / nwg;
+  const uint32_t KSL = (uint32_t)p.nslices;
+  const uint32_t T_total = my_tiles * KSL;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  float* thr_s = reinterpret_cast<float*>(smem + THR0);       // thresholds of the NQB * 16 queries (+inf for padding)
+  if (tid < NQB * 16) thr_s[tid] = p.st.thr[tid];             // published by the first barrier of the loop
+
+  // ---- DMA stream: slice s of my i-th tile, continuous over tile boundaries
+  const bool qloader = w < NQB;
+  uint32_t pf_i = 0, pf_sl = 0, wr_slot = 0;
+  const char* pfa;
+  const char* pfq = reinterpret_cast<const char*>(p.qry_img) + w * 1024 + lane * 16;
+  auto pf_set = [&](uint32_t i) {
+    const uint32_t gt = (uint32_t)p.tile0 + b + (i < my_tiles ? i : my_tiles - 1) * nwg;   // past the end: reload
+    pfa = reinterpret_cast<const char*>(p.gal_img) + (int64_t)gt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
+  };
+  pf_set(0);
+  auto issue = [&]() {
+    char* dst = smem + wr_slot * SLICE_BYTES + w * 2048;
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)pfa, (LDS_AS void*)dst, 16, 0, GAL_AUX);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfa + 1024), (LDS_AS void*)(dst + 1024), 16, 0, GAL_AUX);
+    if (qloader)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfq + (int64_t)pf_sl * SLICE_BYTES),
+                                       (LDS_AS void*)(smem + B_RING0 + wr_slot * BQ_BYTES + w * 1024), 16, 0, 0);
+    pfa += SLICE_BYTES;
+    if (++pf_sl == KSL) {
+      pf_sl = 0;
+      pf_set(++pf_i);
+    }
+    if (++wr_slot == SS_DEPTH) wr_slot = 0;
+  };
+
+  f32x4 acc[2][NQB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NQB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment offsets inside a slot ([rows][32 k] 16-bit, 64-byte rows, chunk-swizzled like the big kernel's)
+  const uint32_t fsw = (0u - (uint32_t)(l15 >> 2)) & 3u;
+  const uint32_t a_off = (uint32_t)(w * 32 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+  const uint32_t b_off = (uint32_t)B_RING0 + (uint32_t)l15 * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+
+  SurvRec* my_rec = p.rec + (uint64_t)(b * 8 + w) * p.rec_cap;
+  uint32_t my_cnt = 0;
+
+#pragma unroll
+  for (int d = 0; d < SS_DEPTH - 1; ++d) issue();             // slices 0 .. DEPTH-2 in flight
+
+  uint32_t rd = 0, cur_i = 0, cur_sl = 0;
+  for (uint32_t S = 0; S < T_total; ++S) {
+    // my pieces of slice S have landed when at most DEPTH-2 later slices of mine are outstanding
+    if (qloader) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // slice S published; reads of slice S-1 retired
+    const char* abase = smem + rd * SLICE_BYTES;
+    const char* bbase = smem + rd * BQ_BYTES;
+    if (++rd == SS_DEPTH) rd = 0;
+    frag_t af[2], bfr[NQB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) af[mb] = *reinterpret_cast<const frag_t*>(abase + a_off + mb * 1024);
+#pragma unroll
+    for (int nb = 0; nb < NQB; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    issue();                                                  // slice S+DEPTH-1 into the slot of slice S-1
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb)
+        if constexpr (F16)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        else
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+
+    if (++cur_sl == KSL) {
+      cur_sl = 0;
+      // ---- tile finished: filter.  C layout of 16x16x32: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+      const uint32_t gt = (uint32_t)p.tile0 + b + cur_i * nwg;
+      const uint32_t row_base = gt * TILE + w * 32 + lq * 4;  // + mb * 16 + reg
+      ++cur_i;
+      float thr[NQB];
+      bool any = false;
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) {
+        thr[nb] = thr_s[nb * 16 + l15];
+        float m = acc[0][nb][0];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
+        any |= m >= thr[nb];
+      }
+      if (__ballot(any)) {
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) {
+          float m = acc[0][nb][0];
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
+          if (__ballot(m >= thr[nb]) == 0) continue;          // wave-uniform
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t row = row_base + mb * 16 + r;
+              const float sc = acc[mb][nb][r];
+              const bool keep = sc >= thr[nb] && row < (uint64_t)p.n;
+              const unsigned long long km = __ballot(keep);
+              if (km) {
+                const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                if (keep && pos < p.rec_cap)
+                  reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(sc), row, nb * 16 + l15, 0u);
+                my_cnt += (uint32_t)__popcll(km);
+              }
+            }
+        }
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (lane == 0) {
+    p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
+    if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // trailing (unused) DMA pieces land before the LDS is released
+}
+
+template <int NQB, bool F16, bool REPAIR>
+static void launch_stream_variant(const ScoreArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)SS_DEPTH * SLICE_BYTES + (size_t)SS_DEPTH * NQB * 1024 + NQB * 16 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)stream_select_kernel<NQB, F16, REPAIR>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((stream_select_kernel<NQB, F16, REPAIR>), dim3(gemm_select_grid()), dim3(512), lds, stream, a);
+}
+
+bool stream_select_applies(const ScoreArgs& a) {
+  return a.small_batch_kernel && a.nqt == 1 && a.nq <= STREAM_MAX_QUERIES && a.debug == 0;
+}
+
+void launch_stream_select(const ScoreArgs& a, hipStream_t stream) {
+  const bool rep = a.cond != nullptr;
+  if (a.nq <= 64) {
+    if (a.img_f16) rep ? launch_stream_variant<4, true, true>(a, stream) : launch_stream_variant<4, true, false>(a, stream);
+    else rep ? launch_stream_variant<4, false, true>(a, stream) : launch_stream_variant<4, false, false>(a, stream);
+  } else {
+    if (a.img_f16) rep ? launch_stream_variant<8, true, true>(a, stream) : launch_stream_variant<8, true, false>(a, stream);
+    else rep ? launch_stream_variant<8, false, true>(a, stream) : launch_stream_variant<8, false, false>(a, stream);
+  }
+}
+
+}  // namespace mi

@@ -196,6 +196,7 @@ int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches 
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
 /* Tunables: "chunk0_tiles", "chunk_growth", "survivor_cap", "rescore_cap", "exact_fallback",
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
+ * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
  * already normalised expanded queries of alpha-QE). */
 int mi_set_option(mi_gallery* g, const char* name, double value);

@@ -211,6 +211,26 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
     assert (st["overflow_batches"] >= 1) == expect_fallback
 
 
+@pytest.mark.parametrize("nq", [1, 16, 17, 64, 65, 70, 128, 129])
+def test_small_batch_kernel_equals_tile_kernel(lib, nq):
+    """Batches of <= 128 queries are scored by the HBM-bound kernel of stream_select.hip (4 or 8 blocks of 16
+    queries); it must produce the answers of the 256 x 256-tile kernel bit for bit, and the exact top-K."""
+    from isehr_amd._lib import Gallery
+    n, d, k = 70001, 320, 50                                # ragged last tile, dp = 320 (10 K-slices)
+    g = synth_rows(91, 0, n, d)
+    q = synth_rows(92, 0, nq, d)
+    G = Gallery.from_host(g)
+    idx1, sc1, _ = G.search(q, k)
+    st1 = G.status()
+    G.set_option("small_batch_kernel", 0)
+    idx0, sc0, _ = G.search(q, k)
+    G.close()
+    assert np.array_equal(idx0, idx1) and np.array_equal(sc0, sc1)
+    assert st1["overflow_batches"] == 0
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx1, s, k, TAU) == []
+
+
 def test_ordered_gallery_keeps_the_fast_path(lib):
     """The reference's 1M gallery is [rOxford | distractors] (src/test_rOP1m.py:136-139): every true positive of a
     query sits in the first rows.  The bootstrap sample is drawn evenly from the whole shard, so that such an ordering
