@@ -36,7 +36,7 @@ struct ScoreArgs {
 // stream_select.hip: the scoring + filter launch for small query batches (HBM-bound; same records and thresholds)
 constexpr int STREAM_MAX_QUERIES = 128;
 bool stream_select_applies(const ScoreArgs& a);
-void launch_stream_select(const ScoreArgs& a, hipStream_t stream);
+void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream);
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
 // buckets the wave-private records of the last scoring launch into the per-query survivor buffers

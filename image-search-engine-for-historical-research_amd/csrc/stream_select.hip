@@ -32,20 +32,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int SS_DEPTH = 6;                                   // ring slots; SS_DEPTH - 1 slices in flight
 constexpr int GAL_AUX = 2;                                    // gallery pieces are read once per launch: nt (aux = 2)
 
-template <int NQB, bool F16, bool REPAIR>
+// MODE 0: filtered launch, 1: conditional repair launch (own instantiation, see gemm_select.hip), 2: bootstrap
+// launch on the sample image (every score stored, slot = sample row)
+template <int NQB, bool F16, int MODE>
 __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BQ_BYTES = NQB * 1024;                        // NQB * 16 query rows of 64 B per slice
   constexpr int B_RING0 = SS_DEPTH * SLICE_BYTES;
   constexpr int THR0 = B_RING0 + SS_DEPTH * BQ_BYTES;
+  constexpr bool REPAIR = MODE == 1, FIRST = MODE == 2;
   if (REPAIR && *p.cond == 0) return;
   const uint32_t b = blockIdx.x, nwg = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t ntiles = (uint32_t)p.ntiles;
   if (b >= ntiles) {
-    if (lane == 0) p.rec_cnt[b * 8 + w] = 0;
+    if (!FIRST && lane == 0) p.rec_cnt[b * 8 + w] = 0;
     return;
   }
   const uint32_t my_tiles = (ntiles - b + nwg - 1) / nwg;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   const int l15 = lane & 15, lq = lane >> 4;
 
   float* thr_s = reinterpret_cast<float*>(smem + THR0);       // thresholds of the NQB * 16 queries (+inf for padding)
-  if (tid < NQB * 16) thr_s[tid] = p.st.thr[tid];             // published by the first barrier of the loop
+  if (!FIRST && tid < NQB * 16) thr_s[tid] = p.st.thr[tid];   // published by the first barrier of the loop
 
   // ---- DMA stream: slice s of my i-th tile, continuous over tile boundaries
   const bool qloader = w < NQB;
@@ -132,8 +135,25 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
       ++cur_i;
       float thr[NQB];
       bool any = false;
+      if constexpr (FIRST) {
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) {
+          const uint32_t q = nb * 16 + l15;
+          if (q < (uint32_t)p.nq) {
+            uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t row = row_base + mb * 16 + r;
+                if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
+              }
+          }
+        }
+      }
 #pragma unroll
       for (int nb = 0; nb < NQB; ++nb) {
+        if constexpr (FIRST) break;
         thr[nb] = thr_s[nb * 16 + l15];
         float m = acc[0][nb][0];
 #pragma unroll
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
           for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
         any |= m >= thr[nb];
       }
-      if (__ballot(any)) {
+      if (!FIRST && __ballot(any)) {
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
           float m = acc[0][nb][0];
@@ -175,38 +195,39 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
         for (int nb = 0; nb < NQB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (lane == 0) {
+  if (!FIRST && lane == 0) {
     p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
     if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // trailing (unused) DMA pieces land before the LDS is released
 }
 
-template <int NQB, bool F16, bool REPAIR>
+template <int NQB, bool F16, int MODE>
 static void launch_stream_variant(const ScoreArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)SS_DEPTH * SLICE_BYTES + (size_t)SS_DEPTH * NQB * 1024 + NQB * 16 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)stream_select_kernel<NQB, F16, REPAIR>,
+    (void)hipFuncSetAttribute((const void*)stream_select_kernel<NQB, F16, MODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((stream_select_kernel<NQB, F16, REPAIR>), dim3(gemm_select_grid()), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(gemm_select_grid()), dim3(512), lds, stream, a);
 }
 
 bool stream_select_applies(const ScoreArgs& a) {
   return a.small_batch_kernel && a.nqt == 1 && a.nq <= STREAM_MAX_QUERIES && a.debug == 0;
 }
 
-void launch_stream_select(const ScoreArgs& a, hipStream_t stream) {
-  const bool rep = a.cond != nullptr;
-  if (a.nq <= 64) {
-    if (a.img_f16) rep ? launch_stream_variant<4, true, true>(a, stream) : launch_stream_variant<4, true, false>(a, stream);
-    else rep ? launch_stream_variant<4, false, true>(a, stream) : launch_stream_variant<4, false, false>(a, stream);
-  } else {
-    if (a.img_f16) rep ? launch_stream_variant<8, true, true>(a, stream) : launch_stream_variant<8, true, false>(a, stream);
-    else rep ? launch_stream_variant<8, false, true>(a, stream) : launch_stream_variant<8, false, false>(a, stream);
-  }
+template <int NQB, bool F16>
+static void launch_stream_mode(const ScoreArgs& a, bool first, hipStream_t stream) {
+  if (first) return launch_stream_variant<NQB, F16, 2>(a, stream);
+  if (a.cond) return launch_stream_variant<NQB, F16, 1>(a, stream);
+  return launch_stream_variant<NQB, F16, 0>(a, stream);
+}
+
+void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream) {
+  if (a.nq <= 64) a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
+  else a.img_f16 ? launch_stream_mode<8, true>(a, first, stream) : launch_stream_mode<8, false>(a, first, stream);
 }
 
 }  // namespace mi
