@@ -415,7 +415,7 @@ static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
 }
 
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
-  if (stream_select_applies(a)) return launch_stream_select(a, first, stream);
+  if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
   const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * 64 * 4;
   if (a.cond) return a.img_f16 ? launch_variant<false, 0, true, true>(a, lds, stream)
                                : launch_variant<false, 0, false, true>(a, lds, stream);

@@ -36,6 +36,7 @@ struct ScoreArgs {
 // stream_select.hip: the scoring + filter launch for small query batches (HBM-bound; same records and thresholds)
 constexpr int STREAM_MAX_QUERIES = 128;
 bool stream_select_applies(const ScoreArgs& a);
+bool stream_bootstrap_applies(const ScoreArgs& a);   // bootstrap launches of any batch size
 void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream);
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8

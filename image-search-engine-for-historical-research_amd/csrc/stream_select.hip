@@ -43,10 +43,14 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   constexpr int THR0 = B_RING0 + SS_DEPTH * BQ_BYTES;
   constexpr bool REPAIR = MODE == 1, FIRST = MODE == 2;
   if (REPAIR && *p.cond == 0) return;
-  const uint32_t b = blockIdx.x, nwg = gridDim.x;
+  // bootstrap launches are not persistent: one workgroup per (tile, group of NQB * 16 queries), so that a 1024-query
+  // batch spreads its 32 sample tiles over 256 CUs instead of 128 tile-kernel workgroups of a full tile time each
+  const uint32_t ntiles = (uint32_t)p.ntiles;
+  const uint32_t qg = FIRST ? blockIdx.x / ntiles : 0u;
+  const uint32_t b = FIRST ? blockIdx.x % ntiles : blockIdx.x, nwg = FIRST ? ntiles : gridDim.x;
+  const uint32_t q0 = qg * NQB * 16;                          // first query of this workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t ntiles = (uint32_t)p.ntiles;
   if (b >= ntiles) {
     if (!FIRST && lane == 0) p.rec_cnt[b * 8 + w] = 0;
     return;
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   const bool qloader = w < NQB;
   uint32_t pf_i = 0, pf_sl = 0, wr_slot = 0;
   const char* pfa;
-  const char* pfq = reinterpret_cast<const char*>(p.qry_img) + w * 1024 + lane * 16;
+  const char* pfq = reinterpret_cast<const char*>(p.qry_img) + (int64_t)(q0 / TILE) * KSL * SLICE_BYTES +
+                    (q0 % TILE) * 64 + w * 1024 + lane * 16;
   auto pf_set = [&](uint32_t i) {
     const uint32_t gt = (uint32_t)p.tile0 + b + (i < my_tiles ? i : my_tiles - 1) * nwg;   // past the end: reload
     pfa = reinterpret_cast<const char*>(p.gal_img) + (int64_t)gt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
       if constexpr (FIRST) {
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
-          const uint32_t q = nb * 16 + l15;
+          const uint32_t q = q0 + nb * 16 + l15;
           if (q < (uint32_t)p.nq) {
             uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
 #pragma unroll
@@ -211,7 +216,8 @@ static void launch_stream_variant(const ScoreArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(gemm_select_grid()), dim3(512), lds, stream, a);
+  const unsigned grid = MODE == 2 ? (unsigned)a.ntiles * (unsigned)((a.nq + NQB * 16 - 1) / (NQB * 16)) : gemm_select_grid();
+  hipLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(grid), dim3(512), lds, stream, a);
 }
 
 bool stream_select_applies(const ScoreArgs& a) {
@@ -224,6 +230,8 @@ static void launch_stream_mode(const ScoreArgs& a, bool first, hipStream_t strea
   if (a.cond) return launch_stream_variant<NQB, F16, 1>(a, stream);
   return launch_stream_variant<NQB, F16, 0>(a, stream);
 }
+
+bool stream_bootstrap_applies(const ScoreArgs& a) { return a.small_batch_kernel && a.debug == 0; }
 
 void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   if (a.nq <= 64) a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
