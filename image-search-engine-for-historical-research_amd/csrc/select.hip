@@ -300,14 +300,16 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
                                                       const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
                                                       double* __restrict__ cand_score) {
   const uint32_t q = blockIdx.y;
-  const uint32_t c0 = blockIdx.x * ROWS_PER_WG;
   const uint32_t nc = cand_cnt[q];
-  if (c0 >= nc) return;
+  if (blockIdx.x * ROWS_PER_WG >= nc) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4* qv = reinterpret_cast<const float4*>(qry + (uint64_t)q * dp);
   const int nvec = dp >> 2;            // float4 per row (dp is a multiple of 64 -> nvec multiple of 16)
   const uint32_t* rows = cand_rows + (uint64_t)q * rcap;
   double* outs = cand_score + (uint64_t)q * rcap;
+  // grid.x covers RESCORE_GRID_X * ROWS_PER_WG candidates per sweep (the usual count fits one sweep; a launch sized for
+  // rcap would consist almost entirely of workgroups that exit at once)
+  for (uint32_t c0 = blockIdx.x * ROWS_PER_WG; c0 < nc; c0 += gridDim.x * ROWS_PER_WG) {
   const uint32_t cend = min(nc, c0 + ROWS_PER_WG);
   for (uint32_t c = c0 + w * 2; c < cend; c += 8) {
     const bool two = (c + 1 < cend);
@@ -333,16 +335,19 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
       if (two) outs[c + 1] = a1;
     }
   }
+  }
 }
 
 // 8 rows per workgroup: every wave makes exactly one 2-row pass.  Measured on 1024 x ~358 candidate rows of 8 KiB:
 // 590 us (5.1 TB/s) vs 977 us with 32 rows per workgroup; the unroll factor of the column loop does not matter.
 constexpr int RESCORE_ROWS_PER_WG = 8;
+constexpr uint32_t RESCORE_GRID_X = 32;     // 256 candidates per query and sweep
 
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                     const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
   hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>),
-                     dim3((rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG, nq), dim3(256), 0, stream, gal_f32,
+                     dim3(std::min<uint32_t>(RESCORE_GRID_X, (rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG), nq),
+                     dim3(256), 0, stream, gal_f32,
                      qry_f32, dp, cand_rows, cand_cnt, rcap, cand_score);
 }
 
