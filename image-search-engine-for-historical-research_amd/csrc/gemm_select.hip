@@ -141,7 +141,11 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // fragment read offsets inside one operand image ([256 rows][32 k] bf16, 64-byte rows, chunk-swizzled)
   const uint32_t fsw = (0u - (uint32_t)(l15 >> 2)) & 3u;
   const uint32_t a_off = (uint32_t)(wr * 128 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
-  const uint32_t b_off = (uint32_t)B_RING + (uint32_t)(wc * 64 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+  uint32_t b_off = (uint32_t)B_RING + (uint32_t)(wc * 64 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+  // opaque to constant folding: otherwise B_RING (80 KiB, beyond the 16-bit ds offset field) is split off again, every
+  // B fragment read gets an address register of its own, and the registers' reuse puts an lgkmcnt(0) wait in the
+  // middle of the read burst
+  asm volatile("" : "+v"(b_off));
 
   uint32_t cur_i = 0, cur_sl = 0, gt, qt;
   tile_of(0, gt, qt);
@@ -259,6 +263,11 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
         }
       }
       if (DBG & 8) { te2 = stamp(); d_e1 += te1 - te0; d_e2 += te2 - te1; d_hits += total; }
+      // no LDS operation may stay pending past the filter: the scan's early exit leaves unused reads in flight, and the
+      // compiler then protects their destination registers (reused for fragments) with an lgkmcnt(0) wait in the middle
+      // of EVERY slice's fragment read burst.  A real s_waitcnt instruction (not inline asm) so that its counter
+      // tracking sees it: lgkmcnt(0), vmcnt / expcnt untouched.
+      __builtin_amdgcn_s_waitcnt(0xC07F);
     }
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb)
