@@ -316,8 +316,27 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
     const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
     double a0 = 0.0, a1 = 0.0;
+    int v = lane;
+    // 4 column steps at a time with all 12 loads issued before the first use (the rolled loop keeps only 3 loads of
+    // 16 B per lane in flight and pays one memory round trip per step)
+    for (; v + 192 < nvec; v += 256) {
+      float4 x[4], y0[4], y1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = qv[v + 64 * u];
+        y0[u] = g0[v + 64 * u];
+        y1[u] = g1[v + 64 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 += (double)x[u].x * (double)y0[u].x; a0 += (double)x[u].y * (double)y0[u].y;
+        a0 += (double)x[u].z * (double)y0[u].z; a0 += (double)x[u].w * (double)y0[u].w;
+        a1 += (double)x[u].x * (double)y1[u].x; a1 += (double)x[u].y * (double)y1[u].y;
+        a1 += (double)x[u].z * (double)y1[u].z; a1 += (double)x[u].w * (double)y1[u].w;
+      }
+    }
 #pragma unroll UNROLL
-    for (int v = lane; v < nvec; v += 64) {
+    for (; v < nvec; v += 64) {
       const float4 x = qv[v];
       const float4 y0 = g0[v];
       const float4 y1 = g1[v];
