@@ -43,6 +43,22 @@ constexpr int HIT_SLOTS = 12;                               // per-wave filter s
 constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1728 B
 constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 13.5 KiB per workgroup
 
+// LDS stores of the filter scratch as inline asm.  The compiler orders every DS store it can see behind ALL pending
+// LDS-DMA transfers (it cannot tell that the scratch and the rings are disjoint) with an s_waitcnt vmcnt(0), which
+// drains the DMA rings at every tile boundary; the hardware needs no such wait for disjoint addresses.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const LDS_AS char*)(const char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_store16(uint32_t addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_store16u(uint32_t addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ void glds16(const char* gsrc, char* ldst) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)ldst, 16, 0, 0);
 }
@@ -156,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // filter scratch of this wave: scores of up to HIT_SLOTS "hit" lanes (32 each) + their (thr, q, row base)
   float* sc_val = reinterpret_cast<float*>(smem + RING_BYTES + w * WAVE_SCRATCH);  // after both rings
   uint4* sc_meta = reinterpret_cast<uint4*>(smem + RING_BYTES + w * WAVE_SCRATCH + HIT_SLOTS * 32 * 4);
+  const uint32_t sc_val_lds = lds_addr(sc_val), sc_meta_lds = lds_addr(sc_meta);
 
   // ---- per-tile filter of the accumulators (+ reset).  Called by group 1 right after its last MFMA segment of
   // the tile and by group 0 ONE INTERVAL LATER (before its first MFMA segment of the next tile), so that both
@@ -225,26 +242,42 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)hm[nb], 0u));
           const bool mine = (hm[nb] >> lane) & 1ull;
           if (mine && rank >= r0 && rank < r0 + HIT_SLOTS) {
-            float4* dst = reinterpret_cast<float4*>(sc_val + (rank - r0) * 32);
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb)
-              dst[mb] = make_float4(acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]);
-            sc_meta[rank - r0] = make_uint4(__float_as_uint(thr4[nb]), ql_base + nb * 16, row_base, 0u);
+            const uint32_t dst = sc_val_lds + (rank - r0) * 128;
+            lds_store16<0>(dst, acc[0][nb]);
+            lds_store16<16>(dst, acc[1][nb]);
+            lds_store16<32>(dst, acc[2][nb]);
+            lds_store16<48>(dst, acc[3][nb]);
+            lds_store16<64>(dst, acc[4][nb]);
+            lds_store16<80>(dst, acc[5][nb]);
+            lds_store16<96>(dst, acc[6][nb]);
+            lds_store16<112>(dst, acc[7][nb]);
+            lds_store16u(sc_meta_lds + (rank - r0) * 16,
+                         (u32x4){__float_as_uint(thr4[nb]), ql_base + nb * 16, row_base, 0u});
           }
         }
         const uint32_t nslots = min(total - r0, (uint32_t)HIT_SLOTS);
         // scan of nslots x 32 scores (entry e -> slot e >> 5, value index e & 31 = mb * 4 + r): all LDS reads of the
         // round are issued before the first ballot, so the round pays ONE read latency, not one per 64 entries
         constexpr int SCAN = HIT_SLOTS * 32 / 64;
-        uint4 mt[SCAN];
+        u32x3 mt[SCAN];                                              // (threshold, query, row base)
         float vv[SCAN];
 #pragma unroll
         for (int it = 0; it < SCAN; ++it) {
           const uint32_t e = it * 64 + lane;
           const bool valid = e < nslots * 32;
-          mt[it] = sc_meta[valid ? (e >> 5) : 0];
-          vv[it] = sc_val[valid ? e : 0];
+          // inline asm for the same reason as the stores (a visible DS load of the scratch is ordered behind the
+          // LDS-DMA transfers as well); the results become usable after the lgkmcnt(0) below, which every value passes
+          asm volatile("ds_read_b96 %0, %2\n\tds_read_b32 %1, %3"
+                       : "=v"(mt[it]), "=v"(vv[it])
+                       : "v"(sc_meta_lds + (valid ? (e >> 5) : 0u) * 16u), "v"(sc_val_lds + (valid ? e : 0u) * 4u)
+                       : "memory");
         }
+        static_assert(SCAN == 6, "the wait below lists the scan registers explicitly");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(mt[0]), "+v"(mt[1]), "+v"(mt[2]), "+v"(mt[3]), "+v"(mt[4]), "+v"(mt[5]), "+v"(vv[0]),
+                       "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5])
+                     :
+                     : "memory");
 #pragma unroll
         for (int it = 0; it < SCAN; ++it) {
           if ((uint32_t)(it * 64) >= nslots * 32) break;              // wave-uniform
