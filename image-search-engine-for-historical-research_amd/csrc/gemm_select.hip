@@ -39,9 +39,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int A_SLOTS = 5, B_SLOTS = 4;
 constexpr int A_RING = 0, B_RING = A_SLOTS * SLICE_BYTES;                 // byte offsets in LDS
 constexpr int RING_BYTES = (A_SLOTS + B_SLOTS) * SLICE_BYTES;             // 144 KiB
-constexpr int HIT_SLOTS = 12;                               // per-wave filter scratch: 12 (lane, block) pairs x 32 scores + meta
-constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1728 B
-constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 13.5 KiB per workgroup
+constexpr int HIT_SLOTS = 8;                                // per-wave filter scratch: 8 (lane, block) pairs x 32 scores + meta
+constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1152 B
+constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 9 KiB per workgroup
 
 // LDS stores of the filter scratch as inline asm.  The compiler orders every DS store it can see behind ALL pending
 // LDS-DMA transfers (it cannot tell that the scratch and the rings are disjoint) with an s_waitcnt vmcnt(0), which
@@ -272,10 +272,9 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
                        : "v"(sc_meta_lds + (valid ? (e >> 5) : 0u) * 16u), "v"(sc_val_lds + (valid ? e : 0u) * 4u)
                        : "memory");
         }
-        static_assert(SCAN == 6, "the wait below lists the scan registers explicitly");
+        static_assert(SCAN == 4, "the wait below lists the scan registers explicitly");
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(mt[0]), "+v"(mt[1]), "+v"(mt[2]), "+v"(mt[3]), "+v"(mt[4]), "+v"(mt[5]), "+v"(vv[0]),
-                       "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5])
+                     : "+v"(mt[0]), "+v"(mt[1]), "+v"(mt[2]), "+v"(mt[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3])
                      :
                      : "memory");
 #pragma unroll
