@@ -86,6 +86,10 @@ struct mi_gallery {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   hipStream_t ev_stream = nullptr;
+  // grow-only device staging of the host entry point mi_knn_search (queries in, results out): a hipMalloc / hipFree
+  // pair per call costs more than a single-query search
+  void* io_buf[3] = {nullptr, nullptr, nullptr};
+  size_t io_cap[3] = {0, 0, 0};
   // diffusion state (offline matrix rows kept on the device for the online stage)
   int32_t* dif_ids = nullptr;
   float* dif_vals = nullptr;
@@ -418,6 +422,7 @@ int mi_gallery_destroy(mi_gallery* g) {
   (void)hipFree(g->gal_f32);
   (void)hipFree(g->gal_img);
   (void)hipFree(g->samp_img);
+  for (void* b : g->io_buf) (void)hipFree(b);
   (void)hipFree(g->rowstat);
   (void)hipFree(g->gstat3);
   (void)hipFree(g->dif_ids);
@@ -738,18 +743,23 @@ int mi_knn_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t r
   int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
   if (rc != MI_OK) return rc;
   const size_t esz = dtype == MI_F32 ? 4 : 8;
-  void* qd = nullptr;
-  int64_t* idx_d = nullptr;
-  float* sc_d = nullptr;
-  HIPC(hipMalloc(&qd, (size_t)elems * esz + 256));
-  auto done = [&](int code) {
-    (void)hipFree(qd);
-    (void)hipFree(idx_d);
-    (void)hipFree(sc_d);
-    return code;
+  auto stage = [&](int slot, size_t bytes) -> void* {
+    if (g->io_cap[slot] < bytes) {
+      (void)hipFree(g->io_buf[slot]);
+      g->io_buf[slot] = nullptr;
+      g->io_cap[slot] = 0;
+      const size_t want = bytes + bytes / 4 + 256;
+      if (hipMalloc(&g->io_buf[slot], want) != hipSuccess) return nullptr;
+      g->io_cap[slot] = want;
+    }
+    return g->io_buf[slot];
   };
-  if (hipMalloc((void**)&idx_d, (size_t)nq * k * 8) != hipSuccess || hipMalloc((void**)&sc_d, (size_t)nq * k * 4) != hipSuccess)
-    return done(fail(MI_ERR_NOMEM, "output buffers"));
+  if ((rc = check_k(g, k)) != MI_OK) return rc;            // before sizing buffers by k
+  void* qd = stage(0, (size_t)elems * esz);
+  int64_t* idx_d = (int64_t*)stage(1, (size_t)nq * k * 8);
+  float* sc_d = (float*)stage(2, (size_t)nq * k * 4);
+  auto done = [&](int code) { return code; };
+  if (!qd || !idx_d || !sc_d) return fail(MI_ERR_NOMEM, "staging buffers of mi_knn_search");
   if (hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice) != hipSuccess)
     return done(fail(MI_ERR_HIP, "H2D query copy failed"));
   rc = search_sync(g, qd, dtype, row_stride, col_stride, g->norm_mode, nq, k, idx_d, sc_d, nullptr);
