@@ -106,7 +106,7 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // Only the 4-byte keys live in LDS (cap * 4 + 1 KiB -> 3 workgroups per CU); the 8-byte entries stay in
 // registers between the read and the in-place compaction (all reads complete before the first write).
 constexpr int MAINT_THREADS = 512;
-constexpr int MAINT_PER_THREAD = 32;            // 512 * 32 = 16384 = largest survivor_cap
+constexpr int MAINT_PER_THREAD_MAX = 32;        // 512 * 32 = 16384 = largest survivor_cap
 
 // MODE 0 (after the bootstrap chunk).  spec_r > 0: SPECULATIVE threshold for the single remaining scoring launch =
 //   the spec_r-th largest sample score (>= K rows above it exist in the whole shard with probability 1 - 1e-6, see
@@ -117,7 +117,9 @@ constexpr int MAINT_PER_THREAD = 32;            // 512 * 32 = 16384 = largest su
 //   L - margin >= thr every candidate row is among them.  Otherwise the query is flagged for the repair pass
 //   (device-side, conditional launches, no host round trip); a query failing again raises FLAG_SPEC_FAIL.
 //   repair != 0: only flagged queries are processed.  cond: skip the launch when *cond == 0.
-template <int MODE>
+// PT = entries per thread kept in registers (PT * 512 >= survivor_cap): 24 instead of 32 at the default cap frees the
+// registers for a second workgroup per CU in MODE 1
+template <int MODE, int PT>
 __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QueryState st, int32_t k,
                                                                         float* __restrict__ topvals,
                                                                         float* __restrict__ l_local,
@@ -135,9 +137,9 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
   const uint32_t n = min(st.cnt[q * CNT_STRIDE], cap);
   if (MODE == 1 && st.cnt[q * CNT_STRIDE] > cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
   uint64_t* gsurv = st.surv + (uint64_t)q * cap;
-  uint64_t ent[MAINT_PER_THREAD];
+  uint64_t ent[PT];
 #pragma unroll
-  for (int j = 0; j < MAINT_PER_THREAD; ++j) {
+  for (int j = 0; j < PT; ++j) {
     const uint32_t i = threadIdx.x + j * MAINT_THREADS;
     ent[j] = (i < n) ? gsurv[i] : 0ull;
     if (i < n) keys[i] = f2key(entry_score(ent[j]));
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
   }
   float* tv = topvals + (uint64_t)q * k;
 #pragma unroll
-  for (int j = 0; j < MAINT_PER_THREAD; ++j) {
+  for (int j = 0; j < PT; ++j) {
     const uint32_t i = threadIdx.x + j * MAINT_THREADS;
     if (i < n && !failed && !(MODE == 0 && spec)) {
       const float sc = entry_score(ent[j]);
@@ -246,12 +248,20 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream) {
   const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;      // keys | hist[256] | sh[8]
-  if (mode == 0)
-    hipLaunchKernelGGL(select_maintain_kernel<0>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
-                       stats2, spec_r, spec, repair, cond);
-  else
-    hipLaunchKernelGGL(select_maintain_kernel<1>, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local,
-                       stats2, spec_r, spec, repair, cond);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local, stats2, spec_r, spec,
+                       repair, cond);
+  };
+  const uint32_t per_thread = (st.cap + MAINT_THREADS - 1) / MAINT_THREADS;
+  if (mode == 0) {
+    if (per_thread <= 16) go(select_maintain_kernel<0, 16>);
+    else if (per_thread <= 24) go(select_maintain_kernel<0, 24>);
+    else go(select_maintain_kernel<0, MAINT_PER_THREAD_MAX>);
+  } else {
+    if (per_thread <= 16) go(select_maintain_kernel<1, 16>);
+    else if (per_thread <= 24) go(select_maintain_kernel<1, 24>);
+    else go(select_maintain_kernel<1, MAINT_PER_THREAD_MAX>);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
