@@ -61,19 +61,50 @@ class ShardedGallery:
                 osc=torch.empty((nq, k), dtype=torch.float32, device=device))
         return self._buf[key]
 
-    def search(self, q, k, query_norm_none=False):
+    def search(self, q, k, query_norm_none=False, verify=False):
         """q: [Q, D] float32 cuda tensor (same on every rank), Q <= 1024.
         Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.
-        query_norm_none: use the queries as they are (expanded queries of alpha-QE)."""
-        import torch
-        nq = q.shape[0]
+        query_norm_none: use the queries as they are (expanded queries of alpha-QE).
+
+        The device entry points run asynchronously and report buffer overflows / a failed speculative threshold
+        through sticky flags (include/mi355_retrieval.h).  verify=True synchronises, reads the flags of EVERY shard
+        (all-reduce) and, if one is raised anywhere, answers the batch again on all shards with the fallbacks the
+        host entry point applies on its own: the rigorous chunk schedule, then the f32 scorer.  The result is exact
+        either way; a caller that batches many searches can instead call `any_flag()` once at the end."""
         if query_norm_none:
             self.g.set_option("query_norm_override", _lib.NORM_NONE)
         try:
-            return self._search(q, k)
+            out = self._search(q, k)
+            if verify and self.any_flag():
+                for name in ("speculative", "force_exact"):
+                    self.g.set_option(name, 0 if name == "speculative" else 1)
+                    try:
+                        out = self._search(q, k)
+                        bad = self.any_flag()
+                    finally:
+                        self.g.set_option(name, 1 if name == "speculative" else 0)
+                    if not bad:
+                        break
+                else:
+                    raise RuntimeError("sharded search: candidate buffers overflow even with the f32 scorer "
+                                       "(massive ties: use the dense path)")
+            return out
         finally:
             if query_norm_none:
                 self.g.set_option("query_norm_override", -1)
+
+    def any_flag(self):
+        """True on every rank iff any shard raised a sticky flag since the last call (synchronises; resets the
+        handle's statistics)."""
+        bad = 1 if self.g.status(reset=True)["overflow_batches"] > 0 else 0
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            t = torch.tensor([bad], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            bad = int(t.item())
+        return bad > 0
 
     def _search(self, q, k):
         import torch

@@ -182,6 +182,34 @@ def test_sharded_two_phase_protocol_equals_single_shard(nshards):
     assert np.array_equal(mi, ref_idx)
 
 
+def test_sharded_search_verify_falls_back_on_sticky_flags():
+    """The asynchronous device path reports a failed speculative threshold only through sticky flags;
+    ShardedGallery.search(verify=True) must notice and answer the batch again with the rigorous schedule.  90
+    near-duplicates of query 0 planted inside the bootstrap sample defeat both speculative thresholds."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    n, d, nq, k = 200000, 64, 6, 100
+    g = synth_rows(71, 0, n, d)
+    qh = synth_rows(72, 0, nq, d)
+    rows = np.random.default_rng(3).choice(_lib.sample_source_rows(n), size=90, replace=False)
+    for j, r in enumerate(rows):
+        g[r] = qh[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
+    G = _lib.Gallery.from_host(g)
+    sg = ShardedGallery(G)
+    q = torch.from_numpy(qh).to("cuda:0")
+    s = oracle.exact_scores_f64(g, qh)
+    idx, _ = sg.search(q, k)                       # unverified: the flag is raised, the answer may be incomplete
+    torch.cuda.synchronize()
+    assert sg.any_flag()
+    idx, sc = sg.search(q, k, verify=True)
+    torch.cuda.synchronize()
+    assert not sg.any_flag()
+    assert oracle.check_topk_parity(idx.cpu().numpy(), s, k, 1e-6) == []
+    assert set(rows) <= set(idx.cpu().numpy()[0])
+    G.close()
+
+
 def test_planted_dataset_map_end_to_end():
     """Search -> alpha-QE -> mAP on a planted dataset equals the CPU restatement's mAP."""
     from isehr_amd.nnsearch import matching_HIP
