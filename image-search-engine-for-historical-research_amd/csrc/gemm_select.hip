@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
           // inline asm for the same reason as the stores (a visible DS load of the scratch is ordered behind the
           // LDS-DMA transfers as well); the results become usable after the lgkmcnt(0) below, which every value passes
           asm volatile("ds_read_b96 %0, %2\n\tds_read_b32 %1, %3"
-                       : "=v"(mt[it]), "=v"(vv[it])
+                       : "=&v"(mt[it]), "=v"(vv[it])      // mt must not share a register with the second address
                        : "v"(sc_meta_lds + (valid ? (e >> 5) : 0u) * 16u), "v"(sc_val_lds + (valid ? e : 0u) * 4u)
                        : "memory");
         }
