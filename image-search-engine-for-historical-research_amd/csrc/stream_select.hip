@@ -141,18 +141,29 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
       float thr[NQB];
       bool any = false;
       if constexpr (FIRST) {
+        // bootstrap: every score is kept (one tile per workgroup, so this runs once, after the last slice).  The
+        // accumulator layout has 16 queries x 4 row quads per store instruction, i.e. 64 different 32-byte sectors of
+        // the [query][slot] survivor array; transposing through the (now idle) ring memory turns that into 512
+        // contiguous bytes per store instruction.
+        constexpr int TSTR = TILE + 4;                                   // floats per query row in LDS
+        float* T = reinterpret_cast<float*>(smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // trailing DMA pieces have landed ...
+        __builtin_amdgcn_s_barrier();                                    // ... for every wave: the rings are free
 #pragma unroll
-        for (int nb = 0; nb < NQB; ++nb) {
-          const uint32_t q = q0 + nb * 16 + l15;
-          if (q < (uint32_t)p.nq) {
-            uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
+        for (int nb = 0; nb < NQB; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+          for (int mb = 0; mb < 2; ++mb)
+            *reinterpret_cast<f32x4*>(T + (nb * 16 + l15) * TSTR + w * 32 + mb * 16 + lq * 4) = acc[mb][nb];
+        __syncthreads();
+        const uint32_t row0 = gt * TILE;
+        for (int qi = w * (NQB * 2); qi < (w + 1) * (NQB * 2); ++qi) {
+          const uint32_t q = q0 + qi;
+          if (q >= (uint32_t)p.nq) break;
+          uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap + row0;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const uint32_t row = row_base + mb * 16 + r;
-                if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
-              }
+          for (int it = 0; it < TILE / 64; ++it) {
+            const uint32_t rl = it * 64 + lane;
+            if (row0 + rl < (uint64_t)p.n) dst[rl] = pack_entry(T[qi * TSTR + rl], row0 + rl);
           }
         }
       }
