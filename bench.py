@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=131072)
-    ap.add_argument("--cpu-sample-queries", type=int, default=4)
+    ap.add_argument("--cpu-sample-queries", type=int, default=16)
     ap.add_argument("--option", action="append", default=[], help="name=value passed to mi_set_option")
     ap.add_argument("--image-dtype", default="f16", choices=["f16", "bf16"],
                     help="element type of the streamed 16-bit operand image (MFMA input type)")
@@ -71,8 +71,21 @@ def cpu_baseline(gallery, q_host, n_total, args):
         blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         blas_threads = None
+    # SURVEY.md 8d's second CPU baseline: the strongest fair exhaustive CPU path (multi-threaded sgemm + partial
+    # selection = what faiss-CPU IndexFlatIP does; faiss itself is not installable offline), at the BLAS width numpy
+    # has on this host, on the same row sample with more queries (a GEMM needs a batch to be fair to the CPU)
+    nqb = min(1024, q_host.shape[0])
+    gn = g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
+    qn = q_host[:nqb] / np.maximum(np.linalg.norm(q_host[:nqb], axis=1, keepdims=True), 1e-30)
+    oracle.knn_flat_ip_blas(gn[:4096], qn, args.topk)          # BLAS warm-up
+    t0 = time.time()
+    oracle.knn_flat_ip_blas(gn, qn, args.topk)
+    dtb = time.time() - t0
+    blas = {"value": nqb / dtb * ns / n_total, "unit": "queries/s", "cores": blas_threads,
+            "sample": "oracle.knn_flat_ip_blas (numpy sgemm + argpartition, f32) on the first %d gallery rows x %d "
+                      "queries, K=%d: %.2f s; scaled by rows" % (ns, nqb, args.topk, dtb)}
     return {
-        "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port",
+        "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port", "blas": blas,
         "sample": "oracle.matching_l2 (numpy, f32, single thread like the reference) on the first %d of %d gallery "
                   "rows x %d queries, K=%d: %.2f s; scaled by rows (cost is linear in N)" % (ns, n_total, nqs,
                                                                                             args.topk, dt),

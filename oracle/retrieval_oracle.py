@@ -9,7 +9,7 @@ import scipy.sparse.linalg as spla
 
 __all__ = [
     "matching_l2", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
-    "extract_ms_tail", "knn_flat_ip", "compute_ap2", "compute_map2", "compute_map_revisited",
+    "extract_ms_tail", "knn_flat_ip", "knn_flat_ip_blas", "compute_ap2", "compute_map2", "compute_map_revisited",
     "get_affinity", "get_laplacian", "diffusion_offline", "diffusion_online", "qge_small",
     "average_query_expansion", "database_augmentation", "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
 ]
@@ -109,6 +109,30 @@ def knn_flat_ip(database, queries, k):
     s = q @ db.T
     order = np.argsort(-s, axis=1, kind="stable")[:, :k]
     return np.take_along_axis(s, order, axis=1), order.astype(np.int64)
+
+
+def knn_flat_ip_blas(database, queries, k):
+    """Same contract as knn_flat_ip (a6, src/utils/knn.py:8-40; also the scoring of src/main_retrieve.py:175-176) the
+    way a tuned CPU library does it: one multi-threaded sgemm, then a partial selection (argpartition) and a sort of
+    only k scores per query.  This is SURVEY.md 8d's "strongest fair CPU exhaustive baseline" and the stand-in for
+    faiss-CPU IndexFlatIP, which is not installable offline.  Ties at the k-th score go to the lower index."""
+    db = np.ascontiguousarray(database, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    s = q @ db.T
+    n = s.shape[1]
+    ids = np.empty((s.shape[0], k), dtype=np.int64)
+    for i in range(s.shape[0]):
+        row = s[i]
+        if k < n:
+            vk = -np.partition(-row, k - 1)[k - 1]                 # the k-th largest score
+            above = np.flatnonzero(row > vk)
+            ties = np.flatnonzero(row == vk)[: k - above.size]     # lowest indices first
+            cand = np.concatenate([above, ties])
+        else:
+            cand = np.arange(n)
+        order = np.lexsort((cand, -row[cand]))                     # score desc, index asc
+        ids[i] = cand[order][:k]
+    return np.take_along_axis(s, ids, axis=1), ids
 
 
 # --------------------------------------------------------------------------- a9

@@ -125,3 +125,17 @@ def test_aqe_and_dba(golden_dir):
     qv, vecs = _aqe_dba_inputs()
     assert np.array_equal(oracle.average_query_expansion(qv, vecs, 50), z["ranks_aqe"])
     assert np.array_equal(oracle.database_augmentation(qv, vecs, 50), z["ranks_dba"])
+
+
+def test_blas_style_flat_ip_equals_the_plain_restatement():
+    """knn_flat_ip_blas (sgemm + partial selection: the CPU baseline bench.py times at full BLAS width) returns
+    exactly what knn_flat_ip (full stable argsort) returns, ties at the k-th score included."""
+    rng = np.random.default_rng(5)
+    db = rng.standard_normal((3000, 48)).astype(np.float32)
+    db[100] = db[7]
+    db[2000] = db[7]                                  # exact ties
+    q = np.vstack([db[7:8] * 2.0, rng.standard_normal((9, 48)).astype(np.float32)])
+    for k in (1, 2, 3, 50, 3000):
+        s0, i0 = oracle.knn_flat_ip(db, q, k)
+        s1, i1 = oracle.knn_flat_ip_blas(db, q, k)
+        assert np.array_equal(i0, i1) and np.array_equal(s0, s1)
