@@ -122,20 +122,37 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   // ---- DMA prefetch state.  Group 0 owns the A stream (lead 4 slices), group 1 the B stream (lead 3 slices).
   // A wave copies 4 KiB (4 pieces) of its operand's 16 KiB slice block.
   uint32_t pf_i = 0, pf_sl = 0;
-  const char* pf;
+  // The source address is kept as a wave-uniform base (scalar registers) plus a constant per-lane byte offset, so that
+  // the DMA instruction takes the saddr + 32-bit voffset form and advancing the stream costs scalar adds only: 64-bit
+  // vector adds in the load segment would compete with the partner wave's MFMAs for the SIMD's vector issue.
+  const char* pf;                                          // uniform
+  const uint32_t pf_lane = (uint32_t)lane * 16u;
   auto pf_set = [&](uint32_t i) {
     uint32_t gt, qt;
     tile_of(i < my_tiles ? i : my_tiles - 1, gt, qt);     // past the end: harmless re-load of the last tile
     pf = (grp == 0 ? (const char*)p.gal_img + (int64_t)gt * KSL * SLICE_BYTES
-                   : (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES) + (w & 3) * 4096 + lane * 16;
+                   : (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES) + (w & 3) * 4096;
   };
   pf_set(0);
   constexpr bool dbg_nodma = DBG & 1, dbg_nomfma = DBG & 2;
   const uint32_t ring_base = (grp == 0 ? A_RING : B_RING) + (w & 3) * 4096;
   uint32_t wr_slot = 0;                                   // ring slot the next issued slice goes to
   const uint32_t my_slots = grp == 0 ? A_SLOTS : B_SLOTS;
+  uint32_t off = 0;
   auto issue_piece = [&](int piece) {
-    if (!dbg_nodma) glds16(pf + piece * 1024, smem + ring_base + wr_slot * SLICE_BYTES + piece * 1024);
+    // the zero extension of the lane offset has to be visible in this basic block for the saddr form to be selected;
+    // the piece is the instruction's immediate offset, which the hardware adds to the global AND the LDS address, so
+    // the four pieces of a slice share one scalar base, one offset register and one M0 value
+    if (!dbg_nodma) {
+      const GLOBAL_AS void* src = (const GLOBAL_AS void*)(pf + off);
+      LDS_AS void* dst = (LDS_AS void*)(smem + ring_base + wr_slot * SLICE_BYTES);
+      switch (piece) {
+        case 0: __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0); break;
+      }
+    }
   };
   auto issue_advance = [&]() {
     pf += SLICE_BYTES;
@@ -146,6 +163,8 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     if (++wr_slot == my_slots) wr_slot = 0;
   };
   auto issue = [&]() {
+    off = pf_lane;
+    asm volatile("" : "+v"(off));
     issue_piece(0);
     issue_piece(1);
     issue_piece(2);
