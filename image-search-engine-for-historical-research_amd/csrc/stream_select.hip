@@ -66,20 +66,25 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   // ---- DMA stream: slice s of my i-th tile, continuous over tile boundaries
   const bool qloader = w < NQB;
   uint32_t pf_i = 0, pf_sl = 0, wr_slot = 0;
+  // wave-uniform bases (scalar registers) + one per-lane byte offset: the DMA instructions take the saddr form and
+  // the second gallery piece is the instruction's immediate offset (added to the global and the LDS address)
   const char* pfa;
   const char* pfq = reinterpret_cast<const char*>(p.qry_img) + (int64_t)(q0 / TILE) * KSL * SLICE_BYTES +
-                    (q0 % TILE) * 64 + w * 1024 + lane * 16;
+                    (q0 % TILE) * 64 + w * 1024;
+  const uint32_t pf_lane = (uint32_t)lane * 16u;
   auto pf_set = [&](uint32_t i) {
     const uint32_t gt = (uint32_t)p.tile0 + b + (i < my_tiles ? i : my_tiles - 1) * nwg;   // past the end: reload
-    pfa = reinterpret_cast<const char*>(p.gal_img) + (int64_t)gt * KSL * SLICE_BYTES + w * 2048 + lane * 16;
+    pfa = reinterpret_cast<const char*>(p.gal_img) + (int64_t)gt * KSL * SLICE_BYTES + w * 2048;
   };
   pf_set(0);
   auto issue = [&]() {
-    char* dst = smem + wr_slot * SLICE_BYTES + w * 2048;
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)pfa, (LDS_AS void*)dst, 16, 0, GAL_AUX);
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfa + 1024), (LDS_AS void*)(dst + 1024), 16, 0, GAL_AUX);
+    uint32_t off = pf_lane;
+    asm volatile("" : "+v"(off));          // keeps the zero extension in this block (saddr form selection)
+    LDS_AS void* dst = (LDS_AS void*)(smem + wr_slot * SLICE_BYTES + w * 2048);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfa + off), dst, 16, 0, GAL_AUX);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfa + off), dst, 16, 1024, GAL_AUX);
     if (qloader)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfq + (int64_t)pf_sl * SLICE_BYTES),
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pfq + (int64_t)pf_sl * SLICE_BYTES + off),
                                        (LDS_AS void*)(smem + B_RING0 + wr_slot * BQ_BYTES + w * 1024), 16, 0, 0);
     pfa += SLICE_BYTES;
     if (++pf_sl == KSL) {
