@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
       tile_epilogue(ep_gt, ep_qt);
       ep_pending = false;
     }
-    __builtin_amdgcn_s_setprio(1);
+    // no s_setprio around the MFMAs: measured 1.4 % faster without (A/B on one box, 1338 vs 1318 TF)
     if (!dbg_nomfma) {
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb)
@@ -399,7 +399,6 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(bfr[nb]));
     }
-    __builtin_amdgcn_s_setprio(0);
     // group 0 (A loader): A(S+1) landed, A(S+2..S+4) may be in flight
     if (grp == 0) vm_wait<(A_SLOTS - 2) * 4>();
     __builtin_amdgcn_sched_barrier(0);
