@@ -304,8 +304,9 @@ void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_
 // exact re-score: s = sum_k g[k] * q[k] with f32 inputs, exact f64 products and f64 accumulation
 // (HBM-bound gather of 4*dp bytes per candidate row).  One wave per row, two rows per wave pass.
 
+constexpr int RESCORE_MAX_THREADS = 256;
 template <int UNROLL, int ROWS_PER_WG>
-__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
+__global__ __launch_bounds__(RESCORE_MAX_THREADS) void rescore_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
                                                       int32_t dp, const uint32_t* __restrict__ cand_rows,
                                                       const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
                                                       double* __restrict__ cand_score) {
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
   // rcap would consist almost entirely of workgroups that exit at once)
   for (uint32_t c0 = blockIdx.x * ROWS_PER_WG; c0 < nc; c0 += gridDim.x * ROWS_PER_WG) {
   const uint32_t cend = min(nc, c0 + ROWS_PER_WG);
-  for (uint32_t c = c0 + w * 2; c < cend; c += 8) {
+  for (uint32_t c = c0 + w * 2; c < cend; c += 2 * (blockDim.x >> 6)) {
     const bool two = (c + 1 < cend);
     const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
     const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
@@ -367,16 +368,18 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
   }
 }
 
-// 8 rows per workgroup: every wave makes exactly one 2-row pass.  Measured on 1024 x ~358 candidate rows of 8 KiB:
-// 590 us (5.1 TB/s) vs 977 us with 32 rows per workgroup; the unroll factor of the column loop does not matter.
-constexpr int RESCORE_ROWS_PER_WG = 8;
-constexpr uint32_t RESCORE_GRID_X = 32;     // 256 candidates per query and sweep
+// One wave per workgroup, one 2-row pass per sweep: the finest granularity balances best.  Measured on 1024 x ~127
+// candidate rows of 8 KiB (same box): 201 us with 2 rows / 64 threads, 207 us with 4 rows / 128 or 256 threads,
+// 266 us with 8 rows / 256 threads, 447 us with 16 rows; the unroll factor of the column loop does not matter.
+constexpr int RESCORE_ROWS_PER_WG = 2;
+constexpr int RESCORE_THREADS = 64;
+constexpr uint32_t RESCORE_GRID_X = 64;     // 128 candidates per query and sweep
 
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                     const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
   hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>),
                      dim3(std::min<uint32_t>(RESCORE_GRID_X, (rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG), nq),
-                     dim3(256), 0, stream, gal_f32,
+                     dim3(RESCORE_THREADS), 0, stream, gal_f32,
                      qry_f32, dp, cand_rows, cand_cnt, rcap, cand_score);
 }
 
