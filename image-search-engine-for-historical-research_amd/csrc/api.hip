@@ -297,7 +297,8 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   };
   if (samp_r > 0) {
     score_launch(0, t0, true, nullptr, false, true);                           // bootstrap on the sample image
-    launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
+    if (sample_threshold_applies(first_cnt, k, samp_r)) launch_sample_threshold(st, nq, k, samp_r, s);
+    else launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
     score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 0, nullptr, s);
     // repair pass for queries whose speculative threshold failed verification: conditional on the device word

@@ -63,6 +63,9 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
                              int use_img_terms, uint32_t first_cnt, QueryState st, hipStream_t stream);
 // mode 0: maintain (threshold <- K-th largest - margin, compact survivors)
 // mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
+// thresholds from the 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
+bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
+void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream);
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream);

@@ -265,6 +265,87 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Thresholds from the bootstrap sample (single-launch schedule): only the r-th and the (4r)-th largest of the n_s sample
+// scores are needed (r < K; see api.hip), i.e. the top few dozen of 8192 values -- a full radix select over all keys
+// (select_maintain_kernel<0>) spends most of its time funnelling LDS atomics into the 2-4 bins that share the scores'
+// sign and exponent.  Here every thread keeps its 16 scores in registers and contributes its maximum; the W-th largest
+// of the 512 maxima (W = 4r) is a lower bound of the W-th largest overall, so the values >= it (W plus a few) are
+// gathered and ranked exactly by counting.  Falls back to the plain select if more than 256 values qualify (ties).
+// The sample entries are dropped afterwards (cnt = 0), like select_maintain_kernel<0> with spec != 0.
+constexpr int SAMP_THREADS = 512, SAMP_PER_THREAD = 16;    // 8192 sample scores
+__global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r) {
+  __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (32 KiB)
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[8];
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = min(st.cnt[q * CNT_STRIDE], (uint32_t)(SAMP_THREADS * SAMP_PER_THREAD));
+  const uint64_t* gsurv = st.surv + (uint64_t)q * st.cap;
+  uint32_t kv[SAMP_PER_THREAD];
+  uint32_t kmax = 0;
+#pragma unroll
+  for (int j = 0; j < SAMP_PER_THREAD; ++j) {
+    const uint32_t i = threadIdx.x + j * SAMP_THREADS;
+    kv[j] = (i < n) ? f2key(entry_score(gsurv[i])) : 0u;
+    kmax = max(kmax, kv[j]);
+  }
+  const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);   // wanted ranks, w1 <= w2 <= 256
+  uint32_t* maxima = keys;                                  // 512 keys
+  maxima[threadIdx.x] = kmax;
+  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; }
+  __syncthreads();
+  const uint32_t t0 = block_kth_largest(maxima, SAMP_THREADS, w2, hist, sh);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SAMP_PER_THREAD; ++j)
+    if (kv[j] >= t0 && kv[j] != 0u) {
+      const uint32_t pos = atomicAdd(&sh[3], 1u);
+      if (pos < 256) hist[pos] = kv[j];
+    }
+  __syncthreads();
+  const uint32_t m = sh[3];
+  uint32_t key1, key2;
+  if (m <= 256) {
+    if (threadIdx.x < m) {
+      const uint32_t me = hist[threadIdx.x];
+      uint32_t gt = 0, ge = 0;
+      for (uint32_t j = 0; j < m; ++j) { gt += hist[j] > me; ge += hist[j] >= me; }
+      if (gt < w1 && w1 <= ge) sh[4] = me;
+      if (gt < w2 && w2 <= ge) sh[5] = me;
+    }
+    __syncthreads();
+    key1 = sh[4];
+    key2 = sh[5];
+  } else {                                                  // a crowd of ties: plain selects over all keys
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SAMP_PER_THREAD; ++j) keys[threadIdx.x + j * SAMP_THREADS] = kv[j];
+    __syncthreads();
+    key1 = block_kth_largest(keys, n, w1, hist, sh);
+    key2 = block_kth_largest(keys, n, w2, hist, sh);
+  }
+  if (threadIdx.x == 0) {
+    const float margin = st.margin[q];
+    // same values as select_maintain_kernel<0>: thr = max(L - margin, r-th) = r-th (r < K);
+    // thr2 = (4r)-th if 4r < K, else the rigorous L - margin with L = K-th largest
+    float thr = key2f(key1), thr2 = key2f(key2);
+    if (4 * spec_r >= k) thr2 = thr2 - margin;
+    if (st.thr[q] == INFINITY) { thr = INFINITY; thr2 = INFINITY; }   // query excluded at init (range overflow)
+    st.thr[q] = thr;
+    st.thr2[q] = thr2;
+    st.cnt[q * CNT_STRIDE] = 0;
+  }
+}
+
+bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
+  return first_cnt == (uint32_t)(SAMP_THREADS * SAMP_PER_THREAD) && spec_r >= 1 && spec_r < k && 4 * spec_r <= 256 &&
+         (int64_t)first_cnt >= k;
+}
+
+void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream) {
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r);
+}
+
+// ------------------------------------------------------------------------------------------------
 // candidates: every surviving row whose approximate score is >= L - margin may belong to the exact
 // top-K (DESIGN.md "Exactness certificate"); rows below cannot.
 __global__ __launch_bounds__(256) void select_candidates_kernel(QueryState st, const float* __restrict__ L,
