@@ -196,6 +196,23 @@ static void prof_collect(mi_gallery* g) {
   g->ev_used = 0;
 }
 
+// Rank of the sample score the speculative threshold is taken from.  The number of the shard's K best rows that fall
+// into a uniform sample of n_s of its N rows is Binomial(K, n_s / N) ~ Poisson(lambda = K n_s / N); the r-th largest
+// sample score exceeds the shard's K-th best (and the threshold fails its verification) iff that number is >= r.
+// r = the smallest rank whose tail probability is <= 1e-7 per query (1e-4 per 1024-query batch: a failed query costs
+// a repair pass, never a wrong answer).  The kernels take `score(r) - margin` as the threshold, so the certificate's
+// band below the K-th score is covered whatever the image type.
+static int32_t spec_rank(double lambda) {
+  double pmf = std::exp(-lambda), cdf = pmf;
+  int32_t r = 1;
+  while (1.0 - cdf > 1e-7 && r < (1 << 20)) {
+    pmf *= lambda / r;
+    cdf += pmf;
+    ++r;
+  }
+  return r;
+}
+
 // (re)build the bootstrap sample image for the current number of rows
 static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
   if (g->samp_img && g->samp_tiles == tiles && g->samp_for_n == g->n) return MI_OK;
@@ -226,13 +243,13 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   // Single-launch schedule?  The speculative threshold is an order statistic of the scores of a SAMPLE: t0 * 256
   // rows drawn evenly (one hashed draw per stratum) into their own small image, so that the order in which the shard
   // was ingested cannot bias it.  With n_s sampled rows the shard's K-th largest score sits near sample rank
-  // lambda = K * n_s / N; the r-th largest sample score with r = lambda + 5 sqrt(lambda) + 6 lies below it except with
-  // probability ~1e-6 per query (Poisson tail) and keeps the expected survivors at r * N / n_s.  The sample entries
+  // lambda = K * n_s / N; the r-th largest sample score with r = spec_rank(lambda) lies below it except with
+  // probability 1e-7 per query (Poisson tail) and keeps the expected survivors at r * N / n_s.  The sample entries
   // are dropped once the threshold is taken (the scoring launch visits every tile, sample rows included).
   int32_t samp_r = 0;
   if (g->speculative && !exact && ntiles >= 2 * t0 && g->n / (t0 * TILE) <= 160) {
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
-    const int32_t r = (int32_t)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 6.0);
+    const int32_t r = spec_rank(lambda);
     if (r < k) samp_r = r;
   }
   if (samp_r > 0) {
@@ -330,7 +347,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       const int64_t n_seen = std::min<int64_t>(g->n, t * TILE);
       if (g->speculative && !exact && g->n / n_seen <= 160) {
         const double lambda = (double)k * (double)n_seen / (double)g->n;
-        const int32_t r = (int32_t)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 6.0);
+        const int32_t r = spec_rank(lambda);
         if (r < k) spec_r = r;
       }
       spec_next = spec_r > 0;

@@ -179,11 +179,12 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
           if (want[t] < (uint32_t)k && gt < want[t] && want[t] <= ge) sh[4 + t] = me;
       }
       __syncthreads();
-      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(sh[4]));
-      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(sh[5]));
+      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(sh[4]) - st.margin[q]);
+      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(sh[5]) - st.margin[q]);
     } else {                                        // a crowd of ties at the K-th score: plain selects
-      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest(keys, n, (uint32_t)spec_r, hist, sh)));
-      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(block_kth_largest(keys, n, (uint32_t)(4 * spec_r), hist, sh)));
+      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest(keys, n, (uint32_t)spec_r, hist, sh)) - st.margin[q]);
+      if (4 * spec_r < k)
+        thr2 = fmaxf(thr2, key2f(block_kth_largest(keys, n, (uint32_t)(4 * spec_r), hist, sh)) - st.margin[q]);
     }
     if (threadIdx.x == 0) sh[3] = 0;
     __syncthreads();
@@ -325,13 +326,12 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
   }
   if (threadIdx.x == 0) {
     const float margin = st.margin[q];
-    // same values as select_maintain_kernel<0>: thr = max(L - margin, r-th) = r-th (r < K);
-    // thr2 = (4r)-th if 4r < K, else the rigorous L - margin with L = K-th largest
-    float thr = key2f(key1), thr2 = key2f(key2);
-    if (4 * spec_r >= k) thr2 = thr2 - margin;
-    if (st.thr[q] == INFINITY) { thr = INFINITY; thr2 = INFINITY; }   // query excluded at init (range overflow)
-    st.thr[q] = thr;
-    st.thr2[q] = thr2;
+    // thr = score(r) - margin (>= the rigorous L_sample - margin since r < K); thr2 = score(min(4r, K)) - margin
+    // minus the margin: the verification asks for L - margin >= thr, and L >= score(r) is what the rank guarantees
+    const float thr = key2f(key1) - margin, thr2 = key2f(key2) - margin;
+    const bool excluded = st.thr[q] == INFINITY;                       // query excluded at init (range overflow)
+    st.thr[q] = excluded ? INFINITY : thr;
+    st.thr2[q] = excluded ? INFINITY : thr2;
     st.cnt[q * CNT_STRIDE] = 0;
   }
 }
