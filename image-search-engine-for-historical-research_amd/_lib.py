@@ -59,6 +59,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "mi_topk_merge_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "mi_topk_merge_strided_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_aqe_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                         C.c_double, C.c_void_p, C.c_void_p]),
     "mi_aqe_finish_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
@@ -353,6 +355,11 @@ class Gallery:
 def kth_of_gathered_device(gathered_ptr, nshards, nq, k, out_ptr, stream=None):
     check(load().mi_kth_of_gathered_device(C.c_void_p(gathered_ptr), nshards, nq, k, C.c_void_p(out_ptr),
                                            C.c_void_p(stream)))
+
+
+def topk_merge_strided_device(score64_ptr, idx_ptr, shard_stride, nshards, nq, k, out_idx_ptr, out_score_ptr, stream=None):
+    check(load().mi_topk_merge_strided_device(C.c_void_p(score64_ptr), C.c_void_p(idx_ptr), shard_stride, nshards, nq, k,
+                                              C.c_void_p(out_idx_ptr), C.c_void_p(out_score_ptr), C.c_void_p(stream)))
 
 
 def topk_merge_device(score64_ptr, idx_ptr, nshards, nq, k, out_idx_ptr, out_score_ptr, stream=None):

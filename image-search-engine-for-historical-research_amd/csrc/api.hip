@@ -850,7 +850,17 @@ int mi_topk_merge_device(const double* score64_dev, const int64_t* idx_dev, int3
                          int64_t* out_idx_dev, float* out_score_dev, void* stream) {
   REQUIRE(score64_dev && idx_dev && out_idx_dev, "null pointer");
   REQUIRE(nshards >= 1 && (int64_t)nshards * k <= 8192, "nshards * k too large");
-  launch_merge(score64_dev, idx_dev, nshards, nq, k, out_idx_dev, out_score_dev, (hipStream_t)stream);
+  launch_merge(score64_dev, idx_dev, nshards, nq, k, nq * (int64_t)k, out_idx_dev, out_score_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_topk_merge_strided_device(const double* score64_dev, const int64_t* idx_dev, int64_t shard_stride, int32_t nshards,
+                                 int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, void* stream) {
+  REQUIRE(score64_dev && idx_dev && out_idx_dev, "null pointer");
+  REQUIRE(nshards >= 1 && (int64_t)nshards * k <= 8192, "nshards * k too large");
+  REQUIRE(shard_stride >= nq * (int64_t)k, "shard_stride smaller than one shard's list");
+  launch_merge(score64_dev, idx_dev, nshards, nq, k, shard_stride, out_idx_dev, out_score_dev, (hipStream_t)stream);
   HIPC(hipGetLastError());
   return MI_OK;
 }

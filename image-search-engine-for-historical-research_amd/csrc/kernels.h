@@ -78,7 +78,7 @@ void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const doub
                  double* out_score64, hipStream_t stream);
 void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, int32_t k, float* out_L,
                             hipStream_t stream);
-void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k,
+void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k, int64_t shard_stride,
                   int64_t* out_idx, float* out_score, hipStream_t stream);
 
 // dense.hip -- exact top-k of dense score rows (global-memory radix select + LDS bitonic sort), k <= 4096

@@ -561,7 +561,7 @@ void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, 
 // ------------------------------------------------------------------------------------------------
 // merge of the shards' exact top-K lists by (score64 desc, idx asc); padded entries carry idx -1 / -inf.
 __global__ __launch_bounds__(256) void merge_kernel(const double* __restrict__ score64, const int64_t* __restrict__ idx,
-                                                    int32_t nshards, int64_t nq, int32_t k,
+                                                    int32_t nshards, int64_t nq, int32_t k, int64_t shard_stride,
                                                     int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t q = blockIdx.x;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const double* __restrict__ s
   for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
     if (i < n) {
       const uint32_t sh = i / k, e = i % k;
-      const uint64_t src = ((uint64_t)sh * nq + q) * k + e;
+      const uint64_t src = (uint64_t)sh * shard_stride + (uint64_t)q * k + e;
       const int64_t v = idx[src];
       s[i] = (v < 0) ? -INFINITY : score64[src];
       id[i] = (unsigned long long)v;          // -1 -> max, sorts last among equals
@@ -589,8 +589,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const double* __restrict__ s
   }
 }
 
-void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k, int64_t* out_idx,
-                  float* out_score, hipStream_t stream) {
+void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k, int64_t shard_stride,
+                  int64_t* out_idx, float* out_score, hipStream_t stream) {
   uint32_t n2 = 2;
   while (n2 < (uint32_t)nshards * (uint32_t)k) n2 <<= 1;
   static bool attr_done = false;
@@ -599,7 +599,7 @@ void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, in
     attr_done = true;
   }
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), (size_t)n2 * 16, stream, score64, idx, nshards, nq,
-                     k, out_idx, out_score);
+                     k, shard_stride, out_idx, out_score);
 }
 
 }  // namespace mi

@@ -8,7 +8,7 @@ phases with two small all-gathers, so that the exact re-scoring work is split ac
   gather 1 all-gather [G][Q][K] f32 (K*4 B per query per rank; 400 KiB at Q=1024, K=100)
            L[q] = K-th largest of the union = K-th largest approximate score of the whole gallery
   phase 2  exact f64 re-score of local rows within the error margin of L -> local exact top-K
-  gather 2 all-gather [G][Q][K] (f64 score, i64 idx)  (1.6 MiB per rank at Q=1024, K=100)
+  gather 2 ONE all-gather of the packed [G][2][Q][K] (f64 score, i64 idx) lists (1.6 MiB per rank at Q=1024, K=100)
   merge    (score desc, idx asc) -> identical to the single-GPU result, bit for bit
 
 Both collectives are latency-bound on xGMI; they run on the caller's stream order (no host sync).
@@ -54,9 +54,10 @@ class ShardedGallery:
             self._buf[key] = dict(
                 approx=torch.empty((nq, k), dtype=torch.float32, device=device),
                 L=torch.empty((nq,), dtype=torch.float32, device=device),
-                idx=torch.empty((nq, k), dtype=torch.int64, device=device),
                 sc=torch.empty((nq, k), dtype=torch.float32, device=device),
-                sc64=torch.empty((nq, k), dtype=torch.float64, device=device),
+                # exact scores (f64, bit pattern kept in int64) and global indices of phase 2, packed so that ONE
+                # all-gather moves both
+                pack=torch.empty((2, nq, k), dtype=torch.int64, device=device),
                 oidx=torch.empty((nq, k), dtype=torch.int64, device=device),
                 osc=torch.empty((nq, k), dtype=torch.float32, device=device))
         return self._buf[key]
@@ -117,12 +118,12 @@ class ShardedGallery:
         self.g.phase1_device(q.data_ptr(), nq, k, b["approx"].data_ptr(), stream)
         gathered = all_gather_stacked(b["approx"], self.group)
         _lib.kth_of_gathered_device(gathered.data_ptr(), self.world, nq, k, b["L"].data_ptr(), stream)
-        self.g.phase2_device(nq, k, b["L"].data_ptr(), b["idx"].data_ptr(), b["sc"].data_ptr(),
-                             b["sc64"].data_ptr(), stream)
-        g_sc = all_gather_stacked(b["sc64"], self.group)
-        g_idx = all_gather_stacked(b["idx"], self.group)
-        _lib.topk_merge_device(g_sc.data_ptr(), g_idx.data_ptr(), self.world, nq, k, b["oidx"].data_ptr(),
-                               b["osc"].data_ptr(), stream)
+        pack = b["pack"]
+        self.g.phase2_device(nq, k, b["L"].data_ptr(), pack[1].data_ptr(), b["sc"].data_ptr(), pack[0].data_ptr(),
+                             stream)
+        gathered2 = all_gather_stacked(pack, self.group)                 # [world, 2, nq, k]
+        _lib.topk_merge_strided_device(gathered2[0, 0].data_ptr(), gathered2[0, 1].data_ptr(), 2 * nq * k, self.world,
+                                       nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), stream)
         return b["oidx"], b["osc"]
 
     def aqe_search(self, ranks, k_qe, w, k, eps=1e-6):

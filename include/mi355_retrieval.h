@@ -110,6 +110,12 @@ int mi_knn_phase2_device(mi_gallery* g, int64_t nq, int32_t k, const float* L_de
 int mi_topk_merge_device(const double* score64_dev, const int64_t* idx_dev, int32_t nshards,
                          int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev,
                          void* stream);
+/* Same merge for lists that arrive interleaved per shard: shard g's scores start at score64_dev + g * shard_stride and its
+ * indices at idx_dev + g * shard_stride (elements of 8 bytes), e.g. one all-gather of a packed [2][nq][k] buffer per rank
+ * (scores, then indices) instead of two collectives. */
+int mi_topk_merge_strided_device(const double* score64_dev, const int64_t* idx_dev, int64_t shard_stride,
+                                 int32_t nshards, int64_t nq, int32_t k, int64_t* out_idx_dev,
+                                 float* out_score_dev, void* stream);
 
 /* ---- alpha query expansion: replaces feature_enhancement (src/utils/Reranking.py:195-208, copy at
  * :288-301): q' = sum_j ((k-j)/k)^w * G[ranks[j,q]], q' /= (||q'|| + eps), then a full re-search.

@@ -177,6 +177,14 @@ def test_sharded_two_phase_protocol_equals_single_shard(nshards):
         sh.close()
     assert np.array_equal(oi.cpu().numpy(), ref_idx)
     assert np.array_equal(os_.cpu().numpy(), ref_sc)
+    # the packed form the RCCL path gathers with ONE collective: [G][2][nq][k] (scores as bit patterns, then indices)
+    packed = torch.stack([sc64.view(torch.int64), idx], dim=1).contiguous()
+    oi2 = torch.empty_like(oi)
+    os2 = torch.empty_like(os_)
+    _lib.topk_merge_strided_device(packed[0, 0].data_ptr(), packed[0, 1].data_ptr(), 2 * nq * k, nshards, nq, k,
+                                   oi2.data_ptr(), os2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(oi2, oi) and torch.equal(os2, os_)
     # the merge kernel against the oracle's merge
     ms, mi = oracle.merge_topk([s for s in sc64.cpu().numpy()], [i for i in idx.cpu().numpy()], k)
     assert np.array_equal(mi, ref_idx)
