@@ -25,7 +25,8 @@ c_f64p = C.POINTER(C.c_double)
 class SearchStats(C.Structure):
     _fields_ = [("searches", C.c_int64), ("queries", C.c_int64), ("overflow_batches", C.c_int64),
                 ("survivors", C.c_int64), ("candidates", C.c_int64), ("gemm_ms", C.c_double),
-                ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double)]
+                ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
+                ("kernel_clock_mhz", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -84,6 +85,10 @@ SIGNATURES = {
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mi_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "mi_search_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "mi_gallery_norm_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "mi_gallery_set_image_dtype": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_debug_read_cycles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi_debug_sample_source_row": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "mi_set_global_option": (C.c_int, [C.c_char_p, C.c_double]),
@@ -337,6 +342,27 @@ class Gallery:
     # ---- instrumentation
     def set_option(self, name, value):
         check(load().mi_set_option(self._h, name.encode(), float(value)))
+
+    def norm_bounds(self, raise_to=None):
+        """{max ||g||, max ||g_hat||, max ||g_hat - g||} of this shard; raise_to: three floats -> the bounds become
+        max(own, given) (agreement across the shards of one gallery, include/mi355_retrieval.h)."""
+        b = (C.c_float * 3)(*(raise_to if raise_to is not None else (0.0, 0.0, 0.0)))
+        check(load().mi_gallery_norm_bounds(self._h, b, 1 if raise_to is not None else 0))
+        return [float(b[0]), float(b[1]), float(b[2])]
+
+    def set_image_dtype(self, f16):
+        check(load().mi_gallery_set_image_dtype(self._h, 1 if f16 else 0))
+
+    def get_option(self, name):
+        v = C.c_double(0.0)
+        check(load().mi_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def flags(self):
+        """Synchronises and returns (then clears) the sticky device flags of the asynchronous entry points."""
+        f = C.c_uint32(0)
+        check(load().mi_search_flags(self._h, C.byref(f)))
+        return f.value
 
     def profile(self, on=True):
         check(load().mi_profile_enable(self._h, 1 if on else 0))

@@ -2,6 +2,7 @@
 // scoring schedule and the two-phase exact top-K protocol.  No torch, no numpy: plain pointers.
 #include "../../include/mi355_retrieval.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -78,6 +79,7 @@ struct mi_gallery {
   // options
   int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0, speculative = 1;
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
+  int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -152,6 +154,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 32));
+  HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
   return MI_OK;
 }
 
@@ -294,6 +297,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.nq = nq;
     a.debug = g->debug;
     a.small_batch_kernel = g->small_batch_kernel;
+    a.variant = g->kernel_variant;
     a.rec = ws.rec;
     a.rec_cnt = ws.rec_cnt;
     a.rec_cap = ws.rec_cap;
@@ -1286,12 +1290,98 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
     uint32_t flags = 0;
     HIPC(hipMemcpy(&flags, g->ws.flags, 4, hipMemcpyDeviceToHost));
     if (flags) {
-      g->stats.overflow_batches += 1;   // sticky: a device-API batch overflowed since the last status call
-      if (reset) HIPC(hipMemset(g->ws.flags, 0, 4));
+      // sticky device flag: a device-API batch overflowed since the last status call.  Counted once and cleared, so
+      // that polling without reset does not count the same event again.
+      g->stats.overflow_batches += 1;
+      HIPC(hipMemset(g->ws.flags, 0, 4));
+    }
+    // in-kernel clock of the last tile-kernel launch: median over its waves of cycles / (10 ns ticks) x 100 MHz
+    std::vector<unsigned long long> c((size_t)g->ws.nseg * 8);
+    HIPC(hipMemcpy(c.data(), g->ws.dbg, c.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (size_t w = 0; w < g->ws.nseg; ++w)
+      if (c[w * 8 + 7] > 0 && c[w * 8 + 6] > 0) mhz.push_back((double)c[w * 8 + 6] / (double)c[w * 8 + 7] * 100.0);
+    if (!mhz.empty()) {
+      std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
+      g->stats.kernel_clock_mhz = mhz[mhz.size() / 2];
     }
   }
   if (out) *out = g->stats;
   if (reset) g->stats = mi_search_stats{};
+  return MI_OK;
+}
+
+int mi_gallery_norm_bounds(mi_gallery* g, float* bounds3, int raise) {
+  REQUIRE(g && bounds3, "null");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipStreamSynchronize(g->stream));
+  float own[3] = {0, 0, 0};
+  HIPC(hipMemcpy(own, g->gstat3, 12, hipMemcpyDeviceToHost));
+  if (raise) {
+    for (int i = 0; i < 3; ++i) {
+      REQUIRE(bounds3[i] == bounds3[i], "NaN bound");
+      own[i] = std::max(own[i], bounds3[i]);
+    }
+    HIPC(hipMemcpy(g->gstat3, own, 12, hipMemcpyHostToDevice));
+  }
+  for (int i = 0; i < 3; ++i) bounds3[i] = own[i];
+  return MI_OK;
+}
+
+int mi_gallery_set_image_dtype(mi_gallery* g, int f16) {
+  REQUIRE(g, "null handle");
+  f16 = f16 != 0;
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (g->img_f16 == f16 || g->n == 0) {
+    g->img_f16 = f16;
+    return MI_OK;
+  }
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipStreamSynchronize(g->stream));
+  // the stored f32 rows are already normalised: re-round them into the other 16-bit type (rows, image and rounding
+  // norms are rewritten; the f32 rows come out bit-identical)
+  launch_ingest(g->gal_f32, MI_F32, g->n, g->d, g->dp, 1, MI_NORM_NONE, g->gal_f32, g->gal_img, f16, g->rowstat, g->dp,
+                g->npad, g->stream);
+  launch_rowstat_max(g->rowstat, g->n, g->gstat3, g->stream);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(g->stream));
+  g->img_f16 = f16;
+  g->samp_for_n = -1;          // the bootstrap sample image is rebuilt from the new image
+  ws_free(g->ws);              // the query image buffers follow the element type
+  return MI_OK;
+}
+
+int mi_search_flags(mi_gallery* g, uint32_t* out_flags) {
+  REQUIRE(g && out_flags, "null");
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipStreamSynchronize(g->stream));
+  HIPC(hipDeviceSynchronize());
+  *out_flags = 0;
+  if (g->ws.qcap) {
+    int rc = read_and_clear_flags(g, out_flags);
+    if (rc != MI_OK) return rc;
+    if (*out_flags) g->stats.overflow_batches += 1;
+  }
+  return MI_OK;
+}
+
+int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
+  REQUIRE(g && name && out_value, "null");
+  const std::string n(name);
+  if (n == "chunk0_tiles") *out_value = g->chunk0_tiles;
+  else if (n == "chunk_growth") *out_value = g->chunk_growth;
+  else if (n == "survivor_cap") *out_value = g->surv_cap;
+  else if (n == "rescore_cap") *out_value = g->rescore_cap;
+  else if (n == "exact_fallback") *out_value = g->exact_fallback;
+  else if (n == "force_exact") *out_value = g->force_exact;
+  else if (n == "debug") *out_value = g->debug;
+  else if (n == "speculative") *out_value = g->speculative;
+  else if (n == "small_batch_kernel") *out_value = g->small_batch_kernel;
+  else if (n == "kernel_variant") *out_value = g->kernel_variant;
+  else if (n == "query_norm_override") *out_value = g->qnorm_override;
+  else if (n == "image_dtype") *out_value = g->img_f16;
+  else return fail(MI_ERR_INVALID, "unknown option: " + n);
   return MI_OK;
 }
 
@@ -1313,6 +1403,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "debug") g->debug = (int)value;
   else if (n == "speculative") g->speculative = value != 0;
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
+  else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
     g->qnorm_override = (int)value;

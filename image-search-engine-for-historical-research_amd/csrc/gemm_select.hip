@@ -69,7 +69,10 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* ldst) {
 }
 
 
-// DBG: diagnostics-only build variants (bit0 skip DMA, bit1 skip MFMA, bit2 skip the filter); 0 = product
+// DBG: diagnostics-only build variants; 0 = product.  bit0 (1) skip DMA, bit1 (2) skip MFMA, bit2 (4) skip the filter,
+// bit3 (8) per-segment stamps, bit5 (32) skip the gallery DMA only, bit6 (64) skip the query DMA only, bit7 (128) read the
+// fragments once (no LDS reads in the loop), bit8 (256) no barriers in the loop.  Every diagnostic build without stamps
+// records the in-kernel clock (s_memtime / s_memrealtime around the loop) in dbg[6], dbg[7].
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
                    : (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES) + (w & 3) * 4096;
   };
   pf_set(0);
-  constexpr bool dbg_nodma = DBG & 1, dbg_nomfma = DBG & 2;
+  constexpr bool dbg_nomfma = DBG & 2;
+  const bool dbg_nodma = (DBG & 1) || ((DBG & 32) && grp == 0) || ((DBG & 64) && grp == 1);
   const uint32_t ring_base = (grp == 0 ? A_RING : B_RING) + (w & 3) * 4096;
   uint32_t wr_slot = 0;                                   // ring slot the next issued slice goes to
   const uint32_t my_slots = grp == 0 ? A_SLOTS : B_SLOTS;
@@ -352,6 +356,8 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   unsigned long long clk0 = 0, rt0 = 0;
   if (DBG & 8) { clk0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   unsigned long long d_load = 0, d_b1 = 0, d_mfma = 0, d_b2 = 0, d_epi = 0, tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0, tt4 = 0;
+  frag_t af[8], bfr[4];
+  if ((DBG & ~8) != 0 && !(DBG & 8)) { clk0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   for (uint32_t S = 0; S < T_total; ++S) {
     if (DBG & 8) tt0 = stamp();
     // ================= LOAD segment (the partner group is in its MFMA segment) =================
@@ -359,11 +365,18 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     const char* bbase = smem + b_rd * SLICE_BYTES;
     if (++a_rd == A_SLOTS) a_rd = 0;
     if (++b_rd == B_SLOTS) b_rd = 0;
-    frag_t af[8], bfr[4];
+    if (!(DBG & 128) || S == 0) {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
+      for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const frag_t*>(abase + a_off + mb * 1024);
+      for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const frag_t*>(abase + a_off + mb * 1024);
+    }
+    if (DBG & 128) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(bfr[nb]));
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) asm volatile("" : "+v"(af[mb]));
+    }
     // DMA issue sits behind the 12 fragment reads: its ~60 cycles per piece overlap the LDS read latency instead
     // of stalling this wave's MFMAs (in the MFMA segment the partner wave cannot fill the matrix pipe).
     // group 0 issues A(S+4) into the slot of A(S-1), group 1 issues B(S+3) into the slot of B(S-1); both groups'
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier: frees the slots (WAR)
     __builtin_amdgcn_sched_barrier(0);
     if (DBG & 8) tt1 = stamp();
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 256)) __builtin_amdgcn_s_barrier();
     if (DBG & 8) tt2 = stamp();
     __builtin_amdgcn_sched_barrier(0);
     // ================= MFMA segment: 32 back-to-back MFMAs =================
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     if (grp == 0) vm_wait<(A_SLOTS - 2) * 4>();
     __builtin_amdgcn_sched_barrier(0);
     if (DBG & 8) tt3 = stamp();
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 256)) __builtin_amdgcn_s_barrier();
     if (DBG & 8) {
       tt4 = stamp();
       d_load += tt1 - tt0; d_b1 += tt2 - tt1; d_mfma += tt3 - tt2; d_b2 += tt4 - tt3;
@@ -422,6 +435,10 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
   }
   if (grp == 0 && ep_pending) tile_epilogue(ep_gt, ep_qt);
   if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the stagger barrier
+  if ((DBG & ~8) != 0 && !(DBG & 8) && lane == 0) {
+    unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
+    dbgp[5] = T_total; dbgp[6] = stamp() - clk0; dbgp[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
   if ((DBG & 8) && lane == 0) {
     unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
     dbgp[0] = d_load; dbgp[1] = d_b1; dbgp[2] = d_mfma; dbgp[3] = d_b2; dbgp[4] = d_epi; dbgp[5] = T_total; dbgp[6] = (p.debug & 16) ? (stamp() - clk0) : d_e1; dbgp[7] = (p.debug & 16) ? (__builtin_amdgcn_s_memrealtime() - rt0) : d_e2 + (d_hits << 40);
@@ -430,6 +447,324 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
     p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
     if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (unused) DMA pieces land before the LDS is released
+}
+
+
+// =====================================================================================================================
+// Structure 2 of the tile kernel: the same tile, rings, ping-pong and filter, with the code laid out for the
+// instruction fetch.  The per-slice loop of structure 1 carries the tile epilogue (the filter, ~10 KB of code) inside
+// its body, so every slice hops over it with three far taken branches, one of them right behind the barrier that opens
+// the MFMA segment; the probe of scripts/mfma_probe.hip (ping-pong of bare 32-MFMA segments: 16.5 cycles per MFMA)
+// against structure 1 with neither DMA nor LDS reads (18.7) locates ~70 cycles per segment there.  Here
+//   * each wave group runs its own copy of the loop (GRP is a compile-time constant: no group tests in the loop),
+//   * the slices of a tile are an inner loop whose body is straight-line code (LOAD, barrier, 32 MFMAs, barrier),
+//   * slice 0 of a tile is peeled (group 0 runs its deferred filter there), the filter sits outside the inner loop.
+// ORDER 1 issues the MFMAs query-block-major (the B fragment stays on the operand bus for 8 MFMAs instead of the A
+// fragment for 4).
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER>
+__global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
+  using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // rings | per-wave scratch | per-wave thresholds  (ONE LDS object)
+  if (REPAIR && *p.cond == 0) return;
+  const uint32_t b = blockIdx.x, nwg = gridDim.x >> 3;
+  const uint32_t xcd = b & 7u, j = b >> 3;
+  const uint32_t nqt = (uint32_t)p.nqt;
+  const uint32_t cnt_x = ((uint32_t)p.ntiles > xcd) ? ((uint32_t)p.ntiles - xcd + 7u) / 8u : 0u;
+  const uint32_t nvirt = cnt_x * nqt;
+  if (j >= nvirt) {
+    if (!FIRST && (threadIdx.x & 63) == 0) p.rec_cnt[b * 8 + (threadIdx.x >> 6)] = 0;
+    return;
+  }
+  const uint32_t my_tiles = (nvirt - j + nwg - 1) / nwg;
+  const uint32_t KSL = (uint32_t)p.nslices;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = w & 3;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  auto run = [&](auto grp_tag) {
+    constexpr int GRP = decltype(grp_tag)::value;              // wave group = gallery half; 0 streams A, 1 streams B
+    constexpr int MY_SLOTS = GRP == 0 ? A_SLOTS : B_SLOTS;
+    constexpr bool dbg_nodma = (DBG & 1) || ((DBG & 32) && GRP == 0) || ((DBG & 64) && GRP == 1);
+    float* thr_w = reinterpret_cast<float*>(smem + RING_BYTES + STAGE_BYTES) + w * 64;
+    uint32_t thr_qt = 0xFFFFFFFFu;
+    auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
+      const uint32_t v = j + i * nwg;
+      qt = v % nqt;
+      gt = (uint32_t)p.tile0 + (v / nqt) * 8u + xcd;
+    };
+    // ---- DMA stream of this group's operand: wave-uniform scalar base + one constant per-lane offset (saddr form)
+    uint32_t pf_i = 0, pf_sl = 0;
+    const char* pf;
+    const uint32_t pf_lane = (uint32_t)lane * 16u;
+    auto pf_set = [&](uint32_t i) {
+      uint32_t gt, qt;
+      tile_of(i < my_tiles ? i : my_tiles - 1, gt, qt);       // past the end: harmless re-load of the last tile
+      pf = (GRP == 0 ? (const char*)p.gal_img + (int64_t)gt * KSL * SLICE_BYTES
+                     : (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES) + wc * 4096;
+    };
+    pf_set(0);
+    const uint32_t ring_base = (GRP == 0 ? A_RING : B_RING) + wc * 4096;
+    uint32_t wr_slot = 0;
+    auto issue = [&]() {
+      uint32_t off = pf_lane;
+      asm volatile("" : "+v"(off));
+      if (!dbg_nodma) {
+        const GLOBAL_AS void* src = (const GLOBAL_AS void*)(pf + off);
+        LDS_AS void* dst = (LDS_AS void*)(smem + ring_base + wr_slot * SLICE_BYTES);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+      }
+      pf += SLICE_BYTES;
+      if (++pf_sl == KSL) {
+        pf_sl = 0;
+        pf_set(++pf_i);
+      }
+      if (++wr_slot == MY_SLOTS) wr_slot = 0;
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t fsw = (0u - (uint32_t)(l15 >> 2)) & 3u;
+    const uint32_t a_off = (uint32_t)(GRP * 128 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+    uint32_t b_off = (uint32_t)B_RING + (uint32_t)(wc * 64 + l15) * 64u + ((((uint32_t)lq) ^ fsw) << 4);
+    asm volatile("" : "+v"(b_off));     // opaque: keeps ONE address register for the four B reads (see structure 1)
+
+    SurvRec* my_rec = p.rec + (uint64_t)(b * 8 + w) * p.rec_cap;
+    uint32_t my_cnt = 0;
+    float* sc_val = reinterpret_cast<float*>(smem + RING_BYTES + w * WAVE_SCRATCH);
+    uint4* sc_meta = reinterpret_cast<uint4*>(smem + RING_BYTES + w * WAVE_SCRATCH + HIT_SLOTS * 32 * 4);
+    const uint32_t sc_val_lds = lds_addr(sc_val), sc_meta_lds = lds_addr(sc_meta);
+
+    // ---- per-tile filter of the accumulators (+ reset); same code as structure 1
+    auto tile_epilogue = [&](uint32_t gt, uint32_t qt) {
+      const uint32_t row_base = gt * TILE + GRP * 128 + lq * 4;          // + mb*16 + reg
+      const uint32_t ql_base = qt * TILE + wc * 64 + l15;                // + nb*16
+      if (DBG & 4) {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(acc[mb][nb]));
+      } else if (FIRST) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const uint32_t q = ql_base + nb * 16;
+          if (q < (uint32_t)p.nq) {
+            uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t row = row_base + mb * 16 + r;
+                if (row < (uint64_t)p.n) dst[row] = pack_entry(acc[mb][nb][r], row);
+              }
+          }
+        }
+      } else {
+        if (qt != thr_qt) {
+          thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
+          thr_qt = qt;
+        }
+        float thr4[4];
+        unsigned long long hm[4];
+        uint32_t base[5];
+        base[0] = 0;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
+          float m = acc[0][nb][0];
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
+          hm[nb] = __ballot(m >= thr4[nb]);
+          base[nb + 1] = base[nb] + (uint32_t)__popcll(hm[nb]);
+        }
+        const uint32_t total = base[4];
+        for (uint32_t r0 = 0; r0 < total; r0 += HIT_SLOTS) {          // almost always zero or one round
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            if (hm[nb] == 0) continue;                                  // wave-uniform
+            const uint32_t rank = base[nb] + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[nb] >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)hm[nb], 0u));
+            const bool mine = (hm[nb] >> lane) & 1ull;
+            if (mine && rank >= r0 && rank < r0 + HIT_SLOTS) {
+              const uint32_t dst = sc_val_lds + (rank - r0) * 128;
+              lds_store16<0>(dst, acc[0][nb]);
+              lds_store16<16>(dst, acc[1][nb]);
+              lds_store16<32>(dst, acc[2][nb]);
+              lds_store16<48>(dst, acc[3][nb]);
+              lds_store16<64>(dst, acc[4][nb]);
+              lds_store16<80>(dst, acc[5][nb]);
+              lds_store16<96>(dst, acc[6][nb]);
+              lds_store16<112>(dst, acc[7][nb]);
+              lds_store16u(sc_meta_lds + (rank - r0) * 16,
+                           (u32x4){__float_as_uint(thr4[nb]), ql_base + nb * 16, row_base, 0u});
+            }
+          }
+          const uint32_t nslots = min(total - r0, (uint32_t)HIT_SLOTS);
+          constexpr int SCAN = HIT_SLOTS * 32 / 64;
+          u32x3 mt[SCAN];                                              // (threshold, query, row base)
+          float vv[SCAN];
+#pragma unroll
+          for (int it = 0; it < SCAN; ++it) {
+            const uint32_t e = it * 64 + lane;
+            const bool valid = e < nslots * 32;
+            asm volatile("ds_read_b96 %0, %2\n\tds_read_b32 %1, %3"
+                         : "=&v"(mt[it]), "=v"(vv[it])
+                         : "v"(sc_meta_lds + (valid ? (e >> 5) : 0u) * 16u), "v"(sc_val_lds + (valid ? e : 0u) * 4u)
+                         : "memory");
+          }
+          static_assert(SCAN == 4, "the wait below lists the scan registers explicitly");
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(mt[0]), "+v"(mt[1]), "+v"(mt[2]), "+v"(mt[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3])
+                       :
+                       : "memory");
+#pragma unroll
+          for (int it = 0; it < SCAN; ++it) {
+            if ((uint32_t)(it * 64) >= nslots * 32) break;              // wave-uniform
+            const uint32_t e = it * 64 + lane;
+            const uint32_t i = e & 31u;
+            const uint32_t row = mt[it].z + (i >> 2) * 16 + (i & 3u);
+            const bool keep = e < nslots * 32 && vv[it] >= __uint_as_float(mt[it].x) && row < (uint64_t)p.n;
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+              const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+              if (keep && pos < p.rec_cap)
+                reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(vv[it]), row, mt[it].y, 0u);
+              my_cnt += (uint32_t)__popcll(km);
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): see structure 1
+      }
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- prologue: all but one slot of this group's ring in flight, slice 0 landed
+#pragma unroll
+    for (int d = 0; d < MY_SLOTS - 1; ++d) issue();
+    vm_wait<(MY_SLOTS - 2) * 4>();
+    __builtin_amdgcn_s_barrier();
+    if (GRP == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
+
+    uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding the current slice
+    frag_t af[8], bfr[4];
+    unsigned long long clk0 = 0, rt0 = 0;
+    // in-kernel clock of every launch (s_memtime / s_memrealtime around the loop, per wave): two scalar reads, and the
+    // number bench.py reports next to the roofline fraction (the chip holds 1.4-1.7 GHz of its 2.4 GHz under this load)
+    if (p.dbg) { clk0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // LOAD segment (the partner group is in its MFMA segment): 12 fragment reads, then the 4 DMA pieces of the slice
+    // MY_SLOTS - 1 ahead into the slot whose reads retired before the barrier behind us
+    auto load_segment = [&](bool first_ever) {
+      const char* abase = smem + a_rd * SLICE_BYTES;
+      const char* bbase = smem + b_rd * SLICE_BYTES;
+      if (++a_rd == A_SLOTS) a_rd = 0;
+      if (++b_rd == B_SLOTS) b_rd = 0;
+      if (!(DBG & 128) || first_ever) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const frag_t*>(abase + a_off + mb * 1024);
+      }
+      if (DBG & 128) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+v"(bfr[nb]));
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) asm volatile("" : "+v"(af[mb]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      issue();
+      if (GRP == 1) vm_wait<(B_SLOTS - 2) * 4>();        // B(S+1) landed before the barrier that opens group 0's LOAD(S+1)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired BEFORE the barrier: frees the slots (WAR)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_segment = [&]() {
+      if (!(DBG & 2)) {
+        if (ORDER == 0) {
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+              if constexpr (F16)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+              else
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+              if constexpr (F16)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+              else
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) asm volatile("" ::"v"(af[mb]));
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(bfr[nb]));
+      }
+      if (GRP == 0) vm_wait<(A_SLOTS - 2) * 4>();        // A(S+1) landed, A(S+2..S+4) may be in flight
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    uint32_t gt, qt, prev_gt = 0, prev_qt = 0;
+    for (uint32_t i = 0; i < my_tiles; ++i) {
+      tile_of(i, gt, qt);
+      // ---- slice 0 of the tile (peeled: group 0 filters the previous tile between its barrier and its MFMAs)
+      load_segment(i == 0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (GRP == 0 && i > 0) tile_epilogue(prev_gt, prev_qt);
+      mfma_segment();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- slices 1 .. KSL-1: straight-line body
+#pragma unroll 1
+      for (uint32_t sl = 1; sl < KSL; ++sl) {
+        load_segment(false);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_segment();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (GRP == 1) tile_epilogue(gt, qt);
+      else { prev_gt = gt; prev_qt = qt; }
+    }
+    if (GRP == 0) {
+      tile_epilogue(prev_gt, prev_qt);
+      __builtin_amdgcn_s_barrier();                        // balance the stagger barrier
+    }
+    if (p.dbg && lane == 0) {
+      unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
+      dbgp[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF;   // HW_REG_XCC_ID[3:0]
+      dbgp[5] = (unsigned long long)my_tiles * KSL;
+      dbgp[6] = stamp() - clk0;
+      dbgp[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+    if (!FIRST && lane == 0) {
+      p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
+      if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
+    }
+  };
+  if (w < 4) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (unused) DMA pieces land before the LDS is released
 }
 
@@ -508,9 +843,34 @@ static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER>
+static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+}
+
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
   const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * 64 * 4;
+  if (a.variant != 1) {                                          // structure 2 (default); variant 1 = structure 1 (A/B)
+    if (a.cond) return a.img_f16 ? launch_tile<false, 0, true, true, 1>(a, lds, stream)
+                                 : launch_tile<false, 0, false, true, 1>(a, lds, stream);
+    if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 1>(a, lds, stream)
+                                : launch_tile<true, 0, false, false, 1>(a, lds, stream);
+    if (!a.img_f16) return launch_tile<false, 0, false, false, 1>(a, lds, stream);
+    const bool o0 = a.variant == 2;                                // MFMA issue order A/B
+    switch (a.debug) {
+      case 4: return o0 ? launch_tile<false, 4, true, false, 0>(a, lds, stream) : launch_tile<false, 4, true, false, 1>(a, lds, stream);
+      case 5: return launch_tile<false, 5, true, false, 1>(a, lds, stream);
+      case 5 + 128: return launch_tile<false, 5 + 128, true, false, 1>(a, lds, stream);
+      default: return o0 ? launch_tile<false, 0, true, false, 0>(a, lds, stream) : launch_tile<false, 0, true, false, 1>(a, lds, stream);
+    }
+  }
   if (a.cond) return a.img_f16 ? launch_variant<false, 0, true, true>(a, lds, stream)
                                : launch_variant<false, 0, false, true>(a, lds, stream);
   if (a.img_f16) {
@@ -519,6 +879,12 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
       case 4: return launch_variant<false, 4, true>(a, lds, stream);
       case 5: return launch_variant<false, 5, true>(a, lds, stream);
       case 8: case 24: return launch_variant<false, 8, true>(a, lds, stream);
+      case 4 + 32: return launch_variant<false, 4 + 32, true>(a, lds, stream);
+      case 4 + 64: return launch_variant<false, 4 + 64, true>(a, lds, stream);
+      case 4 + 128: return launch_variant<false, 4 + 128, true>(a, lds, stream);
+      case 5 + 128: return launch_variant<false, 5 + 128, true>(a, lds, stream);
+      case 5 + 128 + 256: return launch_variant<false, 5 + 128 + 256, true>(a, lds, stream);
+      case 5 + 256: return launch_variant<false, 5 + 256, true>(a, lds, stream);
       default: return launch_variant<false, 0, true>(a, lds, stream);
     }
   }

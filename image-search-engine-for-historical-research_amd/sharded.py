@@ -46,6 +46,24 @@ class ShardedGallery:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._buf = {}
+        if self.world > 1:
+            self._agree()
+
+    def _agree(self):
+        """One error margin for all shards: the certificate's eps must cover the rows of EVERY shard (a row at the
+        K-th approximate score L may sit on a shard with larger rounding norms than mine), so the norm maxima are
+        all-reduced (MAX) and the image element type is the coarsest any shard chose (MIN: a raw shard with large rows
+        falls back to bf16 on its own, csrc/api.hip mi_gallery_create)."""
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        f16 = torch.tensor([int(self.g.get_option("image_dtype"))], dtype=torch.int32, device=dev)
+        dist.all_reduce(f16, op=dist.ReduceOp.MIN, group=self.group)
+        if int(f16.item()) != int(self.g.get_option("image_dtype")):
+            self.g.set_image_dtype(int(f16.item()))
+        b = torch.tensor(self.g.norm_bounds(), dtype=torch.float32, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX, group=self.group)
+        self.g.norm_bounds(raise_to=[float(v) for v in b.tolist()])
 
     def _buffers(self, nq, k, device):
         import torch
@@ -77,13 +95,15 @@ class ShardedGallery:
         try:
             out = self._search(q, k)
             if verify and self.any_flag():
-                for name in ("speculative", "force_exact"):
-                    self.g.set_option(name, 0 if name == "speculative" else 1)
+                # the fallbacks of the host entry point, in its order; the caller's option values are restored afterwards
+                for name, val in (("speculative", 0), ("force_exact", 1)):
+                    prev = self.g.get_option(name)
+                    self.g.set_option(name, val)
                     try:
                         out = self._search(q, k)
                         bad = self.any_flag()
                     finally:
-                        self.g.set_option(name, 1 if name == "speculative" else 0)
+                        self.g.set_option(name, prev)
                     if not bad:
                         break
                 else:
@@ -95,9 +115,9 @@ class ShardedGallery:
                 self.g.set_option("query_norm_override", -1)
 
     def any_flag(self):
-        """True on every rank iff any shard raised a sticky flag since the last call (synchronises; resets the
-        handle's statistics)."""
-        bad = 1 if self.g.status(reset=True)["overflow_batches"] > 0 else 0
+        """True on every rank iff any shard raised a sticky flag since the last call (synchronises; the handle's
+        statistics accumulators are left alone)."""
+        bad = 1 if self.g.flags() else 0
         if self.world > 1:
             import torch
             import torch.distributed as dist

@@ -186,6 +186,15 @@ int mi_column_sum(const void* X, int64_t n, int32_t d, int dtype, int64_t row_st
 int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
                     const double* m, const double* P, int32_t dims, double eps, int device, double* out);
 
+/* ---- agreement between the shards of one gallery (multi-GPU).  The exactness certificate keeps every row
+ * whose approximate score is within 2*eps of the K-th largest approximate score L of the WHOLE gallery; eps is derived
+ * from the norm maxima measured at ingest {max ||g||, max ||g_hat||, max ||g_hat - g||} and from the image element type.
+ * A row on shard B is only guaranteed approx >= L - eps_A - eps_B when the rows at L sit on shard A, so every shard must
+ * use the maxima over ALL shards and the same image type: all-reduce(MAX) the bounds, all-reduce(MIN) the type, write
+ * them back (sharded.ShardedGallery does this on construction). */
+int mi_gallery_norm_bounds(mi_gallery* g, float* bounds3 /* in-out */, int raise);  /* raise=0: read; 1: bounds = max(own, given) */
+int mi_gallery_set_image_dtype(mi_gallery* g, int f16);  /* re-images the stored f32 rows (1 = fp16, 0 = bf16); no-op if equal */
+
 /* ---- status / instrumentation */
 typedef struct mi_search_stats {
   int64_t searches;           /* query batches processed */
@@ -197,6 +206,9 @@ typedef struct mi_search_stats {
   int64_t gemm_launches;
   double gemm_flops;          /* algorithmic 2*Q*N*D of those launches */
   double gemm_bytes;          /* algorithmic gallery + query bytes of those launches */
+  double kernel_clock_mhz;    /* shader clock inside the most recent tile-kernel launch (s_memtime / s_memrealtime around its
+                               * main loop, median over waves); 0 if that kernel has not run.  The chip lowers its clock under
+                               * MFMA load, so this is what the dense peak scales with */
 } mi_search_stats;
 int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches with hipEvents */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
@@ -204,8 +216,14 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
- * already normalised expanded queries of alpha-QE). */
+ * already normalised expanded queries of alpha-QE), "kernel_variant" (structure of the tile kernel, A/B only).
+ * mi_get_option also answers "image_dtype" (1 = fp16, 0 = bf16; read-only, see mi_gallery_set_image_dtype). */
 int mi_set_option(mi_gallery* g, const char* name, double value);
+int mi_get_option(const mi_gallery* g, const char* name, double* out_value);   /* same names as mi_set_option */
+/* Synchronises the handle's work, returns the sticky device flags raised by the asynchronous _device entry points since
+ * the last call (0 = none; any bit = that batch must be answered again: buffer overflow or failed speculative threshold)
+ * and clears them.  Unlike mi_search_status it leaves the statistics accumulators alone. */
+int mi_search_flags(mi_gallery* g, uint32_t* out_flags);
 
 /* Process-wide defaults for galleries created afterwards.  "image_dtype": element type of the 16-bit tile-blocked image the
  * MFMA kernel streams, 1 = fp16 (default: 2^-11 rounding, 8x tighter certificate than bf16 at the same MFMA rate;

@@ -18,7 +18,7 @@ def big():
     raw = torch.empty((N, D), dtype=torch.float32, device=dev)
     _lib.synth_fill_device(raw.data_ptr(), 1234, 0, N, D, s)
     # plant: gallery rows 7, 500000 and N-1 are (scaled) copies of query rows 0, 1, 2
-    q = torch.from_numpy(synth_rows(4321, 0, 64, D)).to(dev)
+    q = torch.from_numpy(synth_rows(4321, 0, 1024, D)).to(dev)
     raw[7] = q[0] * 3.0
     raw[500000] = q[1] * 0.5
     raw[N - 1] = q[2]
@@ -100,3 +100,46 @@ def test_full_size_two_shards_equal_one(big):
     _lib.topk_merge_device(sc64.data_ptr(), idx.data_ptr(), 2, nq, K, oi.data_ptr(), osc.data_ptr(), s)
     torch.cuda.synchronize()
     assert np.array_equal(oi.cpu().numpy(), ref_idx) and np.array_equal(osc.cpu().numpy(), ref_sc)
+
+
+def test_full_size_tile_kernel_equals_exact_path_and_two_shards(big):
+    """The benchmarked configuration itself: 1024 queries (the 256 x 256-tile MFMA kernel, four query tiles, 64 K-slices,
+    speculative threshold) on all 1,005,994 rows -- bit-equal to the f32-scored path and to the two-shard protocol."""
+    import torch
+    from isehr_amd import _lib
+    g, g0, g1, q = big
+    nq = 1024
+    idx, sc = _search(g, q, nq)
+    assert g.status()["overflow_batches"] == 0
+    assert idx[0, 0] == 7 and idx[1, 0] == 500000 and idx[2, 0] == N - 1
+    assert (np.diff(sc, axis=1) <= 0).all() and all(len(set(r)) == K for r in idx)
+    g.set_option("force_exact", 1)
+    try:
+        idx_e, sc_e = _search(g, q, nq)
+    finally:
+        g.set_option("force_exact", 0)
+    assert np.array_equal(idx, idx_e) and np.array_equal(sc, sc_e)
+    # float64 re-computation of 16 queries' 100 scores from the stored rows
+    qn = q.cpu().numpy().astype(np.float64)
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    for qi in range(0, nq, 64):
+        rows = np.stack([g.get_rows(int(r), 1)[0] for r in idx[qi]]).astype(np.float64)
+        assert np.abs(rows @ qn[qi] - sc[qi]).max() < 3e-7
+    # two shards, phase protocol
+    dev, s = q.device, torch.cuda.current_stream().cuda_stream
+    approx = torch.empty((2, nq, K), dtype=torch.float32, device=dev)
+    for r, sh in enumerate((g0, g1)):
+        sh.phase1_device(q.data_ptr(), nq, K, approx[r].data_ptr(), s)
+    L = torch.empty((nq,), dtype=torch.float32, device=dev)
+    _lib.kth_of_gathered_device(approx.data_ptr(), 2, nq, K, L.data_ptr(), s)
+    idx2 = torch.empty((2, nq, K), dtype=torch.int64, device=dev)
+    sc2 = torch.empty((2, nq, K), dtype=torch.float32, device=dev)
+    sc64 = torch.empty((2, nq, K), dtype=torch.float64, device=dev)
+    for r, sh in enumerate((g0, g1)):
+        sh.phase2_device(nq, K, L.data_ptr(), idx2[r].data_ptr(), sc2[r].data_ptr(), sc64[r].data_ptr(), s)
+    oi = torch.empty((nq, K), dtype=torch.int64, device=dev)
+    osc = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    _lib.topk_merge_device(sc64.data_ptr(), idx2.data_ptr(), 2, nq, K, oi.data_ptr(), osc.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert g0.status()["overflow_batches"] == 0 and g1.status()["overflow_batches"] == 0
+    assert np.array_equal(oi.cpu().numpy(), idx) and np.array_equal(osc.cpu().numpy(), sc)
