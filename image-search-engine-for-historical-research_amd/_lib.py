@@ -72,6 +72,10 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, c_f64p]),
     "mi_rank_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                               C.c_void_p, c_f64p]),
+    "mi_rank_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64,
+                                 C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_rank_positions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int,
+                                    C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_diffusion_offline": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -276,6 +280,36 @@ class Gallery:
                                      idx.ctypes.data_as(C.c_void_p),
                                      sc.ctypes.data_as(C.c_void_p) if return_scores else None, C.byref(secs)))
         return (idx, sc, secs.value) if return_scores else (idx, secs.value)
+
+    def rank_prefix(self, queries, keep, query_norm=-1, return_scores=False):
+        """The first `keep` columns of the full-length ranking: -> (idx int64 [Q,keep][, scores float32 [Q,keep]], seconds)."""
+        a, code, rs, cs = _strided(queries)
+        if a.shape[1] != self.d:
+            raise ValueError("query dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        nq, keep = a.shape[0], int(keep)
+        idx = np.empty((nq, keep), dtype=np.int64)
+        sc = np.empty((nq, keep), dtype=np.float32) if return_scores else None
+        secs = C.c_double()
+        with self._lock:
+            check(load().mi_rank_prefix(self._h, C.c_void_p(_base_pointer(a)), nq, code, rs, cs, query_norm, keep,
+                                        idx.ctypes.data_as(C.c_void_p),
+                                        sc.ctypes.data_as(C.c_void_p) if return_scores else None, C.byref(secs)))
+        return (idx, sc, secs.value) if return_scores else (idx, secs.value)
+
+    def rank_positions(self, queries, row_ids, query_norm=-1):
+        """Zero-based positions of the listed rows in every query's full ranking (score desc, idx asc), counted on the
+        device.  row_ids int64 [Q, m] of global ids, -1 = padding -> position -1.  Returns int64 [Q, m]."""
+        a, code, rs, cs = _strided(queries)
+        if a.shape[1] != self.d:
+            raise ValueError("query dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        if ids.ndim != 2 or ids.shape[0] != a.shape[0]:
+            raise ValueError("row_ids must be [Q, m]")
+        out = np.empty(ids.shape, dtype=np.int64)
+        with self._lock:
+            check(load().mi_rank_positions(self._h, C.c_void_p(_base_pointer(a)), a.shape[0], code, rs, cs, query_norm,
+                                           ids.ctypes.data_as(C.c_void_p), ids.shape[1], out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def diffusion_offline(self, n_trunc, kd, alpha=0.99, gamma=3, maxiter=20, tol=1e-6, return_sims=False):
         """-> (ids int64 [N,n_trunc], vals float32 [N,n_trunc][, knn sims float32 [N,n_trunc]])."""

@@ -1030,14 +1030,16 @@ int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int
   return MI_OK;
 }
 
-int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
-                int query_norm, int64_t* out_idx, float* out_score, double* out_seconds) {
+// full-length ranking of every query, of which the first `keep` columns are copied out (keep = N: the whole ranking)
+static int rank_all_impl(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                         int query_norm, int64_t keep, int64_t* out_idx, float* out_score, double* out_seconds) {
   REQUIRE(g && q && out_idx, "null pointer");
   REQUIRE(nq >= 1, "no queries");
   REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
   REQUIRE(query_norm >= -1 && query_norm <= 2, "query_norm: -1 (as the gallery) or an mi_norm value");
   std::lock_guard<std::mutex> lock(g->mu);
   HIPC(hipSetDevice(g->device));
+  REQUIRE(keep >= 1 && keep <= g->n, "keep must be in [1, N]");
   const auto t0 = std::chrono::steady_clock::now();
   const int qn = query_norm < 0 ? g->norm_mode : query_norm;
   int64_t elems;
@@ -1080,10 +1082,83 @@ int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row
     launch_rank_all(dense, n, n, b, ka, ia, kb, ib, g->row_offset, oi, os, s);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(s));
-    HIPC(hipMemcpy(out_idx + q0 * n, oi, (size_t)b * n * 8, hipMemcpyDeviceToHost));
-    if (out_score) HIPC(hipMemcpy(out_score + q0 * n, os, (size_t)b * n * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy2D(out_idx + q0 * keep, (size_t)keep * 8, oi, (size_t)n * 8, (size_t)keep * 8, (size_t)b,
+                     hipMemcpyDeviceToHost));
+    if (out_score)
+      HIPC(hipMemcpy2D(out_score + q0 * keep, (size_t)keep * 4, os, (size_t)n * 4, (size_t)keep * 4, (size_t)b,
+                       hipMemcpyDeviceToHost));
   }
   if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return MI_OK;
+}
+
+int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                int query_norm, int64_t* out_idx, float* out_score, double* out_seconds) {
+  REQUIRE(g, "null handle");
+  return rank_all_impl(g, q, nq, dtype, row_stride, col_stride, query_norm, g->n, out_idx, out_score, out_seconds);
+}
+
+int mi_rank_prefix(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                   int query_norm, int64_t keep, int64_t* out_idx, float* out_score, double* out_seconds) {
+  REQUIRE(g, "null handle");
+  return rank_all_impl(g, q, nq, dtype, row_stride, col_stride, query_norm, keep, out_idx, out_score, out_seconds);
+}
+
+int mi_rank_positions(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                      int query_norm, const int64_t* row_ids, int32_t m, int64_t* out_pos) {
+  REQUIRE(g && q && row_ids && out_pos, "null pointer");
+  REQUIRE(nq >= 1 && m >= 1, "bad sizes");
+  REQUIRE(m <= rank_positions_max_listed(), "too many listed rows per query (max 2048)");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  REQUIRE(query_norm >= -1 && query_norm <= 2, "query_norm: -1 (as the gallery) or an mi_norm value");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const int qn = query_norm < 0 ? g->norm_mode : query_norm;
+  int64_t elems;
+  int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  if ((rc = ws_ensure(g, 1)) != MI_OK) return rc;
+  Workspace& ws = g->ws;
+  hipStream_t s = g->stream;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  const int64_t n = g->n;
+  const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(QB, ((int64_t)1 << 28) / n));
+  TmpAlloc tmp;
+  char* qd = tmp.get<char>((size_t)elems * esz);
+  float* dense = tmp.get<float>((size_t)round_up(qb, 64) * n);
+  int64_t* ids_d = tmp.get<int64_t>((size_t)nq * m);
+  unsigned long long* pos_d = tmp.get<unsigned long long>((size_t)nq * m);
+  if (!qd || !dense || !ids_d || !pos_d) return fail(MI_ERR_NOMEM, "rank_positions buffers");
+  HIPC(hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ids_d, row_ids, (size_t)nq * m * 8, hipMemcpyHostToDevice));
+  HIPC(hipMemsetAsync(pos_d, 0, (size_t)nq * m * 8, s));
+  for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+    const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
+    const int32_t qpad = (int32_t)round_up(b, TILE);
+    launch_ingest(qd + (size_t)q0 * row_stride * esz, dtype, b, g->d, row_stride, col_stride, qn, ws.q_f32, ws.q_img,
+                  g->img_f16, ws.q_stat, g->dp, qpad, s);
+    ExactArgs a;
+    a.gal_f32 = g->gal_f32;
+    a.qry_f32 = ws.q_f32;
+    a.dp = g->dp;
+    a.row0 = 0;
+    a.row1 = n;
+    a.n = n;
+    a.nq = b;
+    a.st = make_state(ws);
+    a.dense_out = dense;
+    a.dense_ld = n;
+    launch_exact_select(a, false, s);
+    launch_rank_positions(dense, n, n, b, ids_d + q0 * m, m, g->row_offset, pos_d + q0 * m, s);
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipMemcpy(out_pos, pos_d, (size_t)nq * m * 8, hipMemcpyDeviceToHost));
+  // ids outside this shard (padding, -1) get position -1
+  for (int64_t i = 0; i < nq * m; ++i) {
+    const int64_t id = row_ids[i] - g->row_offset;
+    if (id < 0 || id >= n) out_pos[i] = -1;
+  }
   return MI_OK;
 }
 

@@ -4,6 +4,8 @@
 // One workgroup per row: 4-pass MSB radix select of the k-th largest key straight from global memory (the row
 // stays in L2), a second select on the INDEX among the ties of that key (ties go to the lower index,
 // deterministically), then the k chosen entries are bitonic-sorted in LDS by (score desc, idx asc).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -227,6 +229,59 @@ __global__ __launch_bounds__(RANK_THREADS) void rank_all_kernel(const float* __r
     if (out_score) out_score[(uint64_t)q * n + i] = row[id];
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Positions of a FEW listed rows in the full ranking of every query, without producing the ranking: position of row r =
+// #{ j : key(j) < key(r)  or  (key(j) == key(r) and j < r) } with key = ~f2key(score), i.e. exactly the place
+// rank_all_kernel would give it (score descending, index ascending, NaN last).  This is all the revisited mAP protocol
+// needs of `ranks_aqe` [N, Q] (src/utils/Reranking.py:207, 280-283; src/utils/evaluate2.py:73-86 looks up the
+// positions of the positive and junk images only).  grid = (row chunks, queries); the m listed keys sit in LDS.
+constexpr int POS_THREADS = 256, POS_MAX_LISTED = 2048;
+__global__ __launch_bounds__(POS_THREADS) void rank_positions_kernel(const float* __restrict__ scores, int64_t ld,
+                                                                      uint32_t n, const int64_t* __restrict__ ids,
+                                                                      int32_t m, int64_t row_offset,
+                                                                      unsigned long long* __restrict__ out_pos) {
+  __shared__ uint32_t lkey[POS_MAX_LISTED];
+  __shared__ uint32_t lrow[POS_MAX_LISTED];
+  __shared__ uint32_t lcnt[POS_MAX_LISTED];
+  const uint32_t q = blockIdx.y;
+  const float* row = scores + (uint64_t)q * ld;
+  for (int i = threadIdx.x; i < m; i += POS_THREADS) {
+    const int64_t id = ids[(uint64_t)q * m + i] - row_offset;
+    const bool ok = id >= 0 && id < (int64_t)n;
+    lrow[i] = ok ? (uint32_t)id : 0xFFFFFFFFu;
+    lkey[i] = ok ? ~f2key(row[id]) : 0u;
+    lcnt[i] = 0;
+  }
+  __syncthreads();
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t j0 = blockIdx.x * per, j1 = min(n, j0 + per);
+  // every thread owns a strided subset of this chunk's rows and compares each against all listed rows; the per-listed-row
+  // counts are reduced over the wave by ballots and added to LDS once per 64 rows
+  const int lane = threadIdx.x & 63;
+  for (uint32_t jb = j0 + (threadIdx.x & ~63u); jb < j1; jb += POS_THREADS) {
+    const uint32_t jj = jb + lane;
+    const bool valid = jj < j1;
+    const uint32_t kj = valid ? ~f2key(row[jj]) : 0xFFFFFFFFu;
+    for (int i = 0; i < m; ++i) {
+      const uint32_t kr = lkey[i], rr = lrow[i];
+      const bool before = valid && rr != 0xFFFFFFFFu && (kj < kr || (kj == kr && jj < rr));
+      const unsigned long long bm = __ballot(before);
+      if (lane == 0 && bm) atomicAdd(&lcnt[i], (uint32_t)__popcll(bm));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += POS_THREADS)
+    if (lrow[i] != 0xFFFFFFFFu && lcnt[i]) atomicAdd(&out_pos[(uint64_t)q * m + i], (unsigned long long)lcnt[i]);
+}
+
+void launch_rank_positions(const float* scores, int64_t ld, int64_t n, int32_t nq, const int64_t* ids, int32_t m,
+                           int64_t row_offset, unsigned long long* out_pos, hipStream_t stream) {
+  const unsigned chunks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, n / 4096));
+  hipLaunchKernelGGL(rank_positions_kernel, dim3(chunks, nq), dim3(POS_THREADS), 0, stream, scores, ld, (uint32_t)n, ids,
+                     m, row_offset, out_pos);
+}
+int rank_positions_max_listed() { return POS_MAX_LISTED; }
 
 void launch_rank_all(const float* scores, int64_t ld, int64_t n, int32_t nq, uint32_t* keys_a, uint32_t* idx_a,
                      uint32_t* keys_b, uint32_t* idx_b, int64_t row_offset, int64_t* out_idx, float* out_score,

@@ -90,6 +90,10 @@ void launch_rank_all(const float* scores, int64_t ld, int64_t n, int32_t nq, uin
                      uint32_t* keys_b, uint32_t* idx_b, int64_t row_offset, int64_t* out_idx, float* out_score,
                      hipStream_t stream);
 
+void launch_rank_positions(const float* scores, int64_t ld, int64_t n, int32_t nq, const int64_t* ids, int32_t m,
+                           int64_t row_offset, unsigned long long* out_pos, hipStream_t stream);
+int rank_positions_max_listed();
+
 // diffusion.hip
 void launch_affinity(const int64_t* ids, const float* sims, int64_t ld, int64_t n, int32_t kd, int32_t gamma,
                      float alpha, float* lap, float* dinv, float* diag, hipStream_t stream);

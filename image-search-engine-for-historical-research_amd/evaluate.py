@@ -41,6 +41,39 @@ def compute_map(ranks, gnd):
     return float(aps[valid].mean()), aps
 
 
+def compute_map_from_positions(pos_ok, pos_junk):
+    """The same AP from the POSITIONS (zero-based places in the full ranking) of every positive and junk image of each
+    query -- all that the reference's compute_map2 reads out of `ranks` [N, Q] (src/utils/evaluate2.py:73-86: np.in1d
+    look-ups of the positive and junk ids).  pos_ok / pos_junk: per query 1-D arrays (entries < 0 are ignored).
+    Equals compute_map on the complete ranking; the [N, Q] array never has to exist (Gallery.rank_positions)."""
+    nq = len(pos_ok)
+    aps = np.full(nq, np.nan)
+    for i in range(nq):
+        ok = np.sort(np.asarray(pos_ok[i])[np.asarray(pos_ok[i]) >= 0])
+        if ok.size == 0:
+            continue
+        junk = np.sort(np.asarray(pos_junk[i])[np.asarray(pos_junk[i]) >= 0])
+        pos = ok - np.searchsorted(junk, ok)                 # junk ranked before a positive does not count
+        aps[i] = average_precision(pos, ok.size)
+    valid = ~np.isnan(aps)
+    return float(aps[valid].mean()), aps
+
+
+EMH = ((("easy",), ("junk", "hard")), (("easy", "hard"), ("junk",)), (("hard",), ("junk", "easy")))
+
+
+def compute_map_revisited_from_positions(gnd, position_of):
+    """(mapE, mapM, mapH) from a per-query look-up `position_of[i][image id] -> position in the full ranking`."""
+    out = []
+    for ok_keys, junk_keys in EMH:
+        ok = [np.array([position_of[i][int(v)] for k in ok_keys for v in np.asarray(x[k]).ravel()], dtype=np.int64)
+              for i, x in enumerate(gnd)]
+        junk = [np.array([position_of[i][int(v)] for k in junk_keys for v in np.asarray(x[k]).ravel()], dtype=np.int64)
+                for i, x in enumerate(gnd)]
+        out.append(compute_map_from_positions(ok, junk)[0])
+    return tuple(out)
+
+
 def compute_map_revisited(ranks, gnd):
     """(mapE, mapM, mapH) with the Easy / Medium / Hard label sets of the revisited protocol."""
     out = []

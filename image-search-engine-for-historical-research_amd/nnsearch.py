@@ -83,12 +83,11 @@ def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=Non
     g = get_gallery(embedded_features_train, dataset, ifgenerate, NORM_L2, device)
     try:
         if int(K) > TOPK_PATH_MAX_K:
-            # deep / full-length ranking (--mode mAP ranks the whole database, src/test_rOP1m.py:144-149):
-            # dense exact scores + per-query radix sort, then the first K columns
-            idx, scores, _ = g.rank_all(embedded_features_test, return_scores=True)
-            if int(K) > idx.shape[1]:
+            # deep / full-length ranking (--mode mAP ranks the whole database, src/test_rOP1m.py:144-149): dense exact
+            # scores + per-query radix sort on the device; only the first K columns come back to the host
+            if int(K) > g.n:
                 raise RuntimeError("mi355_retrieval error 1: k > number of gallery rows")
-            idx, scores = np.ascontiguousarray(idx[:, :int(K)]), np.ascontiguousarray(scores[:, :int(K)])
+            idx, scores, _ = g.rank_prefix(embedded_features_test, int(K), return_scores=True)
         else:
             idx, scores, _ = g.search(embedded_features_test, int(K))
     finally:
@@ -104,6 +103,18 @@ def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=Non
 def matching_L2_hip(K, embedded_features_train, embedded_features_test):
     """Same signature as matching_L2 (src/utils/nnsearch.py:687)."""
     return matching_HIP(K, embedded_features_train, embedded_features_test)
+
+
+def matching_fractional_dis_hip(K, embedded_features_train, embedded_features_test):
+    """Same signature and return shape as matching_fractional_dis (src/utils/nnsearch.py:709-731).  The reference calls
+    its fractional distance with p = 2 (:721), which orders the gallery exactly like matching_L2, and slices the QUERY
+    axis of the argsort by K before the gallery axis (:723-724): it returns the rankings of the first min(Q, K) queries,
+    int64 [min(Q, K), K].  Reproduced as is; the timer divides by all queries like the reference's (:730)."""
+    t1 = time.time()
+    test = np.asarray(embedded_features_test)
+    num_test = test.shape[0]
+    idx, _ = matching_HIP(K, embedded_features_train, test[:int(K)])
+    return idx, (time.time() - t1) / num_test
 
 
 def ip_rank_hip(vecs, qvecs, dataset=None, ifgenerate=False, device=0, return_scores=False):

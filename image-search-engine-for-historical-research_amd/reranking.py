@@ -61,13 +61,40 @@ def QGE_hip(ranks, qvecs, vecs, dataset, gnd, cache_dir=None, gnd_path2=None, AQ
     out = {}
     if n >= 120000:
         Kq = int(K) if K else min(n, 1000)
-        qx, ranks_aqe = feature_enhancement_hip(3, ranks, vecs, 8.0 / 2, Kq, None, False, device)
-        out.update(qvecs_qe=qx, ranks_aqe=ranks_aqe)
-        if gnd is not None:
-            if not quiet:
-                print("mAP after Enhancement")
-            out["map_aqe"] = evaluate.compute_map_and_print(dataset, ranks_aqe, gnd) if not quiet else \
-                evaluate.compute_map_revisited(ranks_aqe, gnd)
+        g = get_gallery(vecs.T, None, False, NORM_NONE, device)
+        try:
+            qx, ranks_aqe = feature_enhancement_hip(3, ranks, g, 8.0 / 2, Kq, None, False, device)
+            out.update(qvecs_qe=qx, ranks_aqe=ranks_aqe)
+            if gnd is not None:
+                # The reference evaluates the COMPLETE ranking ranks_aqe [N, Q] (src/utils/Reranking.py:206-207, 280-283), so
+                # a positive ranked deeper than any top-K still counts.  compute_map2 only looks up where the labelled
+                # images sit (src/utils/evaluate2.py:73-86): their positions in the full ranking are counted on the device
+                # (mi_rank_positions) and give the same mAP without an [N, Q] array.
+                keys = ("easy", "hard", "junk") if "easy" in gnd[0] else ("ok", "junk")
+                ids = [np.unique(np.concatenate([np.asarray(x.get(k, []), dtype=np.int64).ravel() for k in keys])) for x in gnd]
+                m = max(1, max(len(v) for v in ids))
+                table = np.full((len(gnd), m), -1, dtype=np.int64)
+                for i, v in enumerate(ids):
+                    table[i, :len(v)] = v
+                pos = g.rank_positions(np.ascontiguousarray(qx.T), table, query_norm=NORM_NONE)   # expanded queries as is
+                position_of = [dict(zip(ids[i].tolist(), pos[i, :len(ids[i])].tolist())) for i in range(len(gnd))]
+                out["positions"] = position_of
+                if "easy" in gnd[0]:
+                    vals = evaluate.compute_map_revisited_from_positions(gnd, position_of)
+                else:
+                    ok = [np.array([position_of[i][int(v)] for v in np.asarray(x["ok"]).ravel()]) for i, x in enumerate(gnd)]
+                    jk = [np.array([position_of[i][int(v)] for v in np.asarray(x.get("junk", [])).ravel()])
+                          for i, x in enumerate(gnd)]
+                    vals = evaluate.compute_map_from_positions(ok, jk)[0]
+                out["map_aqe"] = vals
+                if not quiet:
+                    print("mAP after Enhancement")
+                    if isinstance(vals, tuple):
+                        print(">> {}: mAP E: {}, M: {}, H: {}".format(dataset, *(np.around(v * 100, decimals=2) for v in vals)))
+                    else:
+                        print(">> {}: mAP {:.2f}".format(dataset, np.around(vals * 100, decimals=2)))
+        finally:
+            g.close()
         return out
     from . import diffusion
     return diffusion.qge_small_hip(ranks, qvecs, vecs, dataset, gnd, AQE=AQE, K=K, device=device, quiet=quiet)

@@ -145,6 +145,15 @@ int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int
  * queries like the gallery, otherwise an mi_norm value (MI_NORM_NONE for an already expanded query). */
 int mi_rank_all(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
                 int query_norm, int64_t* out_idx, float* out_score, double* out_seconds);
+/* The first `keep` columns of that ranking only ([nq, keep] outputs): K beyond the top-K path's limit without [nq, N] host
+ * arrays (matching_HIP with 2048 < K < N). */
+int mi_rank_prefix(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                   int query_norm, int64_t keep, int64_t* out_idx, float* out_score, double* out_seconds);
+/* Zero-based positions, in that same full ranking, of m listed rows per query (row_ids [nq, m], global ids, entries
+ * outside the shard -> -1), computed by counting on the device: what compute_map2 needs of `ranks_aqe` [N, Q]
+ * (src/utils/Reranking.py:280-283, src/utils/evaluate2.py:73-86) without the [N, Q] array.  m <= 2048. */
+int mi_rank_positions(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                      int query_norm, const int64_t* row_ids, int32_t m, int64_t* out_pos);
 
 /* ---- truncated graph diffusion: Diffusion.get_offline_results (src/utils/diffusion.py:52-84 with :15-19, :87-116)
  * on a MI_NORM_NONE gallery of the features.  out_ids [n][n_trunc] (the kNN lists = columns of the sparse

@@ -123,6 +123,18 @@ def main():
         idxz, _ = nn.matching_L2(64, gz, q)
     np.savez_compressed(os.path.join(GOLD, "matching_l2_edge.npz"), g=g, q=q, idx=idx, gz=gz, idxz=idxz)
 
+    # ---- matching_fractional_dis (src/utils/nnsearch.py:709-731): p = 2, same ordering as matching_L2; more queries than
+    # K and fewer queries than K (the function slices the QUERY axis by K)
+    out = {}
+    for tag, (seed, n, d, nq, k) in (("a", (14, 600, 48, 12, 10)), ("b", (15, 500, 40, 5, 20))):
+        for dt in (np.float32, np.float64):
+            g = synth_rows(seed, 0, n, d, dt)
+            q = synth_rows(seed + 1000, 0, nq, d, dt)
+            idx, _ = nn.matching_fractional_dis(k, g, q)
+            out[f"{tag}_{np.dtype(dt).name}_meta"] = np.array([seed, n, d, nq, k], dtype=np.int64)
+            out[f"{tag}_{np.dtype(dt).name}_idx"] = idx
+    np.savez_compressed(os.path.join(GOLD, "fractional.npz"), **out)
+
     # ---- a2 IP ranker (src/main_retrieve.py:175-176 is inline code; the same two numpy calls are
     # executed here on the reference-layout inputs)
     seed, n, d, nq = 21, 2000, 96, 6

@@ -8,7 +8,7 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 __all__ = [
-    "matching_l2", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
+    "matching_l2", "matching_fractional_dis", "fractional_distance", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
     "extract_ms_tail", "knn_flat_ip", "knn_flat_ip_blas", "compute_ap2", "compute_map2", "compute_map_revisited",
     "get_affinity", "get_laplacian", "diffusion_offline", "diffusion_online", "qge_small",
     "average_query_expansion", "database_augmentation", "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
@@ -32,6 +32,27 @@ def matching_l2(K, gallery, queries):
         d = np.linalg.norm(qn[r, :] - gn, axis=1)
         out[r, :] = np.argsort(d)[:K]
     return out
+
+
+def fractional_distance(x, y, p=0.5):
+    """src/utils/nnsearch.py:46-56 -- dist[i, j] = (sum_k |x[i,k] - y[j,k]| ** p) ** (1/p) through an [N, M, d] temporary."""
+    diff = np.abs(np.expand_dims(x, axis=1) - np.expand_dims(y, axis=0))
+    return np.sum(diff ** p, axis=-1) ** (1 / p)
+
+
+def matching_fractional_dis(K, gallery, queries):
+    """src/utils/nnsearch.py:709-731 (matching_fractional_dis), called with p = 2, i.e. the ordering of matching_L2.
+
+    Normalisation as in matching_L2 (no eps, :715-720), one [Q, N] distance matrix (:721), a full argsort along the
+    gallery axis (:723) -- and then `[:K]` on the QUERY axis before `[:, :K]` (:723-724): the reference returns the
+    rankings of the first K queries only, shape [min(Q, K), K].  Restated as written."""
+    gallery = np.asarray(gallery)
+    queries = np.asarray(queries)
+    gn = gallery / np.expand_dims(np.linalg.norm(gallery, axis=1), axis=1)
+    qn = queries / np.expand_dims(np.linalg.norm(queries, axis=1), axis=1)
+    dist = fractional_distance(qn, gn, 2)
+    idx = np.argsort(dist)[:K]
+    return idx[:, :K]
 
 
 # --------------------------------------------------------------------------- a2

@@ -1,0 +1,83 @@
+"""Rank program of tests/test_gpu_sharded_ranks.py: started as fresh processes by `python -m torch.distributed.run`
+(the launcher itself never touches the GPU).  All ranks share cuda:0 (ISEHR_SHARE_GPU=1) and talk over gloo, because
+RCCL refuses two ranks on one device; the code path is the one bench.py --gpus N runs over RCCL on a whole node:
+ShardedGallery.__init__ (agreement on norm bounds / image type), search(verify=True) and aqe_search with world > 1.
+
+Every rank writes <out>.<rank>.npz with its answers; rank 0 also computes the single-shard answers of the same gallery."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--rows", type=int, default=60000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--hetero", action="store_true",
+                    help="un-normalised gallery whose later rows are 60x larger: shards with different norm bounds, "
+                         "the large-row shards fall back to a bf16 image on their own")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import isehr_amd  # noqa: F401
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery, shard_bounds
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, d, nq, k = a.rows, a.dim, a.queries, a.topk
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), 77, 0, n, d, stream)
+    q = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(q.data_ptr(), 78, 0, nq, d, stream)
+    torch.cuda.synchronize()
+    norm = _lib.NORM_L2
+    if a.hetero:
+        norm = _lib.NORM_NONE
+        raw *= 0.05
+        raw[n // 3:] *= 60.0                      # rows of norm ~ 0.8 and ~ 48 in one gallery
+        q *= 0.1
+    lo, hi = shard_bounds(n, world, rank)
+    shard = _lib.Gallery.from_device_ptr(raw[lo:hi].data_ptr(), hi - lo, d, norm_mode=norm, row_offset=lo)
+    own_dtype = int(shard.get_option("image_dtype"))
+    own_bounds = shard.norm_bounds()
+    sg = ShardedGallery(shard)
+    idx, sc = sg.search(q, k, verify=True)
+    idx, sc = idx.clone(), sc.clone()
+    aidx, asc, qx = sg.aqe_search(idx.t(), 3, 4.0, k)
+    torch.cuda.synchronize()
+    flagged = sg.any_flag()
+    out = dict(idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), aidx=aidx.cpu().numpy(), asc=asc.cpu().numpy(),
+               qx=qx.cpu().numpy(), own_dtype=own_dtype, agreed_dtype=int(shard.get_option("image_dtype")),
+               own_bounds=np.array(own_bounds), agreed_bounds=np.array(shard.norm_bounds()), flagged=int(flagged),
+               lo=lo, hi=hi)
+    if rank == 0:
+        single = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d, norm_mode=norm)
+        ridx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        rsc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        single.search_device(q.data_ptr(), nq, k, ridx.data_ptr(), rsc.data_ptr(), None, stream)
+        torch.cuda.synchronize()
+        assert single.flags() == 0
+        ref_idx = ridx.cpu().numpy()
+        r_aidx, r_asc, r_qx, _ = single.aqe_search(np.ascontiguousarray(ref_idx.T), 3, 4.0, k, return_qexp=True)
+        out.update(ref_idx=ref_idx, ref_sc=rsc.cpu().numpy(), ref_aidx=r_aidx, ref_asc=r_asc, ref_qx=r_qx,
+                   single_dtype=int(single.get_option("image_dtype")))
+        single.close()
+    np.savez(a.out + ".%d.npz" % rank, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    shard.close()
+
+
+if __name__ == "__main__":
+    main()

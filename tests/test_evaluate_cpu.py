@@ -26,3 +26,26 @@ def test_map_edge_cases():
     assert mp == 1.0 and np.isnan(aps[1])          # positive 2 sits behind two junk entries -> rank 0
     mo, _ = oracle.compute_map2(ranks, gnd)
     assert mo == mp
+
+
+def test_map_from_positions_equals_map_of_the_full_ranking():
+    """compute_map_from_positions (positions of the labelled images only) == compute_map on the complete ranking, and a
+    truncated ranking scores lower when a positive lies beyond the cut -- the gap the QGE large-N branch must not have."""
+    import numpy as np
+    from isehr_amd import evaluate
+    rng = np.random.default_rng(3)
+    n, nq = 5000, 9
+    ranks = np.stack([rng.permutation(n) for _ in range(nq)], axis=1)           # [N, Q]
+    gnd = []
+    for i in range(nq):
+        ids = rng.choice(n, size=40, replace=False)
+        gnd.append({"easy": ids[:10], "hard": ids[10:25], "junk": ids[25:]})
+    inv = np.empty_like(ranks)
+    for i in range(nq):
+        inv[ranks[:, i], i] = np.arange(n)
+    position_of = [{int(v): int(inv[v, i]) for k in ("easy", "hard", "junk") for v in gnd[i][k]} for i in range(nq)]
+    full = evaluate.compute_map_revisited(ranks, gnd)
+    got = evaluate.compute_map_revisited_from_positions(gnd, position_of)
+    assert np.allclose(full, got, rtol=0, atol=1e-15)
+    cut = evaluate.compute_map_revisited(ranks[:1000], gnd)
+    assert all(c < f for c, f in zip(cut, full))

@@ -278,3 +278,23 @@ def test_bf16_image_path_gives_the_same_answers(lib, golden_dir):
     assert res["f16"][2] < res["bf16"][2]            # tighter certificate -> fewer rows re-scored
     s = oracle.exact_scores_f64(g, q)
     assert oracle.check_topk_parity(res["bf16"][0], s, k, TAU) == []
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_matching_fractional_dis_vs_reference_golden(lib, golden_dir, tag, dt):
+    """matching_fractional_dis (src/utils/nnsearch.py:709-731, p = 2): same ordering as matching_L2, and the reference's
+    return shape [min(Q, K), K] (it slices the query axis by K)."""
+    from isehr_amd.nnsearch import matching_fractional_dis_hip
+    z = np.load(os.path.join(golden_dir, "fractional.npz"))
+    seed, n, d, nq, k = (int(v) for v in z[f"{tag}_{dt}_meta"])
+    g = synth_rows(seed, 0, n, d, np.dtype(dt))
+    q = synth_rows(seed + 1000, 0, nq, d, np.dtype(dt))
+    idx, tpq = matching_fractional_dis_hip(k, g, q)
+    ref = z[f"{tag}_{dt}_idx"]
+    assert idx.shape == ref.shape == (min(nq, k), k) and idx.dtype == np.int64 and tpq > 0
+    s = oracle.exact_scores_f64(g, q[:k])
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
+    assert np.abs(np.take_along_axis(s, idx, 1) - np.take_along_axis(s, ref, 1)).max() <= TAU
+    if dt == "float64":
+        assert np.array_equal(idx, ref)

@@ -348,3 +348,54 @@ def test_aqe_and_dba_vs_reference_golden(golden_dir):
         got = fn(qv, vecs, 50)
         assert got.shape == (50, 11) and (got == z[key]).mean() > 0.97, (key, (got == z[key]).mean())
         assert (got[0] == z[key][0]).all()
+
+
+def test_rank_positions_and_prefix_equal_the_full_ranking():
+    """mi_rank_positions / mi_rank_prefix against mi_rank_all on a gallery with exact ties."""
+    from isehr_amd._lib import Gallery, NORM_NONE
+    g = synth_rows(93, 0, 5000, 40)
+    g[200:230] = g[11]                                          # 31 exact ties
+    q = np.concatenate([g[[11, 4000]], synth_rows(94, 0, 3, 40)])
+    G = Gallery.from_host(g, norm_mode=NORM_NONE)
+    try:
+        full, _ = G.rank_all(q)
+        inv = np.empty_like(full)
+        for i in range(len(q)):
+            inv[i, full[i]] = np.arange(5000)
+        ids = np.stack([np.concatenate([[11, 215, 229, 200, 4999, 0], np.arange(300, 340), [-1, -1]]) for _ in range(len(q))])
+        pos = G.rank_positions(q, ids)
+        assert (pos[:, -2:] == -1).all()
+        assert np.array_equal(pos[:, :-2], np.take_along_axis(inv, ids[:, :-2], 1))
+        pre, sc, _ = G.rank_prefix(q, 3000, return_scores=True)
+        assert np.array_equal(pre, full[:, :3000]) and (np.diff(sc, axis=1) <= 0).all()
+    finally:
+        G.close()
+
+
+def test_qge_large_branch_map_is_the_full_ranking_map():
+    """QGE for N >= 120000 (src/utils/Reranking.py:273-284): the printed mAP is the mAP of the COMPLETE ranking
+    (:206-207, :280-283).  Positives are planted far beyond rank 2048 (weak matches among 130k rows), so a top-K
+    evaluation would report less."""
+    from isehr_amd.reranking import QGE_hip
+    from isehr_amd.nnsearch import ip_topk_hip
+    from isehr_amd import evaluate
+    n, d, nq = 130000, 48, 8
+    vecs, qv, gnd = planted_dataset(43, n, d, nq, n_pos=(30, 40), sigmas=(0.35, 4.0, 6.0))
+    base, _ = ip_topk_hip(vecs, qv, 10)
+    out = QGE_hip(base, qv, vecs, "roxford5k", gnd, quiet=True)
+    qx_ref, ranks_ref = oracle.feature_enhancement(3, base, vecs, 4.0)
+    ref = oracle.compute_map_revisited(ranks_ref, gnd)
+    assert np.allclose(out["map_aqe"], ref, rtol=0, atol=1e-6), (out["map_aqe"], ref)
+    # the labelled images really do sit deeper than the top-K path reaches, and a K = 1000 cut scores lower
+    deepest = max(max(p.values()) for p in out["positions"])
+    assert deepest > 2048
+    cut = evaluate.compute_map_revisited(ranks_ref[:1000], gnd)
+    assert cut[1] < ref[1] - 1e-3
+    # positions equal the oracle's (f32 near-ties aside: compare through the scores)
+    inv = np.empty_like(ranks_ref)
+    for i in range(nq):
+        inv[ranks_ref[:, i], i] = np.arange(n)
+    for i in range(nq):
+        ids = np.array(sorted(out["positions"][i]))
+        got = np.array([out["positions"][i][int(v)] for v in ids])
+        assert np.abs(got - inv[ids, i]).max() <= 2

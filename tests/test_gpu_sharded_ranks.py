@@ -1,0 +1,59 @@
+"""GPU: the multi-rank code path itself -- ShardedGallery with world > 1 (packed all-gathers, strided merge, all-reduced
+flags, sharded alpha-QE) -- run by 2 and 3 fresh rank processes that share the one GPU of the test box and talk over
+gloo.  Answers must equal the single-shard answers bit for bit, on every rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, tmp_path, extra=()):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / ("w%d" % world))
+    env = dict(os.environ, ISEHR_DIST_BACKEND="gloo", ISEHR_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"),
+           "--out", out, *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return [np.load(out + ".%d.npz" % rk) for rk in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_equal_single_shard(world, tmp_path):
+    res = _run(world, tmp_path)
+    z0 = res[0]
+    for z in res:
+        assert int(z["flagged"]) == 0
+        assert np.array_equal(z["idx"], z0["ref_idx"]) and np.array_equal(z["sc"], z0["ref_sc"])
+        assert np.array_equal(z["aidx"], z0["ref_aidx"]) and np.array_equal(z["asc"], z0["ref_asc"])
+        assert np.abs(z["qx"].astype(np.float64) - z0["ref_qx"]).max() < 1e-7        # f32 rounding of the f64 query
+    assert res[-1]["hi"] == 60000 and all(int(a["hi"]) == int(b["lo"]) for a, b in zip(res, res[1:]))
+
+
+def test_sharded_ranks_with_unequal_norm_bounds(tmp_path):
+    """Raw (MI_NORM_NONE) gallery whose rows differ 60x in norm: the shards measure different rounding norms and the
+    large-row shards pick a bf16 image by themselves.  ShardedGallery makes all of them use the coarsest image type and
+    the maxima over all shards (otherwise a shard with a small margin can drop a row of the global top-K); the merged
+    answers equal the single gallery's."""
+    res = _run(3, tmp_path, ("--hetero",))
+    z0 = res[0]
+    own = [int(z["own_dtype"]) for z in res]
+    assert own[0] == 1 and own[-1] == 0                          # fp16 on the small-row shard, bf16 on the large-row one
+    assert all(int(z["agreed_dtype"]) == 0 for z in res)
+    bounds = np.stack([z["agreed_bounds"] for z in res])
+    assert (bounds == bounds[0]).all()
+    assert (bounds[0] >= np.stack([z["own_bounds"] for z in res]).max(0) - 1e-6).all() or \
+        int(z0["own_dtype"]) != int(z0["agreed_dtype"])           # re-imaged shards re-measure their own norms
+    assert int(z0["single_dtype"]) == 0
+    for z in res:
+        assert np.array_equal(z["idx"], z0["ref_idx"]) and np.array_equal(z["sc"], z0["ref_sc"])
+        assert np.array_equal(z["aidx"], z0["ref_aidx"]) and np.array_equal(z["asc"], z0["ref_asc"])

@@ -85,3 +85,39 @@ def test_tile_kernel_structures_agree(lib):
         assert oracle.check_topk_parity(res[0][0], s, 50, TAU) == []
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("img", ["f16", "bf16"])
+def test_large_shard_chunk_schedule_equals_exact_path(lib, img):
+    """A shard of more than 160 x 8192 rows (the per-GPU shard of BASELINE configs[3], 10M rows over 8 GPUs, has
+    1.25 M) is too large for the sample-based single launch: the geometric chunk schedule of csrc/api.hip phase1_batch
+    (rigorous thresholds from the rows seen so far, then one speculative launch for the rest) answers it.  Must equal
+    the f32-scored path bit for bit; bf16 is the image type configs[3] names."""
+    n, d, nq, k = 1600000, 256, 300, 100
+    raw = _device_rows(lib, 51, n, d)
+    q = _device_rows(lib, 52, nq, d)
+    import torch
+    raw[1234567] = q[5] * 2.0                                   # a planted exact match deep inside the shard
+    torch.cuda.synchronize()
+    lib.set_global_option("image_dtype", 1 if img == "f16" else 0)
+    try:
+        g = lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+    finally:
+        lib.set_global_option("image_dtype", 1)
+    del raw
+    try:
+        idx, sc = _search(g, q, k)
+        st = g.status()
+        assert st["overflow_batches"] == 0
+        assert idx[5, 0] == 1234567 and abs(sc[5, 0] - 1.0) < 1e-6
+        g.set_option("force_exact", 1)
+        idx_e, sc_e = _search(g, q, k)
+        assert np.array_equal(idx, idx_e) and np.array_equal(sc, sc_e)
+        # the speculative part off: rigorous chunks only
+        g.set_option("force_exact", 0)
+        g.set_option("speculative", 0)
+        idx_r, sc_r = _search(g, q, k)
+        assert np.array_equal(idx, idx_r) and np.array_equal(sc, sc_r)
+        assert g.status()["overflow_batches"] == 0
+    finally:
+        g.close()

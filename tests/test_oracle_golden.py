@@ -139,3 +139,16 @@ def test_blas_style_flat_ip_equals_the_plain_restatement():
         s0, i0 = oracle.knn_flat_ip(db, q, k)
         s1, i1 = oracle.knn_flat_ip_blas(db, q, k)
         assert np.array_equal(i0, i1) and np.array_equal(s0, s1)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_matching_fractional_dis_bitexact(golden_dir, tag, dt):
+    """src/utils/nnsearch.py:709-731, including its slicing of the query axis by K."""
+    z = _load(golden_dir, "fractional.npz")
+    seed, n, d, nq, k = (int(v) for v in z[f"{tag}_{dt}_meta"])
+    g = synth_rows(seed, 0, n, d, np.dtype(dt))
+    q = synth_rows(seed + 1000, 0, nq, d, np.dtype(dt))
+    idx = oracle.matching_fractional_dis(k, g, q)
+    assert idx.shape == (min(nq, k), k)
+    assert np.array_equal(idx, z[f"{tag}_{dt}_idx"])
