@@ -76,6 +76,8 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, c_f64p]),
     "mi_rank_positions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int,
                                     C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_kr_rerank": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                               C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     "mi_diffusion_offline": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -470,6 +472,23 @@ def desc_ms_accumulate_device(acc_ptr, desc_ptr, count, msp, first, stream=None)
 
 def desc_ms_finish_device(acc_ptr, b, d, nscales, msp, stream=None):
     check(load().mi_desc_ms_finish_device(C.c_void_p(acc_ptr), b, d, nscales, float(msp), C.c_void_p(stream)))
+
+
+def kr_rerank(queries, gallery, k1=20, k2=6, lambda_value=0.3, device=0, return_dist=False):
+    """queries [Q, D], gallery [N, D] (any float strides) -> indices int64 [Q, N][, final distances float32 [Q, N]]."""
+    q, code, qrs, qcs = _strided(queries)
+    g, gcode, grs, gcs = _strided(gallery)
+    if gcode != code:
+        g = g.astype(q.dtype)
+        g, gcode, grs, gcs = _strided(g)
+    if q.shape[1] != g.shape[1]:
+        raise ValueError("query dimension %d != gallery dimension %d" % (q.shape[1], g.shape[1]))
+    idx = np.empty((q.shape[0], g.shape[0]), dtype=np.int64)
+    dist = np.empty((q.shape[0], g.shape[0]), dtype=np.float32) if return_dist else None
+    check(load().mi_kr_rerank(C.c_void_p(_base_pointer(q)), q.shape[0], qrs, qcs, C.c_void_p(_base_pointer(g)), g.shape[0],
+                              grs, gcs, q.shape[1], code, int(k1), int(k2), float(lambda_value), int(device),
+                              idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p) if return_dist else None))
+    return (idx, dist) if return_dist else idx
 
 
 def set_global_option(name, value):

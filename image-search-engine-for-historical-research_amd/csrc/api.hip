@@ -835,7 +835,7 @@ int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
 int mi_kth_of_gathered_device(const float* gathered_dev, int32_t nshards, int64_t nq, int32_t k, float* out_L_dev,
                               void* stream) {
   REQUIRE(gathered_dev && out_L_dev, "null pointer");
-  REQUIRE(nshards >= 1 && (int64_t)nshards * k <= 16384, "nshards * k too large");
+  REQUIRE(nshards >= 1 && (int64_t)nshards * k <= 8192, "nshards * k too large (the merge takes at most 8192 entries per query)");
   launch_kth_of_gathered(gathered_dev, nshards, nq, k, out_L_dev, (hipStream_t)stream);
   HIPC(hipGetLastError());
   return MI_OK;
@@ -1236,6 +1236,92 @@ int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_
   HIPC(hipGetLastError());
   HIPC(hipDeviceSynchronize());
   HIPC(hipMemcpy(out, yd, (size_t)n * dims * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_kr_rerank(const void* qvecs, int64_t nq, int64_t q_row_stride, int64_t q_col_stride, const void* vecs, int64_t n,
+                 int64_t v_row_stride, int64_t v_col_stride, int32_t d, int dtype, int32_t k1, int32_t k2,
+                 double lambda_value, int device, int64_t* out_idx, float* out_dist) {
+  REQUIRE(qvecs && vecs && out_idx, "null pointer");
+  REQUIRE(nq >= 1 && n >= 1 && d >= 1, "bad sizes");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  const int64_t all = nq + n;
+  REQUIRE(all <= 32768, "k-reciprocal re-ranking holds all x all arrays: at most 32768 images (queries + gallery)");
+  REQUIRE(k1 >= 1 && k1 + 1 <= 64 && k1 + 1 <= all, "k1 must be in [1, min(63, all - 1)]");
+  REQUIRE(k2 >= 1 && k2 <= k1 + 1, "k2 must be in [1, k1 + 1]");
+  const int khalf = (int)nearbyint(k1 / 2.0);
+  REQUIRE((k1 + 1) * (khalf + 2) <= kr_rmax(), "k1 too large for the reciprocal-set buffers");
+  HIPC(hipSetDevice(device));
+  int64_t qe, ve;
+  int rc = strided_extent(nq, d, q_row_stride, q_col_stride, &qe);
+  if (rc == MI_OK) rc = strided_extent(n, d, v_row_stride, v_col_stride, &ve);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  const int32_t dp = (int32_t)round_up(d, 16);
+  const int64_t all_pad = round_up(all, 64);
+  const int ld = k1 + 1;
+  TmpAlloc tmp;
+  char* qd = tmp.get<char>((size_t)qe * esz);
+  char* vd = tmp.get<char>((size_t)ve * esz);
+  float* feat = tmp.get<float>((size_t)all_pad * dp);
+  float* S = tmp.get<float>((size_t)all * all);
+  int64_t* rank = tmp.get<int64_t>((size_t)all * ld);
+  int32_t* R = tmp.get<int32_t>((size_t)all * kr_rmax());
+  int32_t* Rcnt = tmp.get<int32_t>((size_t)all);
+  float* V = tmp.get<float>((size_t)all * kr_rmax());
+  float* dmax = tmp.get<float>((size_t)all);
+  uint16_t* Vqe = tmp.get<uint16_t>((size_t)all * all);
+  uint16_t* VqeT = tmp.get<uint16_t>((size_t)all * all);
+  uint32_t* flags = tmp.get<uint32_t>(4);
+  float* negf = tmp.get<float>((size_t)nq * n);
+  uint32_t* ka = tmp.get<uint32_t>((size_t)nq * n);
+  uint32_t* ia = tmp.get<uint32_t>((size_t)nq * n);
+  uint32_t* kb = tmp.get<uint32_t>((size_t)nq * n);
+  uint32_t* ib = tmp.get<uint32_t>((size_t)nq * n);
+  int64_t* oi = tmp.get<int64_t>((size_t)nq * n);
+  float* os = tmp.get<float>((size_t)nq * n);
+  if (!qd || !vd || !feat || !S || !rank || !R || !Rcnt || !V || !dmax || !Vqe || !VqeT || !flags || !negf || !ka || !ia ||
+      !kb || !ib || !oi || !os)
+    return fail(MI_ERR_NOMEM, "k-reciprocal buffers");
+  hipStream_t s = nullptr;
+  HIPC(hipMemcpy(qd, qvecs, (size_t)qe * esz, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(vd, vecs, (size_t)ve * esz, hipMemcpyHostToDevice));
+  HIPC(hipMemsetAsync(feat, 0, (size_t)all_pad * dp * 4, s));
+  HIPC(hipMemsetAsync(flags, 0, 16, s));
+  // feat = [queries; gallery] (torch.cat([probFea, galFea]), :555)
+  launch_kr_pack(qd, dtype, nq, d, q_row_stride, q_col_stride, feat, dp, s);
+  launch_kr_pack(vd, dtype, n, d, v_row_stride, v_col_stride, feat + (size_t)nq * dp, dp, s);
+  // all x all inner products, k-ordered f32 fmaf chains (both S[i, j] and S[j, i] are the same chain)
+  ExactArgs a;
+  a.gal_f32 = feat;
+  a.qry_f32 = feat;
+  a.dp = dp;
+  a.row0 = 0;
+  a.row1 = all;
+  a.n = all;
+  a.nq = (int32_t)all;
+  a.st = QueryState{};
+  a.dense_out = S;
+  a.dense_ld = all;
+  launch_exact_select(a, false, s);
+  // initial_rank: the k1 + 1 nearest of every image among all images, itself included (:555)
+  launch_dense_topk(S, all, all, (int32_t)all, ld, 0, rank, nullptr, s);
+  launch_kr_sets(rank, ld, (int)all, k1, R, Rcnt, flags, s);
+  launch_kr_weights(S, (int)all, R, Rcnt, V, dmax, s);
+  launch_kr_expand(rank, ld, k2, (int)all, R, Rcnt, V, Vqe, VqeT, s);
+  launch_kr_final(Vqe, VqeT, S, dmax, (int)all, (int)nq, (float)(1.0 - lambda_value), (float)lambda_value, negf, flags, s);
+  // np.argsort(final_dist, axis=1) (:618): ascending distance = descending -distance, ties to the lower index
+  launch_rank_all(negf, n, n, (int32_t)nq, ka, ia, kb, ib, 0, oi, os, s);
+  HIPC(hipGetLastError());
+  HIPC(hipDeviceSynchronize());
+  uint32_t fl = 0;
+  HIPC(hipMemcpy(&fl, flags, 4, hipMemcpyDeviceToHost));
+  if (fl) return fail(MI_ERR_OVERFLOW, "k-reciprocal set buffers overflowed");
+  HIPC(hipMemcpy(out_idx, oi, (size_t)nq * n * 8, hipMemcpyDeviceToHost));
+  if (out_dist) {
+    HIPC(hipMemcpy(out_dist, os, (size_t)nq * n * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < nq * n; ++i) out_dist[i] = -out_dist[i];
+  }
   return MI_OK;
 }
 

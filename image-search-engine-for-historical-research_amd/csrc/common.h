@@ -20,6 +20,11 @@ constexpr int SLICE_K = 32;   // K-depth of one slice = one v_mfma_f32_16x16x32_
 constexpr int SLICE_ELEMS = TILE * SLICE_K;          // 8192 elements = 16 KiB
 constexpr int SLICE_BYTES = SLICE_ELEMS * 2;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): a process that opens handles on
+// several devices has to opt every kernel in on each of them.  Returns the current device.
+int ensure_dynamic_lds(const void* kernel, int bytes = 160 * 1024);
+int current_device_cus();     // compute units of the current device (cached per device)
+
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 __host__ __device__ __forceinline__ uint32_t swz_chunk(uint32_t row, uint32_t c) {

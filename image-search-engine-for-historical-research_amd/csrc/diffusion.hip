@@ -190,11 +190,7 @@ void launch_diffusion_cg(const int64_t* ids, int64_t ld, int64_t n, int32_t T, i
                          const float* diag, int32_t maxiter, double tol, int32_t* map_all, unsigned grid,
                          int32_t* out_ids, float* out_vals, hipStream_t stream) {
   const size_t lds = (((size_t)T * 4 + 15) / 16) * 16 + (size_t)T * 8 * 4 + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)diffusion_cg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  ensure_dynamic_lds((const void*)diffusion_cg_kernel);
   hipLaunchKernelGGL(diffusion_cg_kernel, dim3(grid), dim3(256), lds, stream, ids, ld, n, T, kd, lap, diag, maxiter,
                      tol, map_all, out_ids, out_vals);
 }

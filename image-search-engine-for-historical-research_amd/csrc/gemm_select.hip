@@ -769,15 +769,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
 }
 
 static unsigned persistent_grid() {
-  static unsigned cached = 0;
-  if (!cached) {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    cached = (unsigned)(cus / 8) * 8u;
-    if (cached < 8) cached = 8;
-  }
-  return cached;
+  const unsigned g = (unsigned)(current_device_cus() / 8) * 8u;   // one workgroup per CU, whole XCDs
+  return g < 8 ? 8 : g;
 }
 
 unsigned gemm_select_grid() { return persistent_grid(); }
@@ -834,23 +827,13 @@ void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_
 
 template <bool FIRST, int DBG, bool F16, bool REPAIR = false>
 static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_select_kernel<FIRST, DBG, F16, REPAIR>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  ensure_dynamic_lds((const void*)gemm_select_kernel<FIRST, DBG, F16, REPAIR>);
   hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
 template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER>
 static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>);
   hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 

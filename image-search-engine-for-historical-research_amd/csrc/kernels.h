@@ -104,6 +104,19 @@ void launch_diffusion_combine(const int64_t* nn_idx, const float* nn_sims, int32
                               const int32_t* off_ids, const float* off_vals, int32_t T, int64_t n, int32_t nq,
                               float* dense, hipStream_t stream);
 
+// kr_rerank.hip -- k-reciprocal re-ranking (src/utils/Reranking.py:447-624)
+void launch_kr_pack(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, float* out, int32_t dp,
+                    hipStream_t stream);
+void launch_kr_sets(const int64_t* rank, int ld, int all, int k1, int32_t* R, int32_t* Rcnt, uint32_t* flags,
+                    hipStream_t stream);
+void launch_kr_weights(const float* S, int all, const int32_t* R, const int32_t* Rcnt, float* V, float* dmax,
+                       hipStream_t stream);
+void launch_kr_expand(const int64_t* rank, int ld, int k2, int all, const int32_t* R, const int32_t* Rcnt, const float* V,
+                      void* Vqe, void* VqeT, hipStream_t stream);
+void launch_kr_final(const void* Vqe, const void* VqeT, const float* S, const float* dmax, int all, int nq, float w_jac,
+                     float w_org, float* neg_final, uint32_t* flags, hipStream_t stream);
+int kr_rmax();
+
 // whiten.hip
 void launch_whiten(const void* X, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, const double* m,
                    const double* P, int32_t dims, double eps, double* Y, hipStream_t stream);

@@ -3,10 +3,41 @@
 // multi-shard merge.  Together they replace the `np.argsort(dist)[:K]` of matching_L2
 // (src/utils/nnsearch.py:703) and `np.argsort(-scores, axis=0)` of src/utils/Reranking.py:207 for the
 // top-K the callers actually consume (src/online.py:152, src/test_rOP1m.py:157-159).
+#include <map>
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace mi {
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert({kernel, dev}).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return dev;
+}
+
+int current_device_cus() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 256;
+  (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+  cus[dev] = n;
+  return n;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // block-wide K-th largest key among keys[0..n) held in LDS (MSB-first 8-bit radix select).
@@ -250,6 +281,7 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
                             hipStream_t stream) {
   const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;      // keys | hist[256] | sh[8]
   auto go = [&](auto kern) {
+    ensure_dynamic_lds((const void*)kern);                     // survivor_cap = 16384 needs 66.6 KB
     hipLaunchKernelGGL(kern, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local, stats2, spec_r, spec,
                        repair, cond);
   };
@@ -526,7 +558,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
                  int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64,
                  hipStream_t stream) {
-  // rcap is a power of two (enforced by the host), LDS = rcap * 12
+  // rcap is a power of two (enforced by the host), LDS = rcap * 12 (96 KiB at rescore_cap = 8192)
+  ensure_dynamic_lds((const void*)emit_kernel);
   hipLaunchKernelGGL(emit_kernel, dim3(nq), dim3(256), (size_t)rcap * 12, stream, cand_rows, cand_cnt, cand_score,
                      rcap, k, row_offset, out_idx, out_score, out_score64);
 }
@@ -554,6 +587,7 @@ __global__ __launch_bounds__(256) void kth_of_gathered_kernel(const float* __res
 void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, int32_t k, float* out_L,
                             hipStream_t stream) {
   const size_t lds = (size_t)nshards * k * 4 + 256 * 4 + 16;
+  ensure_dynamic_lds((const void*)kth_of_gathered_kernel);
   hipLaunchKernelGGL(kth_of_gathered_kernel, dim3((unsigned)nq), dim3(256), lds, stream, gathered, nshards, nq, k,
                      out_L);
 }
@@ -593,11 +627,7 @@ void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, in
                   int64_t* out_idx, float* out_score, hipStream_t stream) {
   uint32_t n2 = 2;
   while (n2 < (uint32_t)nshards * (uint32_t)k) n2 <<= 1;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  ensure_dynamic_lds((const void*)merge_kernel);
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), (size_t)n2 * 16, stream, score64, idx, nshards, nq,
                      k, shard_stride, out_idx, out_score);
 }

@@ -226,12 +226,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
 template <int NQB, bool F16, int MODE>
 static void launch_stream_variant(const ScoreArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)SS_DEPTH * SLICE_BYTES + (size_t)SS_DEPTH * NQB * 1024 + NQB * 16 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)stream_select_kernel<NQB, F16, MODE>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  ensure_dynamic_lds((const void*)stream_select_kernel<NQB, F16, MODE>);
   const unsigned grid = MODE == 2 ? (unsigned)a.ntiles * (unsigned)((a.nq + NQB * 16 - 1) / (NQB * 16)) : gemm_select_grid();
   hipLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(grid), dim3(512), lds, stream, a);
 }

@@ -156,3 +156,12 @@ def database_augmentation_hip(qvecs, vecs, K, top_k=3, device=0):
     finally:
         orig.close()
     return matching_HIP(K, r_new, q_new, device=device)[0].T
+
+
+def kr_reranking_hip(qvecs, vecs, k1=20, k2=6, lambda_value=0.3, device=0, return_dist=False):
+    """kr_reranking(qvecs, vecs) (src/utils/Reranking.py:447-624): k-reciprocal re-ranking of all queries against the
+    whole database; qvecs [D, Q], vecs [D, N] L2-normalised columns as there.  Returns `indices` int64 [Q, N] like the
+    reference (`return indices`, :623: not transposed).  All x all inner products, reciprocal sets, the float16 encodings
+    and the Jaccard pass run on the GPU (csrc/kr_rerank.hip)."""
+    from . import _lib
+    return _lib.kr_rerank(np.asarray(qvecs).T, np.asarray(vecs).T, k1, k2, lambda_value, device, return_dist)

@@ -155,6 +155,14 @@ int mi_rank_prefix(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t 
 int mi_rank_positions(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
                       int query_norm, const int64_t* row_ids, int32_t m, int64_t* out_pos);
 
+/* ---- k-reciprocal re-ranking: kr_reranking(qvecs, vecs) of src/utils/Reranking.py:447-624 (k1 = 20, k2 = 6,
+ * lambda = 0.3 there).  qvecs [nq, d], vecs [n, d] host arrays (element strides; the reference takes the [d, .] arrays and
+ * transposes), rows assumed L2-normalised like the reference assumes.  out_idx [nq, n]: gallery indices by ascending final
+ * distance (= the reference's returned `indices`); out_dist (may be NULL): those distances.  nq + n <= 32768. */
+int mi_kr_rerank(const void* qvecs, int64_t nq, int64_t q_row_stride, int64_t q_col_stride, const void* vecs, int64_t n,
+                 int64_t v_row_stride, int64_t v_col_stride, int32_t d, int dtype, int32_t k1, int32_t k2,
+                 double lambda_value, int device, int64_t* out_idx, float* out_dist);
+
 /* ---- truncated graph diffusion: Diffusion.get_offline_results (src/utils/diffusion.py:52-84 with :15-19, :87-116)
  * on a MI_NORM_NONE gallery of the features.  out_ids [n][n_trunc] (the kNN lists = columns of the sparse
  * `offline` matrix), out_vals [n][n_trunc] f32 (its values), out_knn_sims (may be NULL).  The result also stays

@@ -206,6 +206,24 @@ def main():
     rr.compute_map_and_print2 = orig
     np.savez_compressed(os.path.join(GOLD, "aqe_dba.npz"), ranks_aqe=captured["aqe"], ranks_dba=captured["dba"])
 
+    # ---- f-4: kr_reranking (src/utils/Reranking.py:447-624).  The function moves its feature matrix to the GPU with
+    # `.cuda()` (:556); there is no GPU in the build container, so for this one call Tensor.cuda is the identity (the torch
+    # CPU kernels run the same float32 arithmetic).  Clustered, L2-normalised features so that reciprocal sets are non-trivial.
+    vk = synth_rows(98, 0, 400, 32).astype(np.float64)
+    ck = synth_rows(99, 0, 25, 32).astype(np.float64)
+    vk = 0.6 * vk + 1.3 * ck[np.arange(400) % 25]
+    vk /= np.linalg.norm(vk, axis=1, keepdims=True)
+    qk = vk[::57][:7] + 0.15 * synth_rows(100, 0, 7, 32)
+    qk /= np.linalg.norm(qk, axis=1, keepdims=True)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            kr_idx = rr.kr_reranking(qk.T.astype(np.float32), vk.T.astype(np.float32))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    np.savez_compressed(os.path.join(GOLD, "kr_rerank.npz"), indices=np.asarray(kr_idx))
+
     # ---- f-2: descriptor tail (GeM -> L2N -> whiten Linear -> L2N), multi-scale average, SOA block -- the reference's
     # own layer functions / classes on seeded feature maps and weights
     import src.networks.networks as rnet

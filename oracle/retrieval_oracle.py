@@ -11,7 +11,7 @@ __all__ = [
     "matching_l2", "matching_fractional_dis", "fractional_distance", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
     "extract_ms_tail", "knn_flat_ip", "knn_flat_ip_blas", "compute_ap2", "compute_map2", "compute_map_revisited",
     "get_affinity", "get_laplacian", "diffusion_offline", "diffusion_online", "qge_small",
-    "average_query_expansion", "database_augmentation", "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
+    "average_query_expansion", "database_augmentation", "kr_reranking", "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
 ]
 
 
@@ -306,6 +306,82 @@ def _centre_normalise(q, r):
 def _dist_rank(q, r):
     qn, rn = _centre_normalise(q, r)
     return np.argsort(2 - 2 * np.dot(qn, rn.T), axis=1)
+
+
+def kr_reranking(qvecs, vecs, k1=20, k2=6, lambda_value=0.3, block=6000, return_dist=False):
+    """f-4: src/utils/Reranking.py:447-624 (kr_reranking; k-reciprocal encoding, Zhong et al. CVPR 2017), restated in numpy
+    float32 with the reference's constants (k1 = 20, k2 = 6, lambda = 0.3, :546-548) and its own blocking (N = 6000).
+
+      feat = [queries; gallery] rows, assumed L2-normalised ("For L2-norm feature", :461-462)
+      dist(a, b) = 2 - 2 a.b (:462); every column block is divided by its column maxima (:501), which changes no order
+      initial_rank = the k1 + 1 nearest of every row among ALL rows, itself included (:502, :555)
+      R[i] = k-reciprocal set of i, expanded by the k1/2-reciprocal sets of its members that overlap it by > 2/3 (:565-575)
+      V[i, R[i]] = softmax(-dist(i, R[i]) / max_j dist(i, j)) (:514-525)
+      V <- mean of the rows of the k2 nearest, stored as FLOAT16 (:585-589)
+      jaccard[i, j] = 1 - m / (2 - m), m = sum_c min(V[i, c], V[j, c]) accumulated in float32 over ascending c (:602-609)
+      final = 0.7 * jaccard + 0.3 * dist / colmax (:612-613); queries x gallery block, argsort ascending (:618, :621)
+
+    Returns indices int64 [Q, N] (as the reference: `return indices`, NOT transposed)."""
+    probe = np.asarray(qvecs.T, dtype=np.float32)
+    gal = np.asarray(vecs.T, dtype=np.float32)
+    query_num = probe.shape[0]
+    feat = np.concatenate([probe, gal])
+    all_num = feat.shape[0]
+
+    def euclid(qf, gf):
+        return (2 - 2 * (qf @ gf.T)).astype(np.float32)
+
+    def normalised_block(gf_block):                       # [m, nj] -> / column max -> [nj, m]   (:492-502, :470-480)
+        d = np.concatenate([euclid(feat[i:i + block], gf_block) for i in range(0, all_num // block * block + 1, block)
+                            if i < all_num], axis=0)
+        d = d / d.max(axis=0)
+        return d.T
+
+    initial_rank = np.concatenate(
+        [np.argsort(normalised_block(feat[j:j + block]), axis=1, kind="stable")[:, :k1 + 1]
+         for j in range(0, all_num // block * block + 1, block) if j < all_num], axis=0)
+
+    def k_reciprocal_neigh(i, k):
+        fwd = initial_rank[i, :k + 1]
+        back = initial_rank[fwd, :k + 1]
+        fi = np.where(back == i)[0]
+        return fwd[fi]
+
+    R = []
+    for i in range(all_num):
+        kr = k_reciprocal_neigh(i, k1)
+        exp_idx = kr
+        for c in kr:
+            ckr = k_reciprocal_neigh(c, int(np.around(k1 / 2)))
+            if len(np.intersect1d(ckr, kr)) > 2. / 3 * len(ckr):
+                exp_idx = np.append(exp_idx, ckr)
+        R.append(np.unique(exp_idx))
+
+    V = np.zeros((all_num, all_num), dtype=np.float32)
+    for i in range(all_num):
+        d = euclid(feat[i:i + 1], feat)
+        d = (d / d.max()).reshape(-1)[R[i]]
+        w = np.exp(-d)
+        V[i, R[i]] = (w / w.sum()).astype(np.float32)
+    ir = initial_rank[:, :k2]
+    if k2 != 1:
+        V_qe = np.zeros_like(V, dtype=np.float16)
+        for i in range(all_num):
+            V_qe[i, :] = np.mean(V[ir[i], :], axis=0)
+        V = V_qe
+    inv_index = [np.where(V[:, i] != 0)[0] for i in range(all_num)]
+    jaccard = np.zeros((query_num, all_num), dtype=np.float32)
+    for i in range(query_num):
+        temp_min = np.zeros((1, all_num), dtype=np.float32)
+        nz = np.where(V[i, :] != 0)[0]
+        for c in nz:
+            temp_min[0, inv_index[c]] = temp_min[0, inv_index[c]] + np.minimum(V[i, c], V[inv_index[c], c])
+        jaccard[i] = 1 - temp_min / (2. - temp_min)
+    original = normalised_block(feat[:query_num])          # batch_euclidean_distance(feat, feat[:query_num])  (:611)
+    final = jaccard * (1 - lambda_value) + original * lambda_value
+    final = final[:query_num, query_num:]
+    idx = np.argsort(final, axis=1, kind="stable")
+    return (idx, final) if return_dist else idx
 
 
 def average_query_expansion(qvecs, vecs, K, top_k=3):

@@ -98,3 +98,34 @@ def test_diffusion_cache_roundtrip(tmp_path):
     d2.close()
     assert (off1 != off2).nnz == 0
     assert np.array_equal(r1, r2) and np.array_equal(s1, s2)
+
+
+def test_diffusion_offline_at_the_reference_size():
+    """The only size the reference ever diffuses at: rOxford5k, N = 4993, truncation 2000, k_gallery 200
+    (src/utils/Reranking.py:230-236; N >= 120000 skips diffusion, :212).  About 20 s of scipy on the host."""
+    import time
+    from isehr_amd.diffusion import Diffusion
+    n, d, T, kd = 4993, 128, 2000, 200
+    f = synth_rows(5, 0, n, d).astype(np.float64)
+    c = synth_rows(6, 0, 40, d).astype(np.float64)
+    f = 0.8 * f + 1.5 * c[np.arange(n) % 40]
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    f = f.astype(np.float32)
+    dd = Diffusion(f)
+    t0 = time.time()
+    ids, vals, sims = dd.gallery.diffusion_offline(T, kd, return_sims=True)
+    t_gpu = time.time() - t0
+    dd.close()
+    t0 = time.time()
+    ref_off, ref_sims, ref_ids, lap, ref_scores = oracle.diffusion_offline(f, T, kd, return_parts=True)
+    t_cpu = time.time() - t0
+    s64 = f.astype(np.float64) @ f.astype(np.float64).T
+    assert oracle.check_topk_parity(ids, s64, T, 2e-6) == []
+    assert np.abs(sims - ref_sims).max() < 2e-6
+    same = (ids == ref_ids).all(axis=1)
+    assert same.mean() > 0.99, same.mean()
+    err = np.abs(vals[same].astype(np.float64) - ref_scores[same]).max()
+    assert err < 5e-6, err
+    assert np.abs(ref_scores).max() > 0.5
+    print("diffusion offline N=%d T=%d kd=%d: GPU %.2f s, oracle %.1f s, identical supports %.4f, max |d| %.2e"
+          % (n, T, kd, t_gpu, t_cpu, same.mean(), err))

@@ -298,3 +298,28 @@ def test_matching_fractional_dis_vs_reference_golden(lib, golden_dir, tag, dt):
     assert np.abs(np.take_along_axis(s, idx, 1) - np.take_along_axis(s, ref, 1)).max() <= TAU
     if dt == "float64":
         assert np.array_equal(idx, ref)
+
+
+def test_raised_caps_answer_massive_ties_without_the_dense_path(lib):
+    """MI_ERR_OVERFLOW tells the user to raise survivor_cap / rescore_cap: at their maxima (16384 / 8192: 66.6 KB and
+    96 KiB of dynamic LDS in the maintain and emit kernels) 3000 exact duplicates of the best match fit the candidate
+    buffers, so the filter path itself answers -- with the ties in index order -- and nothing overflows."""
+    from isehr_amd._lib import Gallery
+    n, d, k = 20000, 128, 100
+    g = synth_rows(61, 0, n, d)
+    dup = np.arange(500, 3500)
+    g[dup] = g[17]
+    q = np.stack([g[17], synth_rows(62, 0, 1, d)[0]])
+    G = Gallery.from_host(g)
+    try:
+        G.set_option("survivor_cap", 16384)
+        G.set_option("rescore_cap", 8192)
+        G.set_option("exact_fallback", 0)                      # an overflow would now be an error, not a fallback
+        idx, sc, _ = G.search(q, k)
+        assert G.status()["overflow_batches"] == 0
+    finally:
+        G.close()
+    expect = np.sort(np.concatenate([[17], dup]))[:k]
+    assert np.array_equal(idx[0], expect)
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
