@@ -44,6 +44,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_desc_ms_accumulate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "mi_desc_ms_finish_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "mi_gallery_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int]),
     "mi_gallery_destroy": (C.c_int, [C.c_void_p]),
     "mi_gallery_info": (C.c_int, [C.c_void_p, c_i64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), c_i64p, c_i64p]),
@@ -198,6 +199,37 @@ class Gallery:
         with self._lock:
             check(load().mi_gallery_append_device(self._h, C.c_void_p(rows_ptr), m, C.c_void_p(stream)))
             self.n += m
+
+    def append(self, rows):
+        """rows: [m, D] float32/float64 host array, any strides -- e.g. a column block `vecs[:, a:b].T` of the
+        reference's [D, N] layout, which moves as one 2-D copy (no host transpose, no float64 promotion)."""
+        a, code, rs, cs = _strided(rows)
+        if a.shape[1] != self.d:
+            raise ValueError("row dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        with self._lock:
+            check(load().mi_gallery_append(self._h, C.c_void_p(_base_pointer(a)), a.shape[0], code, rs, cs, MI_HOST))
+            self.n += a.shape[0]
+
+    @classmethod
+    def from_blocks(cls, blocks, norm_mode=NORM_L2, device=0, row_offset=0, chunk_rows=131072):
+        """Gallery of the concatenation `np.concatenate(blocks, axis=1).T` (src/test_rOP1m.py:136-139: [rOxford | 1M
+        distractors]) WITHOUT building it on the host: every block is a [D, N_i] array (numpy, memory-mapped or a CPU
+        torch tensor) and is appended in column chunks."""
+        blocks = [b.numpy() if hasattr(b, "numpy") and not isinstance(b, np.ndarray) else np.asarray(b) for b in blocks]
+        d = blocks[0].shape[0]
+        if any(b.ndim != 2 or b.shape[0] != d for b in blocks):
+            raise ValueError("blocks must be [D, N_i] arrays with one D")
+        g = cls.empty(sum(b.shape[1] for b in blocks), d, norm_mode, device, row_offset)
+        try:
+            for b in blocks:
+                for c0 in range(0, b.shape[1], chunk_rows):
+                    g.append(b[:, c0:c0 + chunk_rows].T)
+            if norm_mode == NORM_NONE and g.norm_bounds()[0] <= 4.0:
+                g.set_image_dtype(_default_image_f16[0])      # raw rows turned out to sit inside fp16's comfortable range
+        except Exception:
+            g.close()
+            raise
+        return g
 
     @classmethod
     def load(cls, path, device=0):
@@ -491,7 +523,12 @@ def kr_rerank(queries, gallery, k1=20, k2=6, lambda_value=0.3, device=0, return_
     return (idx, dist) if return_dist else idx
 
 
+_default_image_f16 = [1]
+
+
 def set_global_option(name, value):
+    if name == "image_dtype":
+        _default_image_f16[0] = 1 if value else 0
     check(load().mi_set_global_option(name.encode(), float(value)))
 
 

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -57,6 +58,16 @@ struct Workspace {
   unsigned long long* dbg = nullptr;
   uint32_t rec_cap = 4096, nseg = 0;
   std::vector<void*> allocs;
+};
+struct TmpAlloc {
+  std::vector<void*> v;
+  ~TmpAlloc() { for (void* p : v) (void)hipFree(p); }
+  template <typename T> T* get(size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, count * sizeof(T) + 256) != hipSuccess) return nullptr;
+    v.push_back(p);
+    return reinterpret_cast<T*>(p);
+  }
 };
 }  // namespace
 
@@ -570,6 +581,51 @@ int mi_gallery_append_device(mi_gallery* g, const float* rows_dev, int64_t m, vo
   return MI_OK;
 }
 
+int mi_gallery_append(mi_gallery* g, const void* data, int64_t m, int dtype, int64_t row_stride, int64_t col_stride,
+                      int memspace) {
+  REQUIRE(g && data, "null pointer");
+  REQUIRE(m >= 1, "nothing to append");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  REQUIRE(g->n + m <= g->cap, "gallery capacity exceeded");
+  int64_t elems;
+  int rc = strided_extent(m, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  hipStream_t s = g->stream;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  const void* src = data;
+  int64_t rs = row_stride, cs = col_stride;
+  if (memspace == MI_HOST) {
+    // Only the bytes of these m rows cross PCIe.  A column block of a [D, N] array (the reference's layout: callers pass
+    // vecs.T, src/test_rOP1m.py:156) is d runs of m contiguous elements: a 2-D copy packs it to [d][m] on the device and
+    // the ingest kernel reads it with strides (1, m) -- no host transpose, no float64 promotion.
+    if (row_stride == 1 && col_stride >= m) {
+      char* st = tmp.get<char>((size_t)g->d * m * esz);
+      if (!st) return fail(MI_ERR_NOMEM, "append staging");
+      HIPC(hipMemcpy2D(st, (size_t)m * esz, data, (size_t)col_stride * esz, (size_t)m * esz, (size_t)g->d,
+                       hipMemcpyHostToDevice));
+      src = st;
+      rs = 1;
+      cs = m;
+    } else {
+      char* st = tmp.get<char>((size_t)elems * esz);
+      if (!st) return fail(MI_ERR_NOMEM, "append staging");
+      HIPC(hipMemcpy(st, data, (size_t)elems * esz, hipMemcpyHostToDevice));
+      src = st;
+    }
+  }
+  launch_ingest(src, dtype, m, g->d, rs, cs, g->norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat, g->dp, m, s,
+                g->n);
+  launch_rowstat_max(g->rowstat + g->n, m, g->gstat3, s, /*reset=*/false);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(s));          // the staging buffer is freed on return
+  g->n += m;
+  g->npad = round_up(g->n, TILE);
+  return MI_OK;
+}
+
 int mi_desc_tail_device(const float* feat_dev, int32_t b, int32_t c, int32_t hw, float p, float eps,
                         const float* whiten_w_dev, const float* whiten_b_dev, int32_t c_out, float* scratch_dev,
                         float* out_dev, void* stream) {
@@ -620,28 +676,88 @@ int mi_gallery_get_rows(const mi_gallery* g, int64_t row0, int64_t nrows, float*
 }
 
 // ---- persistence -----------------------------------------------------------------------------------
+// Prepared-gallery file "MI355GAL" v2: header | f32 rows [n][dp] | 16-bit image [npad][dp] | row
+// norms [npad].  The header carries a checksum per section and one of itself; sections move through two pinned host
+// buffers so that the disk and the PCIe copy overlap (the v1 loader went through one pageable 64 MB buffer), and the
+// section checksums are recomputed on the device after the copy.
 namespace {
 struct FileHeader {
   char magic[8];
   int64_t version, n, npad, row_offset;
   int32_t d, dp, norm_mode, img_f16;
+  float gstat3[3];
+  uint32_t reserved;
+  uint64_t section_sum[3];     // f32 rows, image, row norms
+  uint64_t header_sum;         // of all bytes above
 };
-int copy_dev_to_file(FILE* f, const void* dev, size_t bytes) {
-  std::vector<char> buf(std::min<size_t>(bytes, (size_t)64 << 20));
-  for (size_t off = 0; off < bytes; off += buf.size()) {
-    const size_t c = std::min(buf.size(), bytes - off);
-    HIPC(hipMemcpy(buf.data(), (const char*)dev + off, c, hipMemcpyDeviceToHost));
-    if (fwrite(buf.data(), 1, c, f) != c) return fail(MI_ERR_IO, "short write");
+uint64_t host_sum(const void* p, size_t bytes) {       // FNV-1a, header only
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < bytes; ++i) h = (h ^ ((const unsigned char*)p)[i]) * 0x100000001b3ull;
+  return h;
+}
+struct PinnedPair {
+  static constexpr size_t CHUNK = (size_t)32 << 20;
+  void* buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipStream_t s = nullptr;
+  int init() {
+    for (int i = 0; i < 2; ++i) {
+      HIPC(hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault));
+      HIPC(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return MI_OK;
+  }
+  ~PinnedPair() {
+    for (int i = 0; i < 2; ++i) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    if (s) (void)hipStreamDestroy(s);
+  }
+};
+// device -> file: the D2H copy of chunk c + 1 runs while chunk c is written
+int copy_dev_to_file(PinnedPair& pp, FILE* f, const void* dev, size_t bytes) {
+  const size_t nchunks = (bytes + PinnedPair::CHUNK - 1) / PinnedPair::CHUNK;
+  auto start = [&](size_t c) -> int {
+    const size_t off = c * PinnedPair::CHUNK, len = std::min(PinnedPair::CHUNK, bytes - off);
+    HIPC(hipMemcpyAsync(pp.buf[c & 1], (const char*)dev + off, len, hipMemcpyDeviceToHost, pp.s));
+    HIPC(hipEventRecord(pp.ev[c & 1], pp.s));
+    return MI_OK;
+  };
+  int rc;
+  if (nchunks && (rc = start(0)) != MI_OK) return rc;
+  for (size_t c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks && (rc = start(c + 1)) != MI_OK) return rc;
+    HIPC(hipEventSynchronize(pp.ev[c & 1]));
+    const size_t len = std::min(PinnedPair::CHUNK, bytes - c * PinnedPair::CHUNK);
+    if (fwrite(pp.buf[c & 1], 1, len, f) != len) return fail(MI_ERR_IO, "short write");
   }
   return MI_OK;
 }
-int copy_file_to_dev(FILE* f, void* dev, size_t bytes) {
-  std::vector<char> buf(std::min<size_t>(bytes, (size_t)64 << 20));
-  for (size_t off = 0; off < bytes; off += buf.size()) {
-    const size_t c = std::min(buf.size(), bytes - off);
-    if (fread(buf.data(), 1, c, f) != c) return fail(MI_ERR_IO, "short read (truncated gallery file)");
-    HIPC(hipMemcpy((char*)dev + off, buf.data(), c, hipMemcpyHostToDevice));
+// file -> device: chunk c + 1 is read from the file while chunk c crosses PCIe
+int copy_file_to_dev(PinnedPair& pp, FILE* f, void* dev, size_t bytes) {
+  const size_t nchunks = (bytes + PinnedPair::CHUNK - 1) / PinnedPair::CHUNK;
+  for (size_t c = 0; c < nchunks; ++c) {
+    const size_t off = c * PinnedPair::CHUNK, len = std::min(PinnedPair::CHUNK, bytes - off);
+    if (c >= 2) HIPC(hipEventSynchronize(pp.ev[c & 1]));        // the copy that last used this buffer is done
+    if (fread(pp.buf[c & 1], 1, len, f) != len) return fail(MI_ERR_IO, "short read (truncated gallery file)");
+    HIPC(hipMemcpyAsync((char*)dev + off, pp.buf[c & 1], len, hipMemcpyHostToDevice, pp.s));
+    HIPC(hipEventRecord(pp.ev[c & 1], pp.s));
   }
+  HIPC(hipStreamSynchronize(pp.s));
+  return MI_OK;
+}
+int section_sums(const mi_gallery* g, uint64_t out[3]) {
+  unsigned long long* d = nullptr;
+  HIPC(hipMalloc((void**)&d, 24));
+  launch_checksum(g->gal_f32, (size_t)g->n * g->dp * 4, d + 0, g->stream);
+  launch_checksum(g->gal_img, (size_t)g->npad * g->dp * 2, d + 1, g->stream);
+  launch_checksum(g->rowstat, (size_t)g->npad * sizeof(RowStat), d + 2, g->stream);
+  hipError_t e = hipStreamSynchronize(g->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d, 24, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MI_ERR_HIP, std::string("checksum: ") + hipGetErrorString(e));
   return MI_OK;
 }
 }  // namespace
@@ -649,11 +765,10 @@ int copy_file_to_dev(FILE* f, void* dev, size_t bytes) {
 int mi_gallery_save(const mi_gallery* g, const char* path) {
   REQUIRE(g && path, "null");
   HIPC(hipSetDevice(g->device));
-  FILE* f = fopen(path, "wb");
-  if (!f) return fail(MI_ERR_IO, std::string("cannot open for writing: ") + path);
+  HIPC(hipStreamSynchronize(g->stream));
   FileHeader h{};
   memcpy(h.magic, "MI355GAL", 8);
-  h.version = 1;
+  h.version = 2;
   h.n = g->n;
   h.npad = g->npad;
   h.row_offset = g->row_offset;
@@ -661,12 +776,18 @@ int mi_gallery_save(const mi_gallery* g, const char* path) {
   h.dp = g->dp;
   h.norm_mode = g->norm_mode;
   h.img_f16 = g->img_f16;
-  int rc = MI_OK;
+  HIPC(hipMemcpy(h.gstat3, g->gstat3, 12, hipMemcpyDeviceToHost));
+  int rc = section_sums(g, h.section_sum);
+  if (rc != MI_OK) return rc;
+  h.header_sum = host_sum(&h, offsetof(FileHeader, header_sum));
+  PinnedPair pp;
+  if ((rc = pp.init()) != MI_OK) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(MI_ERR_IO, std::string("cannot open for writing: ") + path);
   if (fwrite(&h, sizeof h, 1, f) != 1) rc = fail(MI_ERR_IO, "short write");
-  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_f32, (size_t)g->n * g->dp * 4);
-  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gal_img, (size_t)g->npad * g->dp * 2);
-  if (rc == MI_OK) rc = copy_dev_to_file(f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
-  if (rc == MI_OK) rc = copy_dev_to_file(f, g->gstat3, 12);
+  if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->gal_f32, (size_t)g->n * g->dp * 4);
+  if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->gal_img, (size_t)g->npad * g->dp * 2);
+  if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
   if (fclose(f) != 0 && rc == MI_OK) rc = fail(MI_ERR_IO, "close failed");
   return rc;
 }
@@ -676,9 +797,17 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(MI_ERR_IO, std::string("cannot open: ") + path);
   FileHeader h{};
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MI355GAL", 8) != 0 || h.version != 1) {
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MI355GAL", 8) != 0 || h.version != 2) {
     fclose(f);
-    return fail(MI_ERR_IO, "not a MI355GAL v1 file");
+    return fail(MI_ERR_IO, "not a MI355GAL v2 file (files of the v1 layout carry no checksums: rebuild with ifgenerate)");
+  }
+  if (h.header_sum != host_sum(&h, offsetof(FileHeader, header_sum))) {
+    fclose(f);
+    return fail(MI_ERR_IO, "gallery file header checksum mismatch");
+  }
+  if (h.n < 1 || h.d < 1 || h.n >= ((int64_t)1 << 32) || h.norm_mode < 0 || h.norm_mode > 2) {
+    fclose(f);
+    return fail(MI_ERR_IO, "inconsistent header");
   }
   mi_gallery* g = new mi_gallery();
   g->device = device;
@@ -689,11 +818,23 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   g->row_offset = h.row_offset;
   int rc = gallery_alloc(g);
   if (rc == MI_OK && (g->dp != h.dp || g->npad != h.npad)) rc = fail(MI_ERR_IO, "inconsistent header");
-  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_f32, (size_t)g->n * g->dp * 4);
-  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gal_img, (size_t)g->npad * g->dp * 2);
-  if (rc == MI_OK) rc = copy_file_to_dev(f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
-  if (rc == MI_OK) rc = copy_file_to_dev(f, g->gstat3, 12);
+  PinnedPair pp;
+  if (rc == MI_OK) rc = pp.init();
+  if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->gal_f32, (size_t)g->n * g->dp * 4);
+  if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->gal_img, (size_t)g->npad * g->dp * 2);
+  if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
+  if (rc == MI_OK && fgetc(f) != EOF) rc = fail(MI_ERR_IO, "trailing bytes after the last section");
   fclose(f);
+  if (rc == MI_OK && hipMemcpy(g->gstat3, h.gstat3, 12, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(MI_ERR_HIP, "gstat3 copy failed");
+  if (rc == MI_OK) {
+    uint64_t sums[3];
+    rc = section_sums(g, sums);
+    static const char* names[3] = {"f32 rows", "16-bit image", "row norms"};
+    for (int i = 0; i < 3 && rc == MI_OK; ++i)
+      if (sums[i] != h.section_sum[i])
+        rc = fail(MI_ERR_IO, std::string("gallery file checksum mismatch in section: ") + names[i]);
+  }
   if (rc != MI_OK) {
     mi_gallery_destroy(g);
     return rc;
@@ -947,16 +1088,6 @@ int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, in
 
 // ---- dense exact kNN (k a large fraction of N) and truncated graph diffusion ---------------------------------------
 namespace {
-struct TmpAlloc {
-  std::vector<void*> v;
-  ~TmpAlloc() { for (void* p : v) (void)hipFree(p); }
-  template <typename T> T* get(size_t count) {
-    void* p = nullptr;
-    if (hipMalloc(&p, count * sizeof(T) + 256) != hipSuccess) return nullptr;
-    v.push_back(p);
-    return reinterpret_cast<T*>(p);
-  }
-};
 
 // exact f32 inner products of every stored row with nq (device, strided) queries -> top-k, all on `s`
 int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm, int64_t nq,

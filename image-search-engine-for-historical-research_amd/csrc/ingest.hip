@@ -6,6 +6,8 @@
 // the reference redoes it on every call, here it is done once per gallery (HBM-bound, one-off).
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -244,6 +246,38 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
   else
     hipLaunchKernelGGL(ingest_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)src, n,
                        d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad);
+}
+
+// Order-independent 64-bit checksum of a device buffer (8-byte words): sum over words of mix(word ^ index * golden ratio).
+// Computed where the data lives: the prepared-gallery file stores one per section and the loader recomputes it AFTER the
+// copy to the device, so that a flipped bit in the file, in the page cache or on the PCIe path is caught
+// ("header (N, D, dtype, norm flag, checksum)").
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void checksum_kernel(const uint64_t* __restrict__ data, size_t nwords,
+                                                       unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[256];
+  unsigned long long s = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+    s += mix64(data[i] ^ (i * 0x9E3779B97F4A7C15ull));
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+void launch_checksum(const void* data, size_t bytes, unsigned long long* out, hipStream_t stream) {
+  hipMemsetAsync(out, 0, 8, stream);
+  const size_t nwords = bytes / 8;
+  if (!nwords) return;
+  const unsigned blocks = (unsigned)std::min<size_t>(2048, (nwords + 255) / 256);
+  hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, stream, (const uint64_t*)data, nwords, out);
 }
 
 void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream, bool reset) {

@@ -32,3 +32,18 @@ def load_database(datasets, dim_vec=2048):
         vecs = v if vecs is None else np.concatenate([vecs, v], axis=1)
         paths += list(p)
     return vecs, paths
+
+
+def load_torch_vecs(path):
+    """The 1M-distractor descriptors the reference keeps as a torch tensor [D, N] float32
+    (`torch.save(vecs, network + '_vecs_revisitop1m.pt')`, src/extract_1m.py:97-98; loaded and concatenated on the
+    host at src/test_rOP1m.py:136-139).  Returned as a numpy view of the memory-mapped file where torch supports it
+    (zip-format checkpoints), so the 8.2 GB never sit in host memory twice; pass it to Gallery.from_blocks."""
+    import torch
+    try:
+        t = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
+    except (RuntimeError, TypeError, ValueError):
+        t = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(t, torch.Tensor) or t.dim() != 2:
+        raise ValueError("%s does not hold a [D, N] tensor" % path)
+    return t.numpy()

@@ -19,6 +19,7 @@ parser = argparse.ArgumentParser(description="Retrieval test (HIP exhaustive mat
 parser.add_argument("--datasets", "-d", default="roxford5k,rparis6k")
 parser.add_argument("--ifextracted", action="store_true", help="kept for CLI parity; features are always read")
 parser.add_argument("--include1m", action="store_true", help="append outputs/features/revisitop1m_path_feature.pkl")
+parser.add_argument("--distractors", default="", help="torch tensor file [D, N] of the 1M distractors (src/extract_1m.py:98)")
 parser.add_argument("--mode", default="100", help="'mAP' (rank as deep as the HIP path allows) or top-K as int")
 parser.add_argument("--gnd-dir", default="data/test")
 parser.add_argument("--synthetic", type=int, default=0, help="use a planted synthetic dataset with this many rows")
@@ -27,12 +28,16 @@ parser.add_argument("--gpu-id", "-g", default="0")
 
 
 def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0):
-    n = vecs.shape[1]
+    from ..nnsearch import ColumnBlocks
+    blocks = isinstance(vecs, ColumnBlocks)
+    n = vecs.shape[0] if blocks else vecs.shape[1]
     K = n if mode == "mAP" else int(mode)                 # 'mAP' ranks the whole database (src/test_rOP1m.py:144-149)
-    match_idx, time_per_query = matching_HIP(K, vecs.T, qvecs.T, device=device)
+    match_idx, time_per_query = matching_HIP(K, vecs if blocks else vecs.T, qvecs.T, device=device)
     ranks = match_idx.T
     print(">> {}: average matching time: {}".format(dataset, time_per_query))
     res = {"map": evaluate.compute_map_and_print(dataset, ranks, gnd)}
+    if blocks:                # the re-ranking functions take the [D, N] array like the reference's
+        vecs = np.concatenate(vecs.blocks, axis=1)
     res["qge"] = QGE_hip(ranks, qvecs, vecs, dataset, gnd, K=min(K, 2048), device=device)
     return res
 
@@ -48,8 +53,12 @@ def main(argv=None):
         vecs, _ = load_path_features(dataset + "_db")
         qvecs, _ = load_path_features(dataset + "_query")
         if args.include1m:
-            v1m, _ = load_path_features("revisitop1m")
-            vecs = np.concatenate([vecs, v1m], axis=1)
+            # src/test_rOP1m.py:136-139 loads `<network>_vecs_revisitop1m.pt` (torch tensor [D, 1001001]) and concatenates
+            # on the host; here the file is memory-mapped and the gallery is built block by block
+            from ..nnsearch import ColumnBlocks
+            from .features import load_torch_vecs
+            v1m = load_torch_vecs(args.distractors) if args.distractors else load_path_features("revisitop1m")[0]
+            vecs = ColumnBlocks([vecs, v1m])
         with open("{}/{}/gnd_{}.pkl".format(args.gnd_dir, dataset, dataset), "rb") as f:
             gnd = pickle.load(f)["gnd"]
         run_dataset(dataset, vecs, qvecs, gnd, args.mode, dev)

@@ -28,8 +28,11 @@ _cache = {}
 _cache_lock = threading.Lock()
 
 
-def _gallery_path(dataset):
-    return os.path.join("outputs", dataset.replace("/", "_"), "mi355_gallery.bin")
+def _gallery_path(dataset, norm_mode=NORM_L2):
+    # one file per normalisation: matching_HIP (L2-normalised rows) and the QGE / inner-product callers (rows as given)
+    # prepare different galleries of the same dataset
+    suffix = {NORM_L2: "l2", NORM_NONE: "raw", NORM_L2_EPS: "l2eps"}[norm_mode]
+    return os.path.join("outputs", dataset.replace("/", "_"), "mi355_gallery_%s.bin" % suffix)
 
 
 def get_gallery(train, dataset=None, ifgenerate=False, norm_mode=NORM_L2, device=0):
@@ -40,17 +43,17 @@ def get_gallery(train, dataset=None, ifgenerate=False, norm_mode=NORM_L2, device
     (or when its shape no longer matches `train`, which the reference leaves to the user:
     README "delete the cache when the database changes")."""
     if dataset is None:
-        return Gallery.from_host(train, norm_mode=norm_mode, device=device)
+        return _build_gallery(train, norm_mode, device)
     key = (dataset, norm_mode, device)
     with _cache_lock:
         g = _cache.get(key)
-        shape = tuple(np.shape(train))
+        shape = _train_shape(train)
         if g is not None and not ifgenerate and (g.n, g.d) == shape:
             return g
         if g is not None:
             g.close()
             _cache.pop(key, None)
-        path = _gallery_path(dataset)
+        path = _gallery_path(dataset, norm_mode)
         if not ifgenerate and os.path.exists(path):
             g = Gallery.load(path, device=device)
             if (g.n, g.d) != shape or g.norm_mode != norm_mode:
@@ -59,11 +62,30 @@ def get_gallery(train, dataset=None, ifgenerate=False, norm_mode=NORM_L2, device
         else:
             g = None
         if g is None:
-            g = Gallery.from_host(train, norm_mode=norm_mode, device=device)
+            g = _build_gallery(train, norm_mode, device)
             os.makedirs(os.path.dirname(path), exist_ok=True)
             g.save(path)
         _cache[key] = g
         return g
+
+
+class ColumnBlocks:
+    """`train` given as the blocks the reference concatenates on the host -- ColumnBlocks([vecs, vecs_1m]) stands for
+    np.concatenate([vecs, vecs_1m], axis=1).T (src/test_rOP1m.py:136-139, 155-156) -- ingested block by block."""
+
+    def __init__(self, blocks):
+        self.blocks = list(blocks)
+        self.shape = (sum(b.shape[1] for b in self.blocks), self.blocks[0].shape[0])
+
+
+def _train_shape(train):
+    return tuple(train.shape) if isinstance(train, ColumnBlocks) else tuple(np.shape(train))
+
+
+def _build_gallery(train, norm_mode, device):
+    if isinstance(train, ColumnBlocks):
+        return Gallery.from_blocks(train.blocks, norm_mode=norm_mode, device=device)
+    return Gallery.from_host(train, norm_mode=norm_mode, device=device)
 
 
 def drop_cached_galleries():

@@ -66,6 +66,12 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
 int mi_gallery_create_empty(int64_t capacity, int32_t d, int norm_mode, int device, int64_t row_offset,
                             mi_gallery** out);
 int mi_gallery_append_device(mi_gallery* g, const float* rows_dev /*[m][d] f32*/, int64_t m, void* stream);
+/* Strided append of m rows (f32 | f64, host or device memory; synchronous).  A host column block of a [D, N] array --
+ * row_stride 1, col_stride N, the layout of the reference's feature pickles and of its 1M-distractor tensor
+ * (src/utils/general.py:67-92, src/extract_1m.py:97-98, src/test_rOP1m.py:136-139) -- is packed by one 2-D copy and read
+ * with strides on the device: no host transpose, no concatenated host copy, no float64 promotion. */
+int mi_gallery_append(mi_gallery* g, const void* data, int64_t m, int dtype, int64_t row_stride, int64_t col_stride,
+                      int memspace);
 int mi_gallery_destroy(mi_gallery* g);
 int mi_gallery_info(const mi_gallery* g, int64_t* n, int32_t* d, int32_t* norm_mode, int32_t* device,
                     int64_t* row_offset, int64_t* hbm_bytes);

@@ -118,9 +118,32 @@ def test_save_load_roundtrip(tmp_path):
     H.close()
     assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
     assert i1.min() >= 100
+    size = os.path.getsize(path)
+    blob = open(path, "rb").read()
+
+    def corrupt(offset, label):
+        b = bytearray(blob)
+        b[offset] ^= 0x10
+        open(path, "wb").write(bytes(b))
+        with pytest.raises(RuntimeError, match=label):
+            Gallery.load(path)
+
+    # one flipped bit anywhere must be caught: header, f32 rows, 16-bit image, row norms (sections in file order)
+    rows_bytes, img_bytes = 3000 * 128 * 4, 3072 * 128 * 2
+    hdr = size - rows_bytes - img_bytes - 3072 * 12
+    assert 64 <= hdr <= 256
+    corrupt(20, "header")
+    corrupt(hdr + 12345, "f32 rows")
+    corrupt(hdr + rows_bytes + 54321, "16-bit image")
+    corrupt(size - 7, "row norms")
+    open(path, "wb").write(blob + b"x")
+    with pytest.raises(RuntimeError, match="trailing"):
+        Gallery.load(path)
+    open(path, "wb").write(blob)
+    Gallery.load(path).close()                                  # the intact file still loads
     with open(path, "r+b") as f:
-        f.truncate(1000)
-    with pytest.raises(RuntimeError):
+        f.truncate(size - 1000)
+    with pytest.raises(RuntimeError, match="truncated"):
         Gallery.load(path)
 
 
@@ -131,7 +154,7 @@ def test_matching_hip_dataset_cache(tmp_path, monkeypatch):
     g = synth_rows(2, 0, 2000, 64)
     q = synth_rows(3, 0, 4, 64)
     i1, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=True)
-    assert os.path.exists(os.path.join("outputs", "unit_test", "mi355_gallery.bin"))
+    assert os.path.exists(os.path.join("outputs", "unit_test", "mi355_gallery_l2.bin"))
     i2, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=False)      # in-process cache
     nnsearch.drop_cached_galleries()
     i3, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=False)      # from disk
@@ -399,3 +422,40 @@ def test_qge_large_branch_map_is_the_full_ranking_map():
         ids = np.array(sorted(out["positions"][i]))
         got = np.array([out["positions"][i][int(v)] for v in ids])
         assert np.abs(got - inv[ids, i]).max() <= 2
+
+
+def test_distractor_tensor_and_block_ingest(tmp_path):
+    """f-1: the reference keeps the 1M distractors as a torch tensor [D, N] float32 (src/extract_1m.py:97-98) and
+    concatenates [rOxford | distractors] on the host (src/test_rOP1m.py:136-139).  Here the file is memory-mapped and the
+    gallery is built block by block from column chunks (2-D copies, strided ingest): the result must equal the gallery
+    built from the concatenated array, bit for bit, for normalised and raw rows."""
+    import torch
+    from isehr_amd._lib import Gallery, NORM_L2, NORM_NONE
+    from isehr_amd.entry.features import load_torch_vecs
+    from isehr_amd.nnsearch import matching_HIP, ColumnBlocks
+    d, n1, n2 = 96, 700, 50021
+    small = np.ascontiguousarray(synth_rows(15, 0, n1, d).T)                  # [D, n1] like the feature pickles
+    big = torch.from_numpy(np.ascontiguousarray(synth_rows(16, 0, n2, d).T))   # [D, n2]
+    path = str(tmp_path / "net_vecs_revisitop1m.pt")
+    torch.save(big, path)
+    v1m = load_torch_vecs(path)
+    assert v1m.shape == (d, n2) and v1m.dtype == np.float32 and np.array_equal(v1m, big.numpy())
+    q = synth_rows(17, 0, 9, d)
+    cat = np.concatenate([small, big.numpy()], axis=1)
+    for norm in (NORM_L2, NORM_NONE):
+        ref = Gallery.from_host(cat.T, norm_mode=norm)
+        got = Gallery.from_blocks([small, v1m], norm_mode=norm, chunk_rows=8192)
+        try:
+            assert got.n == n1 + n2
+            assert np.array_equal(got.get_rows(0, got.n), ref.get_rows(0, ref.n))
+            assert got.get_option("image_dtype") == ref.get_option("image_dtype")
+            i1, s1, _ = ref.search(q, 40)
+            i2, s2, _ = got.search(q, 40)
+            assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+        finally:
+            ref.close()
+            got.close()
+    # through the matcher surface: ColumnBlocks stands for the concatenation
+    a, _ = matching_HIP(25, cat.T, q)
+    b, _ = matching_HIP(25, ColumnBlocks([small, v1m]), q)
+    assert np.array_equal(a, b)
