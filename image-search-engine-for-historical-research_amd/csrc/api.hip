@@ -56,6 +56,7 @@ struct Workspace {
   SurvRec* rec = nullptr;
   uint32_t* rec_cnt = nullptr;
   unsigned long long* dbg = nullptr;
+  XccBalance* bal = nullptr;      // measured XCD shares of the tile kernel (device memory)
   uint32_t rec_cap = 4096, nseg = 0;
   std::vector<void*> allocs;
 };
@@ -91,6 +92,7 @@ struct mi_gallery {
   int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0, speculative = 1;
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
+  int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -162,10 +164,16 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(rec, (size_t)ws.nseg * ws.rec_cap);
   A(rec_cnt, ws.nseg);
   A(dbg, (size_t)ws.nseg * 8);
+  A(bal, 1);
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 32));
   HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
+  {
+    XccBalance hb;
+    init_xcc_balance_host(&hb);
+    HIPC(hipMemcpy(ws.bal, &hb, sizeof hb, hipMemcpyHostToDevice));
+  }
   return MI_OK;
 }
 
@@ -313,6 +321,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.rec_cnt = ws.rec_cnt;
     a.rec_cap = ws.rec_cap;
     a.cond = cond;
+    a.bal = g->xcc_balance ? ws.bal : nullptr;
     a.dbg = ws.dbg;
     a.st = st;
     profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
@@ -325,7 +334,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       g->stats.gemm_flops += 2.0 * nq * rows * g->d;
       g->stats.gemm_bytes += rows * g->d * 2.0 + (double)nq * g->d * 2.0;
     }
-    if (!first_chunk) launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s);
+    if (!first_chunk)
+      launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s,
+                             (g->xcc_balance && !on_sample && !stream_select_applies(a)) ? ws.bal : nullptr, ws.dbg,
+                             (uint32_t)ntile);
   };
   if (samp_r > 0) {
     score_launch(0, t0, true, nullptr, false, true);                           // bootstrap on the sample image
@@ -1671,6 +1683,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "speculative") *out_value = g->speculative;
   else if (n == "small_batch_kernel") *out_value = g->small_batch_kernel;
   else if (n == "kernel_variant") *out_value = g->kernel_variant;
+  else if (n == "xcc_balance") *out_value = g->xcc_balance;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
@@ -1696,6 +1709,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "speculative") g->speculative = value != 0;
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
+  else if (n == "xcc_balance") g->xcc_balance = value != 0;
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
     g->qnorm_override = (int)value;

@@ -70,6 +70,18 @@ enum : uint32_t { FLAG_SURV_OVERFLOW = 1u, FLAG_CAND_OVERFLOW = 2u, FLAG_REC_OVE
 
 constexpr uint32_t CNT_STRIDE = 32;   // one survivor counter per 128-byte line (atomics to one line serialise in L2)
 
+// Share of the gallery tiles each XCD label (blockIdx % 8) gets from the tile kernel.  The eight XCDs of one MI355X hold
+// different clocks under the same load (measured: 1.47 vs 1.54 GHz, odd vs even XCDs of one device), so an even split
+// leaves the fast ones idle at the end of every launch.  `w` are relative speeds (tiles per unit time, measured by the
+// kernel itself: per-workgroup s_memrealtime around its loop), updated after every large launch by block 0 of the scatter
+// kernel; `cum` is their cumulative sum in 2^-20 units, read by the next launch.  Any split gives the same answers.
+struct XccBalance {
+  uint32_t cum[9];
+  uint32_t launches;
+  float w[8];
+};
+constexpr uint32_t XCC_ONE = 1u << 20;
+
 struct QueryState {       // all arrays sized for qpad queries
   float* thr;             // current pass threshold (approx-score domain), +inf for padded queries
   float* margin;          // 2 * eps_q  (rigorous |approx - exact| bound, both sides)

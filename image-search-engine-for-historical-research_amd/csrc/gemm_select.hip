@@ -470,7 +470,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
   const uint32_t b = blockIdx.x, nwg = gridDim.x >> 3;
   const uint32_t xcd = b & 7u, j = b >> 3;
   const uint32_t nqt = (uint32_t)p.nqt;
-  const uint32_t cnt_x = ((uint32_t)p.ntiles > xcd) ? ((uint32_t)p.ntiles - xcd + 7u) / 8u : 0u;
+  // gallery tiles of this XCD label: the contiguous range [start_x, start_x + cnt_x) of the launch's tiles, sized by the
+  // label's measured speed (XccBalance); rounded to whole rounds of the label's workgroups when the launch is large
+  // enough for that (every workgroup of an XCD then gets the same number of tiles)
+  const uint32_t ntl = (uint32_t)p.ntiles;
+  uint32_t unit = (nwg >= nqt && nwg % nqt == 0) ? nwg / nqt : 1u;    // gallery tiles per round of the label's workgroups
+  if (ntl < 8u * 32u * unit) unit = 1u;                               // rounding to rounds must stay below ~1.5 % of a share
+  auto cum_of = [&](uint32_t x) -> uint32_t {
+    if (x == 0) return 0u;
+    if (x >= 8) return ntl;
+    const uint64_t c = p.bal ? (uint64_t)p.bal->cum[x] : (uint64_t)x * (XCC_ONE / 8u);
+    uint32_t t = (uint32_t)(((uint64_t)ntl * c) >> 20);
+    t = (t + unit / 2u) / unit * unit;
+    return t < ntl ? t : ntl;
+  };
+  const uint32_t start_x = cum_of(xcd);
+  const uint32_t cnt_x = cum_of(xcd + 1u) - start_x;
   const uint32_t nvirt = cnt_x * nqt;
   if (j >= nvirt) {
     if (!FIRST && (threadIdx.x & 63) == 0) p.rec_cnt[b * 8 + (threadIdx.x >> 6)] = 0;
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
       const uint32_t v = j + i * nwg;
       qt = v % nqt;
-      gt = (uint32_t)p.tile0 + (v / nqt) * 8u + xcd;
+      gt = (uint32_t)p.tile0 + start_x + v / nqt;
     };
     // ---- DMA stream of this group's operand: wave-uniform scalar base + one constant per-lane offset (saddr form)
     uint32_t pf_i = 0, pf_sl = 0;
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
               else
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-        } else {
+        } else if (ORDER == 1) {
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -712,6 +727,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
               else
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        } else if (ORDER == 2) {        // diagnostics: operands swapped (C transposed: results invalid with the filter)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+              if constexpr (F16)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);
+              else
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);
+        } else {                        // diagnostics: snake order (every MFMA shares an operand with its predecessor)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int m2 = 0; m2 < 8; ++m2) {
+              const int mb = (nb & 1) ? 7 - m2 : m2;
+              if constexpr (F16)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+              else
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+            }
         }
       } else {
 #pragma unroll
@@ -784,9 +819,54 @@ constexpr int SCATTER_PER_THREAD = 16;                     // covers rec_cap = 4
 __global__ __launch_bounds__(SCATTER_THREADS) void scatter_records_kernel(const SurvRec* __restrict__ rec,
                                                                           const uint32_t* __restrict__ rec_cnt,
                                                                           uint32_t rec_cap, QueryState st,
-                                                                          const uint32_t* __restrict__ cond) {
+                                                                          const uint32_t* __restrict__ cond,
+                                                                          XccBalance* __restrict__ bal,
+                                                                          const unsigned long long* __restrict__ dbg,
+                                                                          uint32_t nseg) {
   __shared__ uint32_t hist[1024];                          // per query of the batch (QB = 1024): count, then base
   if (cond && *cond == 0) return;
+  if (bal && blockIdx.x == 0) {
+    // XCD shares for the next launch from the loop times of the one that has just finished: speed of label x =
+    // slices done by its workgroups / time of its slowest workgroup; new share = half old, half measured
+    uint32_t* tmax = hist;                                 // [8]
+    uint32_t* work = hist + 8;                             // [8]
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t nblk = nseg / 8;
+    for (uint32_t b = threadIdx.x; b < nblk; b += SCATTER_THREADS) {
+      const unsigned long long* d = dbg + (uint64_t)b * 8 * 8;
+      atomicMax(&tmax[b & 7u], (uint32_t)d[7]);
+      atomicAdd(&work[b & 7u], (uint32_t)d[5]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float sp[8], tot = 0.f;
+      bool ok = true;
+      for (int x = 0; x < 8; ++x) {
+        ok &= tmax[x] > 0 && work[x] > 0;
+        sp[x] = ok ? (float)work[x] / (float)tmax[x] : 0.f;
+        tot += sp[x];
+      }
+      if (ok) {
+        float wsum = 0.f, w[8];
+        for (int x = 0; x < 8; ++x) {
+          w[x] = 0.5f * bal->w[x] + 0.5f * sp[x] / tot;
+          wsum += w[x];
+        }
+        float c = 0.f;
+        for (int x = 0; x < 8; ++x) {
+          bal->w[x] = w[x] / wsum;
+          bal->cum[x] = (uint32_t)(c * (float)XCC_ONE + 0.5f);
+          c += w[x] / wsum;
+        }
+        bal->cum[8] = XCC_ONE;
+        bal->launches += 1;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 16; i += SCATTER_THREADS) hist[i] = 0;
+    __syncthreads();
+  }
   const uint32_t seg = blockIdx.x;
   const uint32_t n = min(rec_cnt[seg], (uint32_t)(SCATTER_THREADS * SCATTER_PER_THREAD));
   if (n == 0) return;
@@ -821,8 +901,21 @@ __global__ __launch_bounds__(SCATTER_THREADS) void scatter_records_kernel(const 
 }
 
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
-                            QueryState st, const uint32_t* cond, hipStream_t stream) {
-  hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(SCATTER_THREADS), 0, stream, rec, rec_cnt, rec_cap, st, cond);
+                            QueryState st, const uint32_t* cond, hipStream_t stream, XccBalance* bal,
+                            const unsigned long long* dbg, uint32_t ntiles) {
+  // shares are only re-measured on launches with enough tiles per XCD for the loop time to be a speed
+  if (cond || !dbg || ntiles < 8u * 64u) bal = nullptr;
+  hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(SCATTER_THREADS), 0, stream, rec, rec_cnt, rec_cap, st, cond,
+                     bal, dbg, nseg);
+}
+
+void init_xcc_balance_host(XccBalance* h) {
+  for (int x = 0; x < 8; ++x) {
+    h->cum[x] = (uint32_t)x * (XCC_ONE / 8u);
+    h->w[x] = 0.125f;
+  }
+  h->cum[8] = XCC_ONE;
+  h->launches = 0;
 }
 
 template <bool FIRST, int DBG, bool F16, bool REPAIR = false>
@@ -841,17 +934,25 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
   const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * 64 * 4;
   if (a.variant != 1) {                                          // structure 2 (default); variant 1 = structure 1 (A/B)
-    if (a.cond) return a.img_f16 ? launch_tile<false, 0, true, true, 1>(a, lds, stream)
-                                 : launch_tile<false, 0, false, true, 1>(a, lds, stream);
-    if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 1>(a, lds, stream)
-                                : launch_tile<true, 0, false, false, 1>(a, lds, stream);
-    if (!a.img_f16) return launch_tile<false, 0, false, false, 1>(a, lds, stream);
-    const bool o0 = a.variant == 2;                                // MFMA issue order A/B
+    // MFMA issue order: 3 = query-block-major snake (default: every MFMA shares an operand with its predecessor; bit-identical
+    // results, +0.8 % over plain query-block-major and +4 % over gallery-block-major by the clock the chip holds)
+    if (a.cond) return a.img_f16 ? launch_tile<false, 0, true, true, 3>(a, lds, stream)
+                                 : launch_tile<false, 0, false, true, 3>(a, lds, stream);
+    if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 3>(a, lds, stream)
+                                : launch_tile<true, 0, false, false, 3>(a, lds, stream);
+    if (!a.img_f16) return launch_tile<false, 0, false, false, 3>(a, lds, stream);
     switch (a.debug) {
-      case 4: return o0 ? launch_tile<false, 4, true, false, 0>(a, lds, stream) : launch_tile<false, 4, true, false, 1>(a, lds, stream);
-      case 5: return launch_tile<false, 5, true, false, 1>(a, lds, stream);
-      case 5 + 128: return launch_tile<false, 5 + 128, true, false, 1>(a, lds, stream);
-      default: return o0 ? launch_tile<false, 0, true, false, 0>(a, lds, stream) : launch_tile<false, 0, true, false, 1>(a, lds, stream);
+      case 4:
+        if (a.variant == 2) return launch_tile<false, 4, true, false, 0>(a, lds, stream);
+        if (a.variant == 3) return launch_tile<false, 4, true, false, 2>(a, lds, stream);
+        if (a.variant == 4) return launch_tile<false, 4, true, false, 1>(a, lds, stream);
+        return launch_tile<false, 4, true, false, 3>(a, lds, stream);
+      case 5: return launch_tile<false, 5, true, false, 3>(a, lds, stream);
+      case 5 + 128: return launch_tile<false, 5 + 128, true, false, 3>(a, lds, stream);
+      default:
+        if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream);
+        if (a.variant == 4) return launch_tile<false, 0, true, false, 1>(a, lds, stream);
+        return launch_tile<false, 0, true, false, 3>(a, lds, stream);
     }
   }
   if (a.cond) return a.img_f16 ? launch_variant<false, 0, true, true>(a, lds, stream)

@@ -32,6 +32,7 @@ struct ScoreArgs {
   uint32_t* rec_cnt;      // [grid * 8]
   uint32_t rec_cap;
   const uint32_t* cond;   // non-null: the whole launch is skipped when *cond == 0 (repair pass)
+  const XccBalance* bal = nullptr;   // non-null: weighted split of the gallery tiles over the XCD labels (tile kernel)
   unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
@@ -43,8 +44,11 @@ void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream);
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
 // buckets the wave-private records of the last scoring launch into the per-query survivor buffers
+// bal / dbg / ntiles non-null / non-zero: block 0 also updates the XCD shares from the loop times of the launch that wrote dbg
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
-                            QueryState st, const uint32_t* cond, hipStream_t stream);
+                            QueryState st, const uint32_t* cond, hipStream_t stream, XccBalance* bal = nullptr,
+                            const unsigned long long* dbg = nullptr, uint32_t ntiles = 0);
+void init_xcc_balance_host(XccBalance* host);
 
 // exact_score.hip -- f32 FMA scoring with the same filter (fallback / force_exact)
 struct ExactArgs {
