@@ -169,6 +169,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 32));
   HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
+  HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
   {
     XccBalance hb;
     init_xcc_balance_host(&hb);
@@ -251,9 +252,12 @@ static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
 }
 
 // ---- phase 1 for one batch (nq <= QB): query ingest, chunked scoring + threshold maintenance ----------
+// fuse_cand: the final maintain launch also writes the candidate lists (single-shard search: its L is the global one)
 static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
-                        int32_t nq, int32_t k, bool exact, hipStream_t s) {
+                        int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false) {
   Workspace& ws = g->ws;
+  uint32_t* fc_rows = fuse_cand ? ws.cand_rows : nullptr;
+  uint32_t* fc_cnt = fuse_cand ? ws.cand_cnt : nullptr;
   const int32_t qpad = (int32_t)round_up(nq, TILE);
   launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, qpad, s);
   QueryState st = make_state(ws);
@@ -344,12 +348,12 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     if (sample_threshold_applies(first_cnt, k, samp_r)) launch_sample_threshold(st, nq, k, samp_r, s);
     else launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
     score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
-    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 0, nullptr, s);
+    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 0, nullptr, s, fc_rows, fc_cnt, ws.rcap);
     // repair pass for queries whose speculative threshold failed verification: conditional on the device word
     // flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip
     const uint32_t* cond = ws.flags + 1;
     score_launch(0, ntiles, false, cond, false);
-    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s);
+    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s, fc_rows, fc_cnt, ws.rcap);
     HIPC(hipGetLastError());
     return MI_OK;
   }
@@ -363,11 +367,12 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     score_launch(t, cur, first, nullptr, true);
     t += cur;
     if (t >= ntiles) {
-      launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, spec_cur ? 1 : 0, 0, nullptr, s);
+      launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, spec_cur ? 1 : 0, 0, nullptr, s, fc_rows, fc_cnt,
+                             ws.rcap);
       if (spec_cur) {
         const uint32_t* cond = ws.flags + 1;
         score_launch(0, ntiles, false, cond, false);
-        launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s);
+        launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s, fc_rows, fc_cnt, ws.rcap);
       }
     } else {
       int32_t spec_r = 0;
@@ -395,10 +400,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
 
 // ---- phase 2 for one batch: candidates within the margin of L, exact f64 re-score, sorted emit --------
 static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev, int64_t* out_idx, float* out_score,
-                        double* out_score64, hipStream_t s) {
+                        double* out_score64, hipStream_t s, bool have_cand = false) {
   Workspace& ws = g->ws;
   QueryState st = make_state(ws);
-  launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
+  if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
   launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
   launch_emit(ws.cand_rows, ws.cand_cnt, ws.cand_score, ws.rcap, nq, k, g->row_offset, out_idx, out_score,
               out_score64, s);
@@ -427,9 +432,9 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
   for (int64_t q0 = 0; q0 < nq; q0 += QB) {
     const int32_t b = (int32_t)std::min<int64_t>(QB, nq - q0);
     const char* src = (const char*)q_src + (size_t)q0 * q_rs * esz;
-    if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s)) != MI_OK) return rc;
+    if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true)) != MI_OK) return rc;
     if ((rc = phase2_batch(g, b, k, g->ws.L, out_idx + q0 * k, out_score ? out_score + q0 * k : nullptr,
-                           out_score64 ? out_score64 + q0 * k : nullptr, s)) != MI_OK)
+                           out_score64 ? out_score64 + q0 * k : nullptr, s, /*have_cand=*/true)) != MI_OK)
       return rc;
     g->stats.searches += 1;
     g->stats.queries += b;

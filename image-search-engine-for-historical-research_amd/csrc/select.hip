@@ -156,7 +156,9 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
                                                                         float* __restrict__ l_local,
                                                                         uint64_t* __restrict__ stats2, int32_t spec_r,
                                                                         int32_t spec, int32_t repair,
-                                                                        const uint32_t* __restrict__ cond) {
+                                                                        const uint32_t* __restrict__ cond,
+                                                                        uint32_t* __restrict__ cand_rows,
+                                                                        uint32_t* __restrict__ cand_cnt, uint32_t rcap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (cond && *cond == 0) return;
   const uint32_t q = blockIdx.x;
@@ -232,7 +234,13 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     const uint32_t i = threadIdx.x + j * MAINT_THREADS;
     if (i < n && !failed && !(MODE == 0 && spec)) {
       const float sc = entry_score(ent[j]);
-      if (sc >= thr_new) gsurv[atomicAdd(&sh[2], 1u)] = ent[j];          // compaction (order is irrelevant)
+      if (sc >= thr_new) {                                               // compaction (order is irrelevant)
+        const uint32_t pos = atomicAdd(&sh[2], 1u);
+        gsurv[pos] = ent[j];
+        // single-shard search: L is the K-th largest approximate score of the whole gallery, so the compacted survivors
+        // (score >= L - margin) ARE the candidate set of the certificate: no separate candidates launch
+        if (MODE == 1 && cand_rows && pos < rcap) cand_rows[(uint64_t)q * rcap + pos] = entry_row(ent[j]);
+      }
       if (MODE == 1) {
         // the K largest approximate values (unsorted): everything above L, ties of L filled in below
         if (n >= (uint32_t)k) {
@@ -273,17 +281,25 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     }
     if (MODE == 1 && stats2 && !failed)
       atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)sh[2]);
+    if (MODE == 1 && cand_rows) {
+      // a query whose speculative threshold failed has no candidate list yet (the repair launch writes it; if that fails
+      // too the batch is flagged and answered again): its count must still be defined, the re-score reads it
+      const uint32_t nc = failed ? 0u : min(sh[2], rcap);
+      if (!failed && sh[2] > rcap) atomicOr(st.flags, FLAG_CAND_OVERFLOW);
+      cand_cnt[q] = nc;
+      if (stats2 && nc) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[1]), (unsigned long long)nc);
+    }
   }
 }
 
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
-                            hipStream_t stream) {
+                            hipStream_t stream, uint32_t* cand_rows, uint32_t* cand_cnt, uint32_t rcap) {
   const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;      // keys | hist[256] | sh[8]
   auto go = [&](auto kern) {
     ensure_dynamic_lds((const void*)kern);                     // survivor_cap = 16384 needs 66.6 KB
     hipLaunchKernelGGL(kern, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local, stats2, spec_r, spec,
-                       repair, cond);
+                       repair, cond, cand_rows, cand_cnt, rcap);
   };
   const uint32_t per_thread = (st.cap + MAINT_THREADS - 1) / MAINT_THREADS;
   if (mode == 0) {
