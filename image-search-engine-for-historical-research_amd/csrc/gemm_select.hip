@@ -560,6 +560,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     const uint32_t sc_val_lds = lds_addr(sc_val), sc_meta_lds = lds_addr(sc_meta);
 
     // ---- per-tile filter of the accumulators (+ reset); same code as structure 1
+    unsigned long long fdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG 2048: cycles in decide / write burst / read wait / emit
     auto tile_epilogue = [&](uint32_t gt, uint32_t qt) {
       const uint32_t row_base = gt * TILE + GRP * 128 + lq * 4;          // + mb*16 + reg
       const uint32_t ql_base = qt * TILE + wc * 64 + l15;                // + nb*16
@@ -583,11 +584,126 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
               }
           }
         }
+      } else if (DBG & 8192) {
+        // Filter variant C (A/B, measured 0.3-1.3 % faster than the scratch filter below, but its list can overflow on
+        // duplicate-heavy tiles, which the scratch filter handles in rounds: not the default): per 16 x 16 block the lane maximum of its 4 scores is compared with the query's threshold
+        // (3 VALU + one wave-uniform branch per block); a block with hits appends (4 scores, threshold, packed position)
+        // of its hit lanes to a compact per-wave LDS list -- 2 LDS writes per hit block instead of 9 per hit (lane, query
+        // block) pair, and the write path of the LDS is what the scratch variant waits for.  One scan of the list at the
+        // end of the tile emits the records.
+        constexpr uint32_t ENT = WAVE_SCRATCH / 24;                 // 48 entries: 16 B of scores + 8 B (threshold, position)
+        if (qt != thr_qt) {
+          thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
+          thr_qt = qt;
+        }
+        const uint32_t vals_lds = sc_val_lds, meta_lds = sc_val_lds + ENT * 16u;
+        const uint32_t tile_row0 = gt * TILE + GRP * 128, tile_q0 = qt * TILE + wc * 64;
+        const uint32_t pk_lane = (uint32_t)l15 | ((uint32_t)lq << 9);
+        uint32_t ecnt = 0;                                          // entries in the list (wave-uniform)
+        unsigned long long fc0 = 0;
+        if (DBG & 2048) fc0 = stamp();
+        auto emit_list = [&]() {
+          unsigned long long fs0 = 0;
+          if (DBG & 2048) { fs0 = stamp(); fdbg[4] += ecnt; fdbg[6] += 1; }
+          const uint32_t nval = min(ecnt, ENT) * 4u;
+          for (uint32_t v0 = 0; v0 < nval; v0 += 64) {
+            const uint32_t vi = v0 + lane;
+            const bool valid = vi < nval;
+            float val;
+            unsigned long long meta;
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(val), "=&v"(meta)
+                         : "v"(vals_lds + (valid ? vi : 0u) * 4u), "v"(meta_lds + (valid ? (vi >> 2) : 0u) * 8u)
+                         : "memory");
+            const uint32_t pk = (uint32_t)(meta >> 32);
+            const uint32_t row = tile_row0 + ((pk >> 6) & 7u) * 16u + ((pk >> 9) & 3u) * 4u + (vi & 3u);
+            const bool keep = valid && val >= __uint_as_float((uint32_t)meta) && row < (uint64_t)p.n;
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+              const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+              if (keep && pos < p.rec_cap)
+                reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(val), row, tile_q0 + (pk & 63u), 0u);
+              my_cnt += (uint32_t)__popcll(km);
+            }
+          }
+          if (ecnt > ENT && lane == 0) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);   // list overflow: the batch is answered again
+          ecnt = 0;
+          if (DBG & 2048) fdbg[3] += stamp() - fs0;
+        };
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const float thr = thr_w[nb * 16 + l15];                  // +inf for padded queries
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb) {
+            // (no canonicalising v_max(x, x) in front: the scores are finite sums of finite products)
+            float m3;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(acc[mb][nb][0]), "v"(acc[mb][nb][1]), "v"(acc[mb][nb][2]));
+            const bool mine = (m3 >= thr) | (acc[mb][nb][3] >= thr);
+            const unsigned long long hit = __ballot(mine);
+            if (hit) {
+              const uint32_t pos = ecnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
+              if (mine && pos < ENT) {
+                lds_store16<0>(vals_lds + pos * 16u, acc[mb][nb]);
+                const unsigned long long mt = (unsigned long long)__float_as_uint(thr) |
+                                              ((unsigned long long)(pk_lane | (uint32_t)(nb * 16) | (uint32_t)(mb << 6)) << 32);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(meta_lds + pos * 8u), "v"(mt) : "memory");
+              }
+              ecnt += (uint32_t)__popcll(hit);
+            }
+          }
+          if (nb < 3 && ecnt >= ENT / 2) emit_list();              // keep room for the next query block's hits
+        }
+        if (ecnt) emit_list();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): see structure 1
+        if (DBG & 2048) { fdbg[0] += stamp() - fc0; fdbg[5] += 1; }
+      } else if (DBG & 4096) {
+        // Filter variant B (A/B): no LDS.  Every accumulator is compared with its query's threshold (one v_cmp into a
+        // scalar lane mask each); the four masks of one 16 x 16 block are OR-ed and ONE wave-uniform branch per block
+        // skips the append, which runs for ~11 of the 128 blocks of a tile.
+        if (qt != thr_qt) {
+          thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
+          thr_qt = qt;
+        }
+        unsigned long long fb0 = 0;
+        if (DBG & 2048) fb0 = stamp();
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const float thr = thr_w[nb * 16 + l15];
+          const uint32_t q = ql_base + nb * 16;
+#pragma unroll
+          for (int mb = 0; mb < 8; ++mb) {
+            unsigned long long m[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = __ballot(acc[mb][nb][r] >= thr);
+            if (__builtin_expect(((m[0] | m[1]) | (m[2] | m[3])) != 0ull, 0)) {      // cold: laid out out of line
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t row = row_base + mb * 16 + r;
+                const bool keep = ((m[r] >> lane) & 1ull) && row < (uint64_t)p.n;
+                const unsigned long long km = __ballot(keep);
+                if (km) {
+                  const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                  if (!(DBG & 1024) && keep && pos < p.rec_cap)
+                    reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(acc[mb][nb][r]), row, q, 0u);
+                  if (DBG & 1024) asm volatile("" ::"v"(pos), "v"(row));
+                  my_cnt += (uint32_t)__popcll(km);
+                }
+              }
+              if (DBG & 2048) fdbg[4] += 1;
+            }
+          }
+        }
+        if (DBG & 2048) { fdbg[0] += stamp() - fb0; fdbg[5] += 1; }
       } else {
         if (qt != thr_qt) {
           thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
           thr_qt = qt;
         }
+        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+        if (DBG & 2048) f0 = stamp();
         float thr4[4];
         unsigned long long hm[4];
         uint32_t base[5];
@@ -603,8 +719,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
           hm[nb] = __ballot(m >= thr4[nb]);
           base[nb + 1] = base[nb] + (uint32_t)__popcll(hm[nb]);
         }
-        const uint32_t total = base[4];
+        const uint32_t total = (DBG & 512) ? 0u : base[4];            // DBG 512: decide only, no hit path (diagnostics)
+        if (DBG & 512) asm volatile("" ::"s"(base[4]));
+        if (DBG & 2048) { f1 = stamp(); fdbg[0] += f1 - f0; fdbg[4] += total; fdbg[5] += 1; }
         for (uint32_t r0 = 0; r0 < total; r0 += HIT_SLOTS) {          // almost always zero or one round
+          if (DBG & 2048) f1 = stamp();
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb) {
             if (hm[nb] == 0) continue;                                  // wave-uniform
@@ -626,6 +745,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
             }
           }
           const uint32_t nslots = min(total - r0, (uint32_t)HIT_SLOTS);
+          if (DBG & 2048) { f2 = stamp(); fdbg[1] += f2 - f1; }
           constexpr int SCAN = HIT_SLOTS * 32 / 64;
           u32x3 mt[SCAN];                                              // (threshold, query, row base)
           float vv[SCAN];
@@ -643,6 +763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
                        : "+v"(mt[0]), "+v"(mt[1]), "+v"(mt[2]), "+v"(mt[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3])
                        :
                        : "memory");
+          if (DBG & 2048) { f3 = stamp(); fdbg[2] += f3 - f2; }
 #pragma unroll
           for (int it = 0; it < SCAN; ++it) {
             if ((uint32_t)(it * 64) >= nslots * 32) break;              // wave-uniform
@@ -654,11 +775,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
             if (km) {
               const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-              if (keep && pos < p.rec_cap)
+              if (!(DBG & 1024) && keep && pos < p.rec_cap)          // DBG 1024: no record stores (diagnostics)
                 reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(vv[it]), row, mt[it].y, 0u);
+              if (DBG & 1024) asm volatile("" ::"v"(pos), "v"(row));
               my_cnt += (uint32_t)__popcll(km);
             }
           }
+          if (DBG & 2048) { fdbg[3] += stamp() - f3; fdbg[6] += 1; }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): see structure 1
       }
@@ -790,6 +913,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
       dbgp[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF;   // HW_REG_XCC_ID[3:0]
       dbgp[5] = (unsigned long long)my_tiles * KSL;
+      if (DBG & 2048) {                      // filter stamps in slots 0..3, hits << 32 | tiles in 4... (diagnostics)
+        dbgp[0] = fdbg[0]; dbgp[1] = fdbg[1]; dbgp[2] = fdbg[2]; dbgp[3] = fdbg[3];
+        dbgp[4] = (fdbg[4] << 40) | (fdbg[6] << 20) | fdbg[5];
+      }
       dbgp[6] = stamp() - clk0;
       dbgp[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
@@ -948,6 +1075,14 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
         if (a.variant == 4) return launch_tile<false, 4, true, false, 1>(a, lds, stream);
         return launch_tile<false, 4, true, false, 3>(a, lds, stream);
       case 5: return launch_tile<false, 5, true, false, 3>(a, lds, stream);
+      case 512: return launch_tile<false, 512, true, false, 3>(a, lds, stream);
+      case 1024: return launch_tile<false, 1024, true, false, 3>(a, lds, stream);
+      case 2048: return launch_tile<false, 2048, true, false, 3>(a, lds, stream);
+      case 8192: return launch_tile<false, 8192, true, false, 3>(a, lds, stream);
+      case 8192 + 2048: return launch_tile<false, 8192 + 2048, true, false, 3>(a, lds, stream);
+      case 4096: return launch_tile<false, 4096, true, false, 3>(a, lds, stream);
+      case 4096 + 2048: return launch_tile<false, 4096 + 2048, true, false, 3>(a, lds, stream);
+      case 4096 + 1024: return launch_tile<false, 4096 + 1024, true, false, 3>(a, lds, stream);
       case 5 + 128: return launch_tile<false, 5 + 128, true, false, 3>(a, lds, stream);
       default:
         if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream);

@@ -218,7 +218,22 @@ int main(int argc, char** argv) {
             mhz.push_back((double)c[(size_t)w * 8 + 6] / (double)c[(size_t)w * 8 + 7] * 100.0);
             if (!(v.debug & 8) && c[(size_t)w * 8 + 5] > 0) cps.push_back((double)c[(size_t)w * 8 + 6] / (double)c[(size_t)w * 8 + 5]);
           }
-        if (v.variant >= 1 && !(v.debug & 8)) {
+        if (v.debug & 2048) {
+          for (int grp = 0; grp < 2; ++grp) {
+            double f[4] = {0, 0, 0, 0}, hits = 0, rounds = 0, tiles = 0;
+            for (uint32_t w = 0; w < nseg; ++w)
+              if ((int)((w % 8) / 4) == grp && c[(size_t)w * 8 + 7] > 0) {
+                for (int j = 0; j < 4; ++j) f[j] += (double)c[(size_t)w * 8 + j];
+                const unsigned long long pk = c[(size_t)w * 8 + 4];
+                hits += (double)(pk >> 40);
+                rounds += (double)((pk >> 20) & 0xFFFFF);
+                tiles += (double)(pk & 0xFFFFF);
+              }
+            printf("#   %s group%d filter per tile: decide %.0f  write burst %.0f  read wait %.0f  emit %.0f cycles; hits %.1f, rounds %.2f\n",
+                   v.label.c_str(), grp, f[0] / tiles, f[1] / tiles, f[2] / tiles, f[3] / tiles, hits / tiles, rounds / tiles);
+          }
+        }
+        if (v.variant >= 1 && !(v.debug & 8) && !(v.debug & 2048)) {
           // per XCC: loop duration (us) of its workgroups and their clock
           for (int x = 0; x < 8; ++x) {
             std::vector<double> dur, mh;
