@@ -49,6 +49,10 @@ def parse():
                     help="element type of the streamed 16-bit operand image (MFMA input type)")
     ap.add_argument("--with-aqe", action="store_true",
                     help="BASELINE configs[4]: every step = search + alpha-QE (k=3, w=4) re-search of the expanded queries")
+    ap.add_argument("--async-tail", action="store_true",
+                    help="single GPU: re-score + sort of batch i on the handle's second stream beside the scoring launch of "
+                         "batch i+1 (measured: no gain -- the chip is power-limited and the scoring launch slows down by what "
+                         "the overlap hides; off by default, the roofline is quoted on the undisturbed launch)")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -151,16 +155,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # single GPU: the exact re-score + sort of a batch runs on the handle's second stream beside the scoring launch of the
+    # next batch (mi_set_option "async_tail"); every batch's results are complete after gal.join(), inside the timed region
+    pipelined = world == 1 and args.async_tail
+    if pipelined:
+        gal.set_option("async_tail", 1)
+
     def one_step(qb):
-        idx_, sc_ = sg.search(qb, k)
+        idx_, sc_ = sg.search(qb, k, join=not pipelined or args.with_aqe)
         one_step.last_queries = qb
         if args.with_aqe:
             # ranks[K,Q] view of the [Q,K] result, like `ranks = match_idx.T` (src/test_rOP1m.py:157) -> QGE (N >= 120000)
-            idx_, sc_, one_step.last_queries = sg.aqe_search(idx_.t(), 3, 4.0, k)
+            idx_, sc_, one_step.last_queries = sg.aqe_search(idx_.t(), 3, 4.0, k, join=not pipelined)
         return idx_, sc_
 
     for i in range(args.warmup):
         one_step(pool[i % len(pool)])
+    if pipelined:
+        gal.join(stream)
     barrier()
     gal.status(reset=True)
     gal.profile(True)
@@ -168,6 +180,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         idx, sc = one_step(pool[i % len(pool)])
+    if pipelined:
+        gal.join(stream)
     barrier()
     elapsed = time.perf_counter() - t0
     gal.profile(False)
@@ -247,7 +261,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
                        "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
-                       "parallelism": "row-shard x%d" % world, "alpha_qe": bool(args.with_aqe), "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
+                       "parallelism": "row-shard x%d" % world, "alpha_qe": bool(args.with_aqe),
+                       "tail": "re-score + sort of batch i on a second stream beside the scoring launch of batch i+1; "
+                               "joined inside the timed region" if pipelined else "same stream", "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        "ingest_s": round(ingest_s, 3),
                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                        "survivors_per_query": st["survivors"] / max(1, st["queries"]),

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mi_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "mi_search_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "mi_search_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_gallery_norm_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "mi_gallery_set_image_dtype": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_debug_read_cycles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -420,6 +421,10 @@ class Gallery:
 
     def set_image_dtype(self, f16):
         check(load().mi_gallery_set_image_dtype(self._h, 1 if f16 else 0))
+
+    def join(self, stream=None):
+        """Asynchronous-tail mode: make `stream` wait for the re-score + sort of every search_device call made so far."""
+        check(load().mi_search_join(self._h, C.c_void_p(stream)))
 
     def get_option(self, name):
         v = C.c_double(0.0)

@@ -52,6 +52,11 @@ struct Workspace {
   float *topvals = nullptr, *L = nullptr;
   uint32_t *cand_rows = nullptr, *cand_cnt = nullptr;
   double* cand_score = nullptr;
+  // second set of the buffers the tail of a search (exact re-score + emit) reads, for the asynchronous tail: the tail of
+  // batch i runs on its own stream beside the scoring launch of batch i + 1, which refills the other set
+  float* q_f32_set[2] = {nullptr, nullptr};
+  uint32_t *cand_rows_set[2] = {nullptr, nullptr}, *cand_cnt_set[2] = {nullptr, nullptr};
+  double* cand_score_set[2] = {nullptr, nullptr};
   uint64_t* stats2 = nullptr;
   SurvRec* rec = nullptr;
   uint32_t* rec_cnt = nullptr;
@@ -93,6 +98,14 @@ struct mi_gallery {
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
+  // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
+  // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 96
+  // VGPRs per SIMD lane and no LDS: exactly one re-score wave per SIMD fits next to its two); results are valid after
+  // mi_search_join
+  int async_tail = 0, tail_set = 0;
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+  bool ev_tail_valid[2] = {false, false};
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -165,11 +178,20 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(rec_cnt, ws.nseg);
   A(dbg, (size_t)ws.nseg * 8);
   A(bal, 1);
+  ws.q_f32_set[0] = ws.q_f32;
+  ws.cand_rows_set[0] = ws.cand_rows;
+  ws.cand_cnt_set[0] = ws.cand_cnt;
+  ws.cand_score_set[0] = ws.cand_score;
+  A(q_f32_set[1], (size_t)QB * g->dp);
+  A(cand_rows_set[1], (size_t)QB * ws.rcap);
+  A(cand_cnt_set[1], QB);
+  A(cand_score_set[1], (size_t)QB * ws.rcap);
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 32));
   HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
   HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
+  HIPC(hipMemset(ws.cand_cnt_set[1], 0, (size_t)QB * 4));
   {
     XccBalance hb;
     init_xcc_balance_host(&hb);
@@ -400,11 +422,12 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
 
 // ---- phase 2 for one batch: candidates within the margin of L, exact f64 re-score, sorted emit --------
 static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev, int64_t* out_idx, float* out_score,
-                        double* out_score64, hipStream_t s, bool have_cand = false) {
+                        double* out_score64, hipStream_t s, bool have_cand = false, bool resident = false) {
   Workspace& ws = g->ws;
   QueryState st = make_state(ws);
   if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
-  launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
+  if (resident) launch_rescore_resident(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
+  else launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
   launch_emit(ws.cand_rows, ws.cand_cnt, ws.cand_score, ws.rcap, nq, k, g->row_offset, out_idx, out_score,
               out_score64, s);
   HIPC(hipGetLastError());
@@ -424,21 +447,58 @@ static int check_k(const mi_gallery* g, int32_t k) {
 // full search of up to any nq on device inputs (strided, any dtype), outputs on device
 static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                          int64_t nq, int32_t k, int64_t* out_idx, float* out_score, double* out_score64, bool exact,
-                         hipStream_t s) {
+                         hipStream_t s, bool allow_async = false) {
   int rc = check_k(g, k);
   if (rc != MI_OK) return rc;
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
   const size_t esz = q_dtype == MI_F32 ? 4 : 8;
+  const bool async = g->async_tail != 0 && allow_async;
+  if (async && !g->tail_stream) {
+    HIPC(hipStreamCreateWithFlags(&g->tail_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPC(hipEventCreateWithFlags(&g->ev_p1[i], hipEventDisableTiming));
+      HIPC(hipEventCreateWithFlags(&g->ev_tail[i], hipEventDisableTiming));
+    }
+  }
+  Workspace& ws = g->ws;
   for (int64_t q0 = 0; q0 < nq; q0 += QB) {
     const int32_t b = (int32_t)std::min<int64_t>(QB, nq - q0);
     const char* src = (const char*)q_src + (size_t)q0 * q_rs * esz;
+    hipStream_t tail = s;
+    int set = 0;
+    if (async) {
+      set = g->tail_set;
+      g->tail_set ^= 1;
+      tail = g->tail_stream;
+      if (g->ev_tail_valid[set]) HIPC(hipStreamWaitEvent(s, g->ev_tail[set], 0));   // the tail that last read this set is done
+    }
+    ws.q_f32 = ws.q_f32_set[set];
+    ws.cand_rows = ws.cand_rows_set[set];
+    ws.cand_cnt = ws.cand_cnt_set[set];
+    ws.cand_score = ws.cand_score_set[set];
     if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true)) != MI_OK) return rc;
+    if (async) {
+      HIPC(hipEventRecord(g->ev_p1[set], s));
+      HIPC(hipStreamWaitEvent(tail, g->ev_p1[set], 0));
+    }
     if ((rc = phase2_batch(g, b, k, g->ws.L, out_idx + q0 * k, out_score ? out_score + q0 * k : nullptr,
-                           out_score64 ? out_score64 + q0 * k : nullptr, s, /*have_cand=*/true)) != MI_OK)
+                           out_score64 ? out_score64 + q0 * k : nullptr, tail, /*have_cand=*/true,
+                           /*resident=*/async && b > STREAM_MAX_QUERIES)) != MI_OK)
       return rc;
+    if (async) {
+      HIPC(hipEventRecord(g->ev_tail[set], tail));
+      g->ev_tail_valid[set] = true;
+    }
     g->stats.searches += 1;
     g->stats.queries += b;
   }
+  return MI_OK;
+}
+
+// makes `s` wait for every tail enqueued so far (no-op in the synchronous mode)
+static int join_tails(mi_gallery* g, hipStream_t s) {
+  for (int i = 0; i < 2; ++i)
+    if (g->ev_tail_valid[i]) HIPC(hipStreamWaitEvent(s, g->ev_tail[i], 0));
   return MI_OK;
 }
 
@@ -463,7 +523,13 @@ int mi_gallery_destroy(mi_gallery* g) {
   if (!g) return MI_OK;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->tail_stream) (void)hipStreamSynchronize(g->tail_stream);
   (void)hipDeviceSynchronize();
+  for (int i = 0; i < 2; ++i) {
+    if (g->ev_p1[i]) (void)hipEventDestroy(g->ev_p1[i]);
+    if (g->ev_tail[i]) (void)hipEventDestroy(g->ev_tail[i]);
+  }
+  if (g->tail_stream) (void)hipStreamDestroy(g->tail_stream);
   ws_free(g->ws);
   for (auto& e : g->ev_pool) {
     (void)hipEventDestroy(e.first);
@@ -958,7 +1024,14 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   REQUIRE(nq >= 1, "no queries");
   HIPC(hipSetDevice(g->device));
   return search_device(g, q_dev, MI_F32, g->d, 1, g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode, nq, k,
-                       out_idx_dev, out_score_dev, out_score64_dev, g->force_exact != 0, (hipStream_t)stream);
+                       out_idx_dev, out_score_dev, out_score64_dev, g->force_exact != 0, (hipStream_t)stream,
+                       /*allow_async=*/true);
+}
+
+int mi_search_join(mi_gallery* g, void* stream) {
+  REQUIRE(g, "null handle");
+  HIPC(hipSetDevice(g->device));
+  return join_tails(g, (hipStream_t)stream);
 }
 
 int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t k, float* out_approx_dev,
@@ -1689,6 +1762,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "small_batch_kernel") *out_value = g->small_batch_kernel;
   else if (n == "kernel_variant") *out_value = g->kernel_variant;
   else if (n == "xcc_balance") *out_value = g->xcc_balance;
+  else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
   else return fail(MI_ERR_INVALID, "unknown option: " + n);
@@ -1715,6 +1789,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
+  else if (n == "async_tail") g->async_tail = value != 0;
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
     g->qnorm_override = (int)value;

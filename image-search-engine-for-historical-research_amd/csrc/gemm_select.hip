@@ -799,7 +799,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     if (GRP == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
 
     uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding the current slice
-    frag_t af[8], bfr[4];
     unsigned long long clk0 = 0, rt0 = 0;
     // in-kernel clock of every launch (s_memtime / s_memrealtime around the loop, per wave): two scalar reads, and the
     // number bench.py reports next to the roofline fraction (the chip holds 1.4-1.7 GHz of its 2.4 GHz under this load)
@@ -807,11 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
 
     // LOAD segment (the partner group is in its MFMA segment): 12 fragment reads, then the 4 DMA pieces of the slice
     // MY_SLOTS - 1 ahead into the slot whose reads retired before the barrier behind us
-    auto load_segment = [&](bool first_ever) {
-      const char* abase = smem + a_rd * SLICE_BYTES;
-      const char* bbase = smem + b_rd * SLICE_BYTES;
-      if (++a_rd == A_SLOTS) a_rd = 0;
-      if (++b_rd == B_SLOTS) b_rd = 0;
+    auto frag_reads = [&](frag_t (&af)[8], frag_t (&bfr)[4], const char* abase, const char* bbase, bool first_ever) {
       if (!(DBG & 128) || first_ever) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
@@ -824,13 +819,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) asm volatile("" : "+v"(af[mb]));
       }
+    };
+    auto load_segment = [&](frag_t (&af)[8], frag_t (&bfr)[4], bool first_ever) {
+      const char* abase = smem + a_rd * SLICE_BYTES;
+      const char* bbase = smem + b_rd * SLICE_BYTES;
+      if (++a_rd == A_SLOTS) a_rd = 0;
+      if (++b_rd == B_SLOTS) b_rd = 0;
+      frag_reads(af, bfr, abase, bbase, first_ever);
       __builtin_amdgcn_sched_barrier(0);
       issue();
       if (GRP == 1) vm_wait<(B_SLOTS - 2) * 4>();        // B(S+1) landed before the barrier that opens group 0's LOAD(S+1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired BEFORE the barrier: frees the slots (WAR)
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto mfma_segment = [&]() {
+    auto mfma_segment = [&](frag_t (&af)[8], frag_t (&bfr)[4]) {
       if (!(DBG & 2)) {
         if (ORDER == 0) {
 #pragma unroll
@@ -884,21 +886,43 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     uint32_t gt, qt, prev_gt = 0, prev_qt = 0;
     for (uint32_t i = 0; i < my_tiles; ++i) {
       tile_of(i, gt, qt);
-      // ---- slice 0 of the tile (peeled: group 0 filters the previous tile between its barrier and its MFMAs)
-      load_segment(i == 0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (GRP == 0 && i > 0) tile_epilogue(prev_gt, prev_qt);
-      mfma_segment();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+      // ---- slice 0 of the tile (peeled: group 0 filters the previous tile between its barrier and its MFMAs).  Group 0
+      // reads the fragments of this slice AFTER that filter (their slots are not refilled before the next LOAD segment),
+      // so no fragment register is live across the filter: the kernel's VGPR peak is the loop's, not loop + filter.
+      {
+        frag_t af[8], bfr[4];
+        if constexpr (GRP == 0) {
+          const char* abase = smem + a_rd * SLICE_BYTES;
+          const char* bbase = smem + b_rd * SLICE_BYTES;
+          if (++a_rd == A_SLOTS) a_rd = 0;
+          if (++b_rd == B_SLOTS) b_rd = 0;
+          __builtin_amdgcn_sched_barrier(0);
+          issue();
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          if (i > 0) tile_epilogue(prev_gt, prev_qt);
+          __builtin_amdgcn_sched_barrier(0);
+          frag_reads(af, bfr, abase, bbase, i == 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          load_segment(af, bfr, i == 0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_segment(af, bfr);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- slices 1 .. KSL-1: straight-line body
 #pragma unroll 1
       for (uint32_t sl = 1; sl < KSL; ++sl) {
-        load_segment(false);
+        frag_t af[8], bfr[4];
+        load_segment(af, bfr, false);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_segment();
+        mfma_segment(af, bfr);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }

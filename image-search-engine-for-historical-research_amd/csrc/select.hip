@@ -504,6 +504,76 @@ constexpr int RESCORE_ROWS_PER_WG = 2;
 constexpr int RESCORE_THREADS = 64;
 constexpr uint32_t RESCORE_GRID_X = 64;     // 128 candidates per query and sweep
 
+// Resident variant for the asynchronous tail: ONE 256-thread workgroup per CU (its four waves land on the four SIMDs), so
+// that the launch occupies exactly the 96 VGPRs per SIMD lane the tile kernel leaves free and the NEXT batch's scoring
+// launch finds room on every CU at once (a grid of 64 k one-wave workgroups fills the SIMDs with re-score waves first
+// and the persistent kernel then waits for them to drain).  Query q belongs to SUB consecutive waves, which take its
+// candidate pairs round-robin; same arithmetic as rescore_kernel.
+__global__ __launch_bounds__(256, 5) void rescore_resident_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
+                                                               int32_t dp, int32_t nq, const uint32_t* __restrict__ cand_rows,
+                                                               const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
+                                                               double* __restrict__ cand_score, uint32_t sub) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int nvec = dp >> 2;
+  for (uint32_t t = gw; t < (uint32_t)nq * sub; t += nwaves) {
+    const uint32_t q = t / sub, part = t % sub;
+    const uint32_t nc = min(cand_cnt[q], rcap);
+    const float4* qv = reinterpret_cast<const float4*>(qry + (uint64_t)q * dp);
+    const uint32_t* rows = cand_rows + (uint64_t)q * rcap;
+    double* outs = cand_score + (uint64_t)q * rcap;
+    for (uint32_t c = part * 2; c < nc; c += 2 * sub) {
+      const bool two = (c + 1 < nc);
+      const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
+      const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
+      double a0 = 0.0, a1 = 0.0;
+      int v = lane;
+      for (; v + 192 < nvec; v += 256) {
+        float4 x[4], y0[4], y1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          x[u] = qv[v + 64 * u];
+          y0[u] = g0[v + 64 * u];
+          y1[u] = g1[v + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a0 += (double)x[u].x * (double)y0[u].x; a0 += (double)x[u].y * (double)y0[u].y;
+          a0 += (double)x[u].z * (double)y0[u].z; a0 += (double)x[u].w * (double)y0[u].w;
+          a1 += (double)x[u].x * (double)y1[u].x; a1 += (double)x[u].y * (double)y1[u].y;
+          a1 += (double)x[u].z * (double)y1[u].z; a1 += (double)x[u].w * (double)y1[u].w;
+        }
+      }
+      for (; v < nvec; v += 64) {
+        const float4 x = qv[v];
+        const float4 y0 = g0[v];
+        const float4 y1 = g1[v];
+        a0 += (double)x.x * (double)y0.x; a0 += (double)x.y * (double)y0.y;
+        a0 += (double)x.z * (double)y0.z; a0 += (double)x.w * (double)y0.w;
+        a1 += (double)x.x * (double)y1.x; a1 += (double)x.y * (double)y1.y;
+        a1 += (double)x.z * (double)y1.z; a1 += (double)x.w * (double)y1.w;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+      }
+      if (lane == 0) {
+        outs[c] = a0;
+        if (two) outs[c + 1] = a1;
+      }
+    }
+  }
+}
+
+void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
+                             const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
+  const unsigned grid = (unsigned)current_device_cus();
+  uint32_t sub = 1;
+  while ((uint64_t)nq * sub * 2 <= (uint64_t)grid * 4) sub *= 2;      // every wave of the grid gets a share
+  hipLaunchKernelGGL(rescore_resident_kernel, dim3(grid), dim3(256), 0, stream, gal_f32, qry_f32, dp, nq, cand_rows,
+                     cand_cnt, rcap, cand_score, sub);
+}
+
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                     const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
   hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>),

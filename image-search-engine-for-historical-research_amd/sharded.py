@@ -46,6 +46,7 @@ class ShardedGallery:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._buf = {}
+        self._join = True
         if self.world > 1:
             self._agree()
 
@@ -80,7 +81,7 @@ class ShardedGallery:
                 osc=torch.empty((nq, k), dtype=torch.float32, device=device))
         return self._buf[key]
 
-    def search(self, q, k, query_norm_none=False, verify=False):
+    def search(self, q, k, query_norm_none=False, verify=False, join=True):
         """q: [Q, D] float32 cuda tensor (same on every rank), Q <= 1024.
         Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.
         query_norm_none: use the queries as they are (expanded queries of alpha-QE).
@@ -89,9 +90,14 @@ class ShardedGallery:
         through sticky flags (include/mi355_retrieval.h).  verify=True synchronises, reads the flags of EVERY shard
         (all-reduce) and, if one is raised anywhere, answers the batch again on all shards with the fallbacks the
         host entry point applies on its own: the rigorous chunk schedule, then the f32 scorer.  The result is exact
-        either way; a caller that batches many searches can instead call `any_flag()` once at the end."""
+        either way; a caller that batches many searches can instead call `any_flag()` once at the end.
+
+        join: only matters when the shard's handle runs in the asynchronous-tail mode (`set_option("async_tail", 1)`,
+        single shard): join=False leaves the exact re-score + sort of this batch running on the handle's own stream
+        beside the scoring launch of the next search; the returned tensors are complete after `self.g.join(stream)`."""
         if query_norm_none:
             self.g.set_option("query_norm_override", _lib.NORM_NONE)
+        self._join = join or verify
         try:
             out = self._search(q, k)
             if verify and self.any_flag():
@@ -134,6 +140,8 @@ class ShardedGallery:
         stream = torch.cuda.current_stream().cuda_stream
         if self.world == 1:
             self.g.search_device(q.data_ptr(), nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), None, stream)
+            if self._join:
+                self.g.join(stream)
             return b["oidx"], b["osc"]
         self.g.phase1_device(q.data_ptr(), nq, k, b["approx"].data_ptr(), stream)
         gathered = all_gather_stacked(b["approx"], self.group)
@@ -146,7 +154,7 @@ class ShardedGallery:
                                        nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), stream)
         return b["oidx"], b["osc"]
 
-    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6):
+    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6, join=True):
         """alpha-QE across shards (src/utils/Reranking.py:195-208): every rank adds the rows it owns into a
         float64 partial sum [Q, D] (`mi_aqe_partial_device`), the partials are all-reduced (8 MiB at Q = 1024,
         D = 2048, f64: the rows of one query may live on any shard), every rank normalises redundantly
@@ -165,5 +173,5 @@ class ShardedGallery:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
         qx = torch.empty((nq, d), dtype=torch.float32, device=ranks.device)
         _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)
-        idx, sc = self.search(qx, k, query_norm_none=True)
+        idx, sc = self.search(qx, k, query_norm_none=True, join=join)
         return idx, sc, qx

@@ -98,6 +98,13 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
                          int64_t* out_idx_dev, float* out_score_dev, double* out_score64_dev,
                          void* stream);
 
+/* Asynchronous tail (mi_set_option "async_tail" = 1): mi_knn_search_device enqueues the scoring / filtering part of a batch
+ * on `stream` and the exact re-score + sort on a stream of the handle, so that the tail of batch i runs beside the scoring
+ * launch of batch i + 1 (the MFMA kernel leaves exactly the registers one re-score wave per SIMD needs and no LDS).  The
+ * outputs of every call made so far are complete, in the order of `stream`, after mi_search_join(g, stream).  Default off:
+ * outputs are then complete in stream order when mi_knn_search_device returns, as before. */
+int mi_search_join(mi_gallery* g, void* stream);
+
 /* Sharded search = phase 1 on every shard, all-gather of approx top-k values, phase 2, all-gather of
  * exact (score64, idx), merge.  New functionality (the reference is single-process).
  * phase 1: bf16 MFMA scoring + survivor filtering; writes the shard's k largest approximate scores

@@ -1,0 +1,38 @@
+# Everything DESIGN.md quotes, on ONE box, kept under gpurun_out/<tag>_* (then: python scripts/summarize_profile.py <tag>;
+# python scripts/collect_record.py <tag>).  Usage on the GPU box: bash scripts/profile_record.sh <tag>
+set -e
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+o=gpurun_out
+# 1. headline bench + its rocprofv3 kernel trace + PMC passes (separate runs, as the microarchitecture guide prescribes)
+python bench.py --steps 20 --warmup 5 > $o/${tag}_bench.json 2> $o/${tag}_bench.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/${tag}_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $o/${tag}_pmc_l2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_l2.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_sq.log 2>&1 || true
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_pmc_grbm -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_grbm.log 2>&1 || true
+echo "pmc done"
+# 2. the other configurations, each as bench line + rocprofv3 kernel stats of the same command
+for v in "q1:--queries 1" "q70:--queries 70" "bf16:--image-dtype bf16" "aqe:--with-aqe" "10m:--workload 10m --steps 5 --warmup 2"; do
+  name=${v%%:*}; args=${v#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_${name}_trace -- python3 bench.py --no-cpu-baseline $args > $o/${tag}_${name}_bench.json 2> $o/${tag}_${name}.err || echo "$name failed"
+  echo "$name done"
+done
+# 3. timelines (per-dispatch) of the full gallery and of a 1/8 shard; scripts
+bash scripts/timeline.sh ${tag}_full > $o/${tag}_timeline_full.txt 2>&1 || true
+bash scripts/timeline.sh ${tag}_s8 --rows 125750 > $o/${tag}_timeline_s8.txt 2>&1 || true
+python scripts/rank_all_timing.py > $o/${tag}_rank_all.txt 2>&1 || true
+python scripts/host_api_rate.py > $o/${tag}_host_api.txt 2>&1 || true
+python scripts/gallery_io_rate.py > $o/${tag}_gallery_io.json 2> /dev/null || true
+python scripts/xcc_report.py > $o/${tag}_xcc_report.txt 2>&1 || true
+python -m pytest tests/test_gpu_diffusion.py -q -s -k reference_size > $o/${tag}_diffusion_refsize.txt 2>&1 || true
+echo "scripts done"
+# 4. kernel A/B driver and MFMA probe (C++, no torch)
+(cd image-search-engine-for-historical-research_amd && ./build/mfma_probe > ../$o/${tag}_mfma_probe.txt 2>&1 || true)
+(cd image-search-engine-for-historical-research_amd && ./build/kbench --rounds 4 --reps 5 default:0 structure1:0:1 nofilter:4 nofilter_s1:4:1 nodma:5 nodma_nofrag:133 filter_stamps:2048 > ../$o/${tag}_kbench.txt 2>&1 || true)
+# 5. multi-rank rehearsal of bench.py (ranks share the GPU, gloo)
+bash scripts/rehearse_sharded.sh 2 > $o/${tag}_rehearse2.txt 2>&1 || true
+bash scripts/rehearse_sharded.sh 4 > $o/${tag}_rehearse4.txt 2>&1 || true
+echo "all done"

@@ -1,6 +1,8 @@
 """Summarises a scripts/profile_round.sh run into profiles/<tag>_*.  Usage: python scripts/summarize_profile.py <tag>"""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 tag = sys.argv[1]
+# the filtered scoring launch of a batch (not the conditional repair instantiation, whose last bool is true)
+MAIN = re.compile(r"gemm_(tile|select)_kernel<false, 0, (true|false), false")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
@@ -27,7 +29,7 @@ def per_launch_values(sub, counter):
     vals = []
     for f in [newest(f"{go}/{tag}_{sub}/*/*counter_collection.csv")] if glob.glob(f"{go}/{tag}_{sub}/*/*counter_collection.csv") else []:
         for r in csv.DictReader(open(f)):
-            if ("gemm_select_kernel<false, 0, true, false>" in r["Kernel_Name"] or "gemm_select_kernel<false, 0, false, false>" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+            if MAIN.search(r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
     return vals
 fv, wv = per_launch_values("pmc_fetch", "FETCH_SIZE"), per_launch_values("pmc_write", "WRITE_SIZE")
@@ -45,5 +47,5 @@ for r in csv.DictReader(open(f"{pr}/{tag}_kernel_stats.csv")):
     print("%-44s calls=%4s avg=%9.1f us  %5s%%" % (r["Name"].split("(")[0].replace("void mi::", "").replace("mi::", "")[:44], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 print({k: v for k, v in out.items() if k.startswith("gemm_select")})
 for k, v in pm.items():
-    if "gemm_select_kernel<false" in k or "rescore" in k:
+    if "gemm_tile_kernel<false" in k or "gemm_select_kernel<false" in k or "rescore" in k:
         print(k, {c: ("%.4g" % (x["sum"] / x["launches"])) for c, x in v.items()})

@@ -121,3 +121,46 @@ def test_large_shard_chunk_schedule_equals_exact_path(lib, img):
         assert g.status()["overflow_batches"] == 0
     finally:
         g.close()
+
+
+def test_async_tail_gives_the_same_answers(lib):
+    """mi_set_option("async_tail", 1): re-score + sort of batch i on the handle's own stream beside the scoring launch of
+    batch i + 1.  Several different batches in flight, distinct output buffers: after mi_search_join every batch equals
+    the synchronous answer bit for bit; a synchronous host search on the same handle in between is unaffected."""
+    import torch
+    n, d, k = 300000, 256, 100
+    raw = _device_rows(lib, 61, n, d)
+    g = lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+    try:
+        qs = [_device_rows(lib, 70 + i, 1024 if i % 2 == 0 else 300, d) for i in range(5)]
+        ref = [_search(g, q, k) for q in qs]
+        g.set_option("async_tail", 1)
+        stream = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for rep in range(2):
+            for q in qs:
+                idx = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
+                sc = torch.empty((q.shape[0], k), dtype=torch.float32, device=q.device)
+                g.search_device(q.data_ptr(), q.shape[0], k, idx.data_ptr(), sc.data_ptr(), None, stream)
+                outs.append((idx, sc))
+        g.join(stream)
+        torch.cuda.synchronize()
+        assert g.flags() == 0
+        for j, (idx, sc) in enumerate(outs):
+            ri, rs = ref[j % len(qs)]
+            assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(sc.cpu().numpy(), rs)
+        # one call of 2500 queries = three batches through both buffer sets
+        big = _device_rows(lib, 90, 2500, d)
+        g.set_option("async_tail", 0)
+        bi, bs = _search(g, big, k)
+        g.set_option("async_tail", 1)
+        idx = torch.empty((2500, k), dtype=torch.int64, device=big.device)
+        sc = torch.empty((2500, k), dtype=torch.float32, device=big.device)
+        g.search_device(big.data_ptr(), 2500, k, idx.data_ptr(), sc.data_ptr(), None, stream)
+        hi, hs, _ = g.search(qs[1].cpu().numpy(), k)                     # host API: synchronous, own staging
+        g.join(stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(idx.cpu().numpy(), bi) and np.array_equal(sc.cpu().numpy(), bs)
+        assert np.array_equal(hi, ref[1][0]) and np.array_equal(hs, ref[1][1])
+    finally:
+        g.close()
