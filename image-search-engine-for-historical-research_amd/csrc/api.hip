@@ -3,6 +3,7 @@
 #include "../../include/mi355_retrieval.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -18,7 +19,7 @@
 using namespace mi;
 
 static thread_local std::string g_err;
-static int g_default_img_f16 = 1;   // mi_set_global_option("image_dtype", 0 = bf16 | 1 = fp16)
+static std::atomic<int> g_default_img_f16{1};   // mi_set_global_option("image_dtype", 0 = bf16 | 1 = fp16); read at gallery creation
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -599,7 +600,7 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
     if (e != hipSuccess) return cleanup(fail(MI_ERR_HIP, std::string("H2D copy: ") + hipGetErrorString(e)));
     src = staged;
   }
-  g->img_f16 = g_default_img_f16;
+  g->img_f16 = g_default_img_f16.load();
   hipError_t e = hipSuccess;
   for (int pass = 0; pass < 2; ++pass) {
     launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat,
@@ -632,7 +633,7 @@ int mi_gallery_create_empty(int64_t capacity, int32_t d, int norm_mode, int devi
   g->d = d;
   g->norm_mode = norm_mode;
   g->row_offset = row_offset;
-  g->img_f16 = (norm_mode == MI_NORM_NONE) ? 0 : g_default_img_f16;   // raw rows of unknown range: bf16 image
+  g->img_f16 = (norm_mode == MI_NORM_NONE) ? 0 : g_default_img_f16.load();   // raw rows of unknown range: bf16 image
   int rc = gallery_alloc(g);
   if (rc == MI_OK) {
     hipError_t e = hipMemset(g->gal_img, 0, (size_t)round_up(capacity, TILE) * g->dp * 2);

@@ -25,10 +25,8 @@ class Diffusion:
         features = np.asarray(features)
         self.N = len(features)
         self.cache_dir = cache_dir
-        if self.N >= 110000:
-            # the reference switches the kNN graph to an approximate IVFPQ index here
-            # (src/utils/diffusion.py:47-49,57-60); this build keeps the graph exact at every size.
-            pass
+        # (for N >= 110000 the reference switches its kNN graph to an approximate IVFPQ index, src/utils/diffusion.py:47-49,
+        # 57-60; QGE never diffuses at that size, src/utils/Reranking.py:212, and this build keeps the graph exact throughout)
         self.gallery = Gallery.from_host(features, norm_mode=NORM_NONE, device=device)
         self.n_trunc = None
 
