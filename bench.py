@@ -24,6 +24,7 @@ WORKLOADS = {
     # name: (gallery rows, description)
     "roxford5k+1m": (1005994, "rOxford5k+1M distractors (synthetic 2048-d), HIP MFMA QxG^T + top-100"),
     "roxford5k": (4993, "rOxford5k-sized synthetic gallery"),
+    "rparis6k+1m": (1007323, "rParis6k+1M distractors (synthetic 2048-d): BASELINE configs[4] with --with-aqe"),
     "10m": (10000000, "synthetic 10Mx2048 gallery"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 = dense f16, /opt/skills/guides/MI355X_MICROARCH.md
