@@ -152,3 +152,22 @@ def test_matching_fractional_dis_bitexact(golden_dir, tag, dt):
     idx = oracle.matching_fractional_dis(k, g, q)
     assert idx.shape == (min(nq, k), k)
     assert np.array_equal(idx, z[f"{tag}_{dt}_idx"])
+
+
+def test_kr_reranking_bitexact(golden_dir):
+    """src/utils/Reranking.py:447-624 (kr_reranking), captured by oracle/make_golden.py from the reference function itself
+    (Tensor.cuda made the identity for that call: no GPU in the build container).  The numpy restatement reproduces the
+    reference's `indices` on every one of the 7 x 400 positions."""
+    z = _load(golden_dir, "kr_rerank.npz")["indices"]
+    vk = synth_rows(98, 0, 400, 32).astype(np.float64)
+    ck = synth_rows(99, 0, 25, 32).astype(np.float64)
+    vk = 0.6 * vk + 1.3 * ck[np.arange(400) % 25]
+    vk /= np.linalg.norm(vk, axis=1, keepdims=True)
+    qk = vk[::57][:7] + 0.15 * synth_rows(100, 0, 7, 32)
+    qk /= np.linalg.norm(qk, axis=1, keepdims=True)
+    idx = oracle.kr_reranking(qk.T.astype(np.float32), vk.T.astype(np.float32))
+    assert idx.shape == z.shape == (7, 400)
+    assert np.array_equal(idx, z)
+    # the re-ranking is not the plain cosine order (the Jaccard term moves images)
+    plain = np.argsort(-(qk @ vk.T), axis=1, kind="stable")
+    assert (idx != plain).mean() > 0.05
