@@ -47,6 +47,8 @@ struct Workspace {
   RowStat* q_stat = nullptr;
   float *thr = nullptr, *margin = nullptr, *thr2 = nullptr;
   uint32_t* qflag = nullptr;
+  float* lad_tc = nullptr;
+  uint32_t *lad_pack = nullptr, *lad_cnt = nullptr;
   uint32_t* cnt = nullptr;
   uint64_t* surv = nullptr;
   uint32_t* flags = nullptr;
@@ -99,6 +101,7 @@ struct mi_gallery {
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
+  int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
   // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 96
   // VGPRs per SIMD lane and no LDS: exactly one re-score wave per SIMD fits next to its two); results are valid after
@@ -164,6 +167,9 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(margin, QB);
   A(thr2, QB);
   A(qflag, QB);
+  A(lad_tc, QB);
+  A(lad_pack, QB);
+  A(lad_cnt, QB);
   A(cnt, (size_t)QB * CNT_STRIDE);
   A(surv, (size_t)QB * ws.cap);
   A(flags, 4);
@@ -210,6 +216,9 @@ static QueryState make_state(const Workspace& ws) {
   st.flags = ws.flags;
   st.thr2 = ws.thr2;
   st.qflag = ws.qflag;
+  st.lad_tc = ws.lad_tc;
+  st.lad_pack = ws.lad_pack;
+  st.lad_cnt = ws.lad_cnt;
   st.cap = ws.cap;
   return st;
 }
@@ -315,6 +324,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   int64_t bound = t0;
   int64_t t = 0, len = t0;
   bool first = true;
+  bool ladder_on = false;           // set for the one filtered launch of the sample-based schedule
   auto score_launch = [&](int64_t tile_from, int64_t ntile, bool first_chunk, const uint32_t* cond, bool profile_it,
                           bool on_sample = false) {
     const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
@@ -349,6 +359,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.rec_cap = ws.rec_cap;
     a.cond = cond;
     a.bal = g->xcc_balance ? ws.bal : nullptr;
+    a.lad_k = ladder_on ? k : 0;
     a.dbg = ws.dbg;
     a.st = st;
     profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
@@ -368,9 +379,24 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   };
   if (samp_r > 0) {
     score_launch(0, t0, true, nullptr, false, true);                           // bootstrap on the sample image
-    if (sample_threshold_applies(first_cnt, k, samp_r)) launch_sample_threshold(st, nq, k, samp_r, s);
-    else launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
+    // in-launch ladder: a tighter sample order statistic (rank j < r) becomes a rigorous threshold once K rows above it have
+    // been counted during the launch.  In units of N / n_s rows: score(j) has expected rank j in the shard and is validated
+    // after the fraction lambda / j of the rows (lambda = K n_s / N), so the survivors are ~ (lambda / j) r + (1 - lambda / j) j,
+    // smallest at j = sqrt(lambda r) (3 at N = 1M, K = 100: 1500 -> 900 survivors per query)
+    int32_t lad_r = 0;
+    if (g->ladder && samp_r > 1) {
+      const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
+      lad_r = (int32_t)std::lround(std::sqrt(lambda * samp_r));
+      lad_r = std::max<int32_t>(1, std::min<int32_t>(lad_r, samp_r - 1));
+    }
+    if (sample_threshold_applies(first_cnt, k, samp_r)) {
+      launch_sample_threshold(st, nq, k, samp_r, s, lad_r);
+      ladder_on = lad_r > 0;
+    } else {
+      launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
+    }
     score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
+    ladder_on = false;
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 0, nullptr, s, fc_rows, fc_cnt, ws.rcap);
     // repair pass for queries whose speculative threshold failed verification: conditional on the device word
     // flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip
@@ -1763,6 +1789,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "small_batch_kernel") *out_value = g->small_batch_kernel;
   else if (n == "kernel_variant") *out_value = g->kernel_variant;
   else if (n == "xcc_balance") *out_value = g->xcc_balance;
+  else if (n == "ladder") *out_value = g->ladder;
   else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
@@ -1790,6 +1817,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
+  else if (n == "ladder") g->ladder = value != 0;
   else if (n == "async_tail") g->async_tail = value != 0;
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");

@@ -42,6 +42,20 @@ __device__ __forceinline__ float key2f(uint32_t k) {
   return __uint_as_float(u);
 }
 
+// f32 -> upper 16 bits (bf16 layout), rounded toward -inf: a threshold may only get looser by the packing
+__host__ __device__ __forceinline__ uint32_t bf16_down(float f) {
+  uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u = __float_as_uint(f);
+#else
+  __builtin_memcpy(&u, &f, 4);
+#endif
+  if (f != f) return 0xFF80u;                                  // NaN -> -inf (nothing is filtered out)
+  uint32_t hi = u >> 16;
+  if ((u & 0x80000000u) && (u & 0xFFFFu)) hi += 1;             // negative: truncation rounds up, step one down
+  return hi & 0xFFFFu;
+}
+
 // survivor entry: (score bits << 32) | local row
 __device__ __forceinline__ uint64_t pack_entry(float s, uint32_t row) {
   return ((uint64_t)__float_as_uint(s) << 32) | row;
@@ -90,6 +104,10 @@ struct QueryState {       // all arrays sized for qpad queries
   uint32_t* flags;        // [0] sticky error flags, [1] 'repair needed' word of the current batch (speculative threshold)
   float* thr2;            // fallback (looser) speculative threshold per query
   uint32_t* qflag;        // per query: 1 = its speculative threshold failed verification, repair it
+  // in-launch threshold ladder (tile kernel, single-launch schedule; DESIGN.md "Thresholds while streaming" (iii)):
+  float* lad_tc;          // count level t_c: a sample order statistic tighter than the speculative one (+inf = off)
+  uint32_t* lad_pack;     // bf16(thr, rounded down) | bf16(t_c - margin, rounded down) << 16: the two thresholds a wave may apply
+  uint32_t* lad_cnt;      // rows seen with approx >= t_c; once >= K, t_c - margin is a RIGOROUS threshold
   uint32_t cap;
 };
 

@@ -42,6 +42,7 @@ constexpr int RING_BYTES = (A_SLOTS + B_SLOTS) * SLICE_BYTES;             // 144
 constexpr int HIT_SLOTS = 8;                                // per-wave filter scratch: 8 (lane, block) pairs x 32 scores + meta
 constexpr int WAVE_SCRATCH = HIT_SLOTS * 32 * 4 + HIT_SLOTS * 16;         // 1152 B
 constexpr int STAGE_BYTES = 8 * WAVE_SCRATCH;               // 9 KiB per workgroup
+constexpr int THR_WORDS = 192;                              // per wave: thresholds | ladder counters | ladder levels (64 each)
 
 // LDS stores of the filter scratch as inline asm.  The compiler orders every DS store it can see behind ALL pending
 // LDS-DMA transfers (it cannot tell that the scratch and the rings are disjoint) with an s_waitcnt vmcnt(0), which
@@ -503,8 +504,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     constexpr int GRP = decltype(grp_tag)::value;              // wave group = gallery half; 0 streams A, 1 streams B
     constexpr int MY_SLOTS = GRP == 0 ? A_SLOTS : B_SLOTS;
     constexpr bool dbg_nodma = (DBG & 1) || ((DBG & 32) && GRP == 0) || ((DBG & 64) && GRP == 1);
-    float* thr_w = reinterpret_cast<float*>(smem + RING_BYTES + STAGE_BYTES) + w * 64;
+    // per-wave threshold words of its 64 queries: [0..63] threshold (f32) -- or, ladder on, the packed pair of thresholds --,
+    // [64..127] ladder counters (refreshed by a 256-byte DMA per tile), [128..191] ladder count levels t_c
+    float* thr_w = reinterpret_cast<float*>(smem + RING_BYTES + STAGE_BYTES) + w * THR_WORDS;
+    const bool lad = !FIRST && !REPAIR && p.lad_k > 0 && p.st.lad_cnt != nullptr;
+    const uint32_t* lad_cnt_src = p.st.lad_cnt;                 // + query of this lane, set with the thresholds
     uint32_t thr_qt = 0xFFFFFFFFu;
+    auto load_thresholds = [&](uint32_t qt) {                   // plain loads: drains the DMA rings (query tile changes only)
+      const uint32_t q = qt * TILE + wc * 64 + lane;
+      if (lad) {
+        reinterpret_cast<uint32_t*>(thr_w)[lane] = p.st.lad_pack[q];
+        reinterpret_cast<uint32_t*>(thr_w)[64 + lane] = p.st.lad_cnt[q];
+        thr_w[128 + lane] = p.st.lad_tc[q];
+      } else {
+        thr_w[lane] = p.st.thr[q];
+      }
+      thr_qt = qt;
+    };
+    // ladder: this wave's 64 counters, straight into LDS (one 4-byte-per-lane DMA piece in the wave's vmcnt order)
+    auto refresh_counts = [&](uint32_t qt) {
+      if (lad && qt == thr_qt)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(lad_cnt_src + qt * TILE + wc * 64 + lane),
+                                         (LDS_AS void*)(thr_w + 64), 4, 0, 0);
+    };
     auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
       const uint32_t v = j + i * nwg;
       qt = v % nqt;
@@ -592,10 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
         // block) pair, and the write path of the LDS is what the scratch variant waits for.  One scan of the list at the
         // end of the tile emits the records.
         constexpr uint32_t ENT = WAVE_SCRATCH / 24;                 // 48 entries: 16 B of scores + 8 B (threshold, position)
-        if (qt != thr_qt) {
-          thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
-          thr_qt = qt;
-        }
+        if (qt != thr_qt) load_thresholds(qt);
         const uint32_t vals_lds = sc_val_lds, meta_lds = sc_val_lds + ENT * 16u;
         const uint32_t tile_row0 = gt * TILE + GRP * 128, tile_q0 = qt * TILE + wc * 64;
         const uint32_t pk_lane = (uint32_t)l15 | ((uint32_t)lq << 9);
@@ -662,10 +681,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
         // Filter variant B (A/B): no LDS.  Every accumulator is compared with its query's threshold (one v_cmp into a
         // scalar lane mask each); the four masks of one 16 x 16 block are OR-ed and ONE wave-uniform branch per block
         // skips the append, which runs for ~11 of the 128 blocks of a tile.
-        if (qt != thr_qt) {
-          thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
-          thr_qt = qt;
-        }
+        if (qt != thr_qt) load_thresholds(qt);
         unsigned long long fb0 = 0;
         if (DBG & 2048) fb0 = stamp();
 #pragma unroll
@@ -698,10 +714,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
         }
         if (DBG & 2048) { fdbg[0] += stamp() - fb0; fdbg[5] += 1; }
       } else {
-        if (qt != thr_qt) {
-          thr_w[lane] = p.st.thr[qt * TILE + wc * 64 + lane];
-          thr_qt = qt;
-        }
+        if (qt != thr_qt) load_thresholds(qt);
         unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
         if (DBG & 2048) f0 = stamp();
         float thr4[4];
@@ -710,7 +723,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
         base[0] = 0;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-          thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
+          if (lad) {
+            // the tighter threshold t_c - margin once K rows with approx >= t_c have been counted (by any wave of the
+            // launch: the counter is a fact about rows already scored, so it is a rigorous bound whenever it is read)
+            const uint32_t pk = reinterpret_cast<const uint32_t*>(thr_w)[nb * 16 + l15];
+            // the counters are written by this wave's own DMA piece, issued a tile ago and long retired by the counted
+            // vmcnt waits of the slices in between; read through asm so that the compiler does not order the read behind
+            // ALL pending DMA with a vmcnt(0), which would drain the rings at every tile boundary
+            uint32_t cnt;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cnt) : "v"(lds_addr(thr_w + 64 + nb * 16 + l15)) : "memory");
+            thr4[nb] = __uint_as_float(cnt >= (uint32_t)p.lad_k ? (pk & 0xFFFF0000u) : (pk << 16));
+          } else {
+            thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
+          }
           float m = acc[0][nb][0];
 #pragma unroll
           for (int mb = 0; mb < 8; ++mb)
@@ -741,19 +766,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
               lds_store16<96>(dst, acc[6][nb]);
               lds_store16<112>(dst, acc[7][nb]);
               lds_store16u(sc_meta_lds + (rank - r0) * 16,
-                           (u32x4){__float_as_uint(thr4[nb]), ql_base + nb * 16, row_base, 0u});
+                           (u32x4){__float_as_uint(thr4[nb]), ql_base + nb * 16, row_base,
+                                   lad ? __float_as_uint(thr_w[128 + nb * 16 + l15]) : 0x7F800000u});
             }
           }
           const uint32_t nslots = min(total - r0, (uint32_t)HIT_SLOTS);
           if (DBG & 2048) { f2 = stamp(); fdbg[1] += f2 - f1; }
           constexpr int SCAN = HIT_SLOTS * 32 / 64;
-          u32x3 mt[SCAN];                                              // (threshold, query, row base)
+          u32x4 mt[SCAN];                                              // (threshold, query, row base, ladder level t_c)
           float vv[SCAN];
 #pragma unroll
           for (int it = 0; it < SCAN; ++it) {
             const uint32_t e = it * 64 + lane;
             const bool valid = e < nslots * 32;
-            asm volatile("ds_read_b96 %0, %2\n\tds_read_b32 %1, %3"
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3"
                          : "=&v"(mt[it]), "=v"(vv[it])
                          : "v"(sc_meta_lds + (valid ? (e >> 5) : 0u) * 16u), "v"(sc_val_lds + (valid ? e : 0u) * 4u)
                          : "memory");
@@ -777,6 +803,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
               if (!(DBG & 1024) && keep && pos < p.rec_cap)          // DBG 1024: no record stores (diagnostics)
                 reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(vv[it]), row, mt[it].y, 0u);
+              if (lad && keep && vv[it] >= __uint_as_float(mt[it].w)) atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
               if (DBG & 1024) asm volatile("" ::"v"(pos), "v"(row));
               my_cnt += (uint32_t)__popcll(km);
             }
@@ -891,6 +918,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       // so no fragment register is live across the filter: the kernel's VGPR peak is the loop's, not loop + filter.
       {
         frag_t af[8], bfr[4];
+        refresh_counts(qt);
         if constexpr (GRP == 0) {
           const char* abase = smem + a_rd * SLICE_BYTES;
           const char* bbase = smem + b_rd * SLICE_BYTES;
@@ -935,6 +963,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     }
     if (p.dbg && lane == 0) {
       unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
+      dbgp[3] = my_cnt;                                                              // records this wave emitted
       dbgp[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF;   // HW_REG_XCC_ID[3:0]
       dbgp[5] = (unsigned long long)my_tiles * KSL;
       if (DBG & 2048) {                      // filter stamps in slots 0..3, hits << 32 | tiles in 4... (diagnostics)
@@ -1083,7 +1112,7 @@ static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
 
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
-  const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * 64 * 4;
+  const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * THR_WORDS * 4;      // 162,816 B of the 163,840
   if (a.variant != 1) {                                          // structure 2 (default); variant 1 = structure 1 (A/B)
     // MFMA issue order: 3 = query-block-major snake (default: every MFMA shares an operand with its predecessor; bit-identical
     // results, +0.8 % over plain query-block-major and +4 % over gallery-block-major by the clock the chip holds)

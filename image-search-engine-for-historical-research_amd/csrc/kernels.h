@@ -33,6 +33,7 @@ struct ScoreArgs {
   uint32_t rec_cap;
   const uint32_t* cond;   // non-null: the whole launch is skipped when *cond == 0 (repair pass)
   const XccBalance* bal = nullptr;   // non-null: weighted split of the gallery tiles over the XCD labels (tile kernel)
+  int32_t lad_k = 0;                 // > 0: in-launch threshold ladder on (K of the search); tile kernel, filtered launch only
   unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
@@ -71,7 +72,7 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
 // thresholds from the 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
-void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream);
+void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream, int32_t lad_r = 0);
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows = nullptr, uint32_t* cand_cnt = nullptr,

@@ -123,6 +123,11 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
     st.margin[q] = 0.f;
     st.cnt[q * CNT_STRIDE] = 0;
   }
+  if (st.lad_tc) {                        // ladder off until a sample-threshold launch turns it on
+    st.lad_tc[q] = INFINITY;
+    st.lad_pack[q] = 0x7F807F80u;         // (+inf, +inf)
+    st.lad_cnt[q] = 0;
+  }
 }
 
 void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t nq, int32_t qpad, float gamma,
@@ -225,7 +230,10 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
   bool failed = false;
   if (MODE == 1 && spec) {
     const float used = st.thr[q];
-    failed = (used > -INFINITY) && !(n >= (uint32_t)k && L - st.margin[q] >= used);
+    // ladder validated: >= K rows with approx >= t_c were emitted, so L >= t_c and every row with approx >= t_c - margin
+    // (the tightest threshold any wave applied) is among the survivors: nothing speculative is left to verify
+    const bool lad_ok = st.lad_cnt && !repair && st.lad_cnt[q] >= (uint32_t)k && n >= (uint32_t)k;
+    failed = !lad_ok && (used > -INFINITY) && !(n >= (uint32_t)k && L - st.margin[q] >= used);
     if (failed) thr_new = st.thr2[q];
   }
   float* tv = topvals + (uint64_t)q * k;
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
       st.thr[q] = thr_new;
       st.cnt[q * CNT_STRIDE] = sh[2];
     }
-    if (MODE == 1 && stats2 && !failed)
-      atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)sh[2]);
+    if (MODE == 1 && stats2 && !failed)        // survivors = entries the filter kept (before the cut at L - margin)
+      atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)n);
     if (MODE == 1 && cand_rows) {
       // a query whose speculative threshold failed has no candidate list yet (the repair launch writes it; if that fails
       // too the batch is flagged and answered again): its count must still be defined, the re-score reads it
@@ -322,7 +330,8 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 // gathered and ranked exactly by counting.  Falls back to the plain select if more than 256 values qualify (ties).
 // The sample entries are dropped afterwards (cnt = 0), like select_maintain_kernel<0> with spec != 0.
 constexpr int SAMP_THREADS = 512, SAMP_PER_THREAD = 16;    // 8192 sample scores
-__global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r) {
+__global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
+                                                                        int32_t lad_r) {
   __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (32 KiB)
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sh[8];
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
   const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);   // wanted ranks, w1 <= w2 <= 256
   uint32_t* maxima = keys;                                  // 512 keys
   maxima[threadIdx.x] = kmax;
-  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; }
+  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
   __syncthreads();
   const uint32_t t0 = block_kth_largest(maxima, SAMP_THREADS, w2, hist, sh);
   __syncthreads();
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     }
   __syncthreads();
   const uint32_t m = sh[3];
-  uint32_t key1, key2;
+  uint32_t key1, key2, key3 = 0;
   if (m <= 256) {
     if (threadIdx.x < m) {
       const uint32_t me = hist[threadIdx.x];
@@ -360,10 +369,12 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
       for (uint32_t j = 0; j < m; ++j) { gt += hist[j] > me; ge += hist[j] >= me; }
       if (gt < w1 && w1 <= ge) sh[4] = me;
       if (gt < w2 && w2 <= ge) sh[5] = me;
+      if (lad_r > 0 && gt < (uint32_t)lad_r && (uint32_t)lad_r <= ge) sh[6] = me;
     }
     __syncthreads();
     key1 = sh[4];
     key2 = sh[5];
+    key3 = sh[6];
   } else {                                                  // a crowd of ties: plain selects over all keys
     __syncthreads();
 #pragma unroll
@@ -371,6 +382,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     __syncthreads();
     key1 = block_kth_largest(keys, n, w1, hist, sh);
     key2 = block_kth_largest(keys, n, w2, hist, sh);
+    if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist, sh);
   }
   if (threadIdx.x == 0) {
     const float margin = st.margin[q];
@@ -381,6 +393,15 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     st.thr[q] = excluded ? INFINITY : thr;
     st.thr2[q] = excluded ? INFINITY : thr2;
     st.cnt[q * CNT_STRIDE] = 0;
+    if (st.lad_tc) {
+      // ladder level: t_c = score(lad_r), lad_r < r, so t_c >= score(r) >= every threshold a wave applies and every row
+      // with approx >= t_c is emitted and counted; once K are counted, L >= t_c and t_c - margin is a rigorous threshold
+      const bool on = lad_r > 0 && !excluded;
+      const float tc = on ? key2f(key3) : INFINITY;
+      st.lad_tc[q] = tc;
+      st.lad_pack[q] = bf16_down(excluded ? INFINITY : thr) | (bf16_down(on ? tc - margin : INFINITY) << 16);
+      st.lad_cnt[q] = 0;
+    }
   }
 }
 
@@ -389,8 +410,8 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
          (int64_t)first_cnt >= k;
 }
 
-void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream) {
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r);
+void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream, int32_t lad_r) {
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -164,3 +164,37 @@ def test_async_tail_gives_the_same_answers(lib):
         assert np.array_equal(hi, ref[1][0]) and np.array_equal(hs, ref[1][1])
     finally:
         g.close()
+
+
+def test_ladder_thresholds_keep_the_answer_and_cut_the_survivors(lib):
+    """In-launch ladder (csrc/common.h QueryState::lad_*): a tighter sample order statistic t_c becomes a RIGOROUS threshold
+    for a query once K rows with approximate score >= t_c have been counted during the launch.  Answers are identical with
+    the ladder on and off; the filter keeps fewer rows with it; an ordered gallery (every strong match in the first rows,
+    the layout of src/test_rOP1m.py:136-139) and a query with fewer than K rows above its level are handled."""
+    import torch
+    n, d, k = 400000, 256, 100
+    raw = _device_rows(lib, 81, n, d)
+    q = _device_rows(lib, 82, 1024, d)
+    for qi in range(40):                                   # 300 strong matches of 40 queries, all inside the first 12000 rows
+        raw[qi * 300:(qi + 1) * 300] = q[qi] * 0.5 + 0.6 * raw[qi * 300:(qi + 1) * 300]
+    raw[300000] = q[900] * 3.0                             # a single outlier match for one query
+    torch.cuda.synchronize()
+    g = lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+    try:
+        res = {}
+        for lad in (0, 1):
+            g.set_option("ladder", lad)
+            g.status(reset=True)
+            idx, sc = _search(g, q, k)
+            st = g.status()
+            assert st["overflow_batches"] == 0
+            res[lad] = (idx, sc, st["survivors"] / st["queries"], st["candidates"] / st["queries"])
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert res[0][3] == res[1][3]                      # same candidate sets
+        assert res[1][2] < 0.8 * res[0][2], (res[0][2], res[1][2])
+        assert res[1][0][900, 0] == 300000
+        g.set_option("force_exact", 1)
+        idx_e, sc_e = _search(g, q, k)
+        assert np.array_equal(res[1][0], idx_e) and np.array_equal(res[1][1], sc_e)
+    finally:
+        g.close()
