@@ -30,6 +30,7 @@ python scripts/xcc_report.py > $o/${tag}_xcc_report.txt 2>&1 || true
 python -m pytest tests/test_gpu_diffusion.py -q -s -k reference_size > $o/${tag}_diffusion_refsize.txt 2>&1 || true
 echo "scripts done"
 # 4. kernel A/B driver and MFMA probe (C++, no torch)
+bash scripts/kbench_build.sh > /dev/null 2>&1 || true    # the driver shares struct layouts with the library: never run a stale one
 (cd image-search-engine-for-historical-research_amd && ./build/mfma_probe > ../$o/${tag}_mfma_probe.txt 2>&1 || true)
 (cd image-search-engine-for-historical-research_amd && ./build/kbench --rounds 4 --reps 5 default:0 structure1:0:1 nofilter:4 nofilter_s1:4:1 nodma:5 nodma_nofrag:133 filter_stamps:2048 > ../$o/${tag}_kbench.txt 2>&1 || true)
 # 5. multi-rank rehearsal of bench.py (ranks share the GPU, gloo)
