@@ -960,12 +960,13 @@ static int read_and_clear_flags(mi_gallery* g, uint32_t* flags) {
   return MI_OK;
 }
 
-static int dense_search_device_fwd(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm,
-                                   int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, hipStream_t s);
+static int dense64_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm,
+                                 int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, double* out_score64_dev,
+                                 hipStream_t s);
 
-// synchronous search with overflow handling: bf16 pass, then (if buffers overflowed) the f32-scored filter pass, then
-// (massive ties: thousands of rows within the margin of the K-th score) the dense path, which scores every row in f32
-// and breaks ties by index
+// synchronous search with overflow handling: 16-bit MFMA pass, then (if buffers overflowed) the f32-scored filter pass,
+// then (massive ties: more rows within the margin of the K-th score than the buffers hold) the dense f64 path: every
+// score at full precision, exact top-k of the dense matrix -- the same contract as the filtered paths, at any data
 static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs, int64_t cs, int q_norm, int64_t nq,
                        int32_t k, int64_t* idx_dev, float* score_dev, double* score64_dev) {
   hipStream_t s = g->stream;
@@ -979,8 +980,9 @@ static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs
     bool exact = g->force_exact != 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
       if (attempt == 2) {
-        if ((rc = dense_search_device_fwd(g, src, q_dtype, rs, cs, q_norm, b, k, idx_dev + q0 * k,
-                                          score_dev ? score_dev + q0 * k : nullptr, s)) != MI_OK)
+        if ((rc = dense64_search_device(g, src, q_dtype, rs, cs, q_norm, b, k, idx_dev + q0 * k,
+                                        score_dev ? score_dev + q0 * k : nullptr,
+                                        score64_dev ? score64_dev + q0 * k : nullptr, s)) != MI_OK)
           return rc;
         break;
       }
@@ -993,7 +995,7 @@ static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs
       if ((rc = read_and_clear_flags(g, &flags)) != MI_OK) return rc;
       if (!flags) break;
       g->stats.overflow_batches += 1;
-      if (exact && g->exact_fallback && !score64_dev && k <= 4096) continue;      // -> dense path
+      if (exact && g->exact_fallback && k <= 4096) continue;      // -> dense f64 path
       if (exact || !g->exact_fallback)
         return fail(MI_ERR_OVERFLOW,
                     "candidate buffers overflowed (more than survivor_cap / rescore_cap rows within the error margin "
@@ -1245,9 +1247,33 @@ int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t r
 }
 }  // namespace
 
-static int dense_search_device_fwd(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm,
-                                   int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, hipStream_t s) {
-  return dense_search_device(g, q_src, q_dtype, rs, cs, q_norm, nq, k, out_idx_dev, out_score_dev, s);
+// the same at full precision (search_sync's last resort): dense f64 scores of a sub-batch of queries (<= 2 GiB of scores
+// at a time), exact top-k by (f64 score desc, idx asc)
+static int dense64_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t rs, int64_t cs, int q_norm,
+                                 int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev, double* out_score64_dev,
+                                 hipStream_t s) {
+  REQUIRE(k >= 1 && (int64_t)k <= g->n && k <= 4096, "dense top-k supports k <= min(N, 4096)");
+  int rc = ws_ensure(g, std::min<int32_t>(k, 1024));
+  if (rc != MI_OK) return rc;
+  Workspace& ws = g->ws;
+  const int64_t qb = std::min<int64_t>(QB, std::max<int64_t>(16, ((int64_t)1 << 28) / g->n));
+  TmpAlloc tmp;
+  double* dense = tmp.get<double>((size_t)qb * g->n);
+  if (!dense) return fail(MI_ERR_NOMEM, "dense f64 score buffer");
+  const size_t esz = q_dtype == MI_F32 ? 4 : 8;
+  for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+    const int32_t b = (int32_t)std::min<int64_t>(qb, nq - q0);
+    const int32_t qpad = (int32_t)round_up(b, TILE);
+    launch_ingest((const char*)q_src + (size_t)q0 * rs * esz, q_dtype, b, g->d, rs, cs, q_norm, ws.q_f32, ws.q_img,
+                  g->img_f16, ws.q_stat, g->dp, qpad, s);
+    launch_dense_score64(g->gal_f32, ws.q_f32, g->dp, g->n, b, dense, g->n, s);
+    launch_dense_topk64(dense, g->n, g->n, b, k, g->row_offset, out_idx_dev + q0 * k,
+                        out_score_dev ? out_score_dev + q0 * k : nullptr,
+                        out_score64_dev ? out_score64_dev + q0 * k : nullptr, s);
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipStreamSynchronize(s));      // `dense` is freed on return
+  return MI_OK;
 }
 
 extern "C" {

@@ -127,6 +127,145 @@ __global__ __launch_bounds__(512) void dense_topk_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Last resort of the exhaustive search (csrc/api.hip search_sync): data with MASSIVE ties -- more rows within the error
+// margin of the K-th score than any candidate buffer holds (thousands of near-duplicates of one image).  No filter can
+// help there, so every score is computed at full precision (f32 stored rows, exact f64 products, f64 accumulation: the
+// arithmetic of rescore_kernel) into a dense [queries][rows] f64 matrix and the exact top-k is selected from it.
+// LDS-tiled 64 queries x 64 rows per workgroup, 4 x 4 per thread, v_fma_f64; throughput is irrelevant next to
+// correctness here (the filtered path never gets this far on descriptor data).
+__global__ __launch_bounds__(256) void dense_score64_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
+                                                            int32_t dp, int64_t n, int32_t nq, double* __restrict__ out,
+                                                            int64_t ld) {
+  __shared__ double Qs[16][65];
+  __shared__ double Gs[16][65];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int q0 = blockIdx.y * 64;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  const int lr = t >> 2, lk = (t & 3) * 4;
+  for (int k0 = 0; k0 < dp; k0 += 16) {           // dp is a multiple of 64
+    __syncthreads();
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), qv = gv;
+    if (row0 + lr < n) gv = *reinterpret_cast<const float4*>(gal + (uint64_t)(row0 + lr) * dp + k0 + lk);
+    if (q0 + lr < nq) qv = *reinterpret_cast<const float4*>(qry + (uint64_t)(q0 + lr) * dp + k0 + lk);
+    Gs[lk][lr] = (double)gv.x; Gs[lk + 1][lr] = (double)gv.y; Gs[lk + 2][lr] = (double)gv.z; Gs[lk + 3][lr] = (double)gv.w;
+    Qs[lk][lr] = (double)qv.x; Qs[lk + 1][lr] = (double)qv.y; Qs[lk + 2][lr] = (double)qv.z; Qs[lk + 3][lr] = (double)qv.w;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Qs[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Gs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + ty * 4 + i;
+    if (q >= nq) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = row0 + tx * 4 + j;
+      if (r < n) out[(uint64_t)q * ld + r] = acc[i][j];
+    }
+  }
+}
+
+// order-preserving 64-bit key of an f64 score: NaN lowest, -0 == +0
+__device__ __forceinline__ uint64_t d2key(double d) {
+  if (d != d) return 0ull;
+  d += 0.0;
+  const uint64_t u = (uint64_t)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// dense_topk_kernel on f64 rows: the 64-bit key of the k-th largest score is found in two 32-bit radix selects (high
+// word, then low word among the rows that share it), the rest is the same (index select among exact ties, collect,
+// bitonic sort by (score desc, idx asc)).
+__global__ __launch_bounds__(512) void dense_topk64_kernel(const double* __restrict__ scores, int64_t ld, uint32_t n,
+                                                           int32_t k, int64_t row_offset, int64_t* __restrict__ out_idx,
+                                                           float* __restrict__ out_score, double* __restrict__ out_score64) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t q = blockIdx.x;
+  const double* row = scores + (uint64_t)q * ld;
+  uint32_t k2 = 2;
+  while (k2 < (uint32_t)k) k2 <<= 1;
+  double* s = reinterpret_cast<double*>(smem);
+  uint32_t* id = reinterpret_cast<uint32_t*>(smem + (size_t)k2 * 8);
+  uint32_t* hist = id + k2;
+  uint32_t* sh = hist + 256;                     // [0,1] radix select; [2] above (high word); [3] collect; [4] above (key)
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t hiK = block_radix_kth_largest(
+      [&](uint32_t i, uint32_t& key) { key = (uint32_t)(d2key(row[i]) >> 32); return true; }, n, (uint32_t)k, hist, sh);
+  uint32_t cnt = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cnt += ((uint32_t)(d2key(row[i]) >> 32) > hiK);
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&sh[2], cnt);
+  __syncthreads();
+  const uint32_t need_lo = (uint32_t)k - sh[2];              // >= 1
+  __syncthreads();
+  const uint32_t loK = block_radix_kth_largest(
+      [&](uint32_t i, uint32_t& key) {
+        const uint64_t kk = d2key(row[i]);
+        key = (uint32_t)kk;
+        return (uint32_t)(kk >> 32) == hiK;
+      },
+      n, need_lo, hist, sh);
+  const uint64_t keyK = ((uint64_t)hiK << 32) | loK;
+  cnt = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cnt += (d2key(row[i]) > keyK);
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&sh[4], cnt);
+  __syncthreads();
+  const uint32_t need_ties = (uint32_t)k - sh[4];            // >= 1
+  __syncthreads();
+  const uint32_t invT = block_radix_kth_largest(
+      [&](uint32_t i, uint32_t& key) { key = ~i; return d2key(row[i]) == keyK; }, n, need_ties, hist, sh);
+  const uint32_t idxT = ~invT;
+  for (uint32_t i = threadIdx.x; i < k2; i += blockDim.x) { s[i] = -INFINITY; id[i] = 0xFFFFFFFFu; }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = row[i];
+    const uint64_t key = d2key(v);
+    if (key > keyK || (key == keyK && i <= idxT)) {
+      const uint32_t pos = atomicAdd(&sh[3], 1u);
+      if (pos < k2) { s[pos] = v; id[pos] = i; }
+    }
+  }
+  bitonic_sort_desc_t<double, uint32_t>(s, id, k2);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
+    out_idx[(uint64_t)q * k + i] = row_offset + (int64_t)id[i];
+    if (out_score) out_score[(uint64_t)q * k + i] = (float)s[i];
+    if (out_score64) out_score64[(uint64_t)q * k + i] = s[i];
+  }
+}
+
+void launch_dense_score64(const float* gal_f32, const float* qry_f32, int32_t dp, int64_t n, int32_t nq, double* out,
+                          int64_t ld, hipStream_t stream) {
+  hipLaunchKernelGGL(dense_score64_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((nq + 63) / 64)), dim3(256), 0, stream,
+                     gal_f32, qry_f32, dp, n, nq, out, ld);
+}
+
+void launch_dense_topk64(const double* scores, int64_t ld, int64_t n, int32_t nq, int32_t k, int64_t row_offset,
+                         int64_t* out_idx, float* out_score, double* out_score64, hipStream_t stream) {
+  uint32_t k2 = 2;
+  while (k2 < (uint32_t)k) k2 <<= 1;
+  const size_t lds = (size_t)k2 * 12 + 256 * 4 + 32;
+  hipLaunchKernelGGL(dense_topk64_kernel, dim3(nq), dim3(512), lds, stream, scores, ld, (uint32_t)n, k, row_offset, out_idx,
+                     out_score, out_score64);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Full-length ranking: `np.argsort(-scores, axis=0)` over ALL rows (src/main_retrieve.py:176,
 // src/utils/Reranking.py:207, --mode mAP of src/test_rOP1m.py:144-149).  One 1024-thread workgroup per query runs a
 // stable LSD radix sort (4 passes of 8 bits) on key = ~f2key(score) with the row index as payload, so the result is

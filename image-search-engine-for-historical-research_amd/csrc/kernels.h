@@ -95,6 +95,11 @@ void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, in
 void launch_dense_topk(const float* scores, int64_t ld, int64_t n, int32_t nq, int32_t k, int64_t row_offset,
                        int64_t* out_idx, float* out_score, hipStream_t stream);
 
+// last resort of the exhaustive search (massive ties): dense f64 scores of every row + exact top-k of them
+void launch_dense_score64(const float* gal_f32, const float* qry_f32, int32_t dp, int64_t n, int32_t nq, double* out,
+                          int64_t ld, hipStream_t stream);
+void launch_dense_topk64(const double* scores, int64_t ld, int64_t n, int32_t nq, int32_t k, int64_t row_offset,
+                         int64_t* out_idx, float* out_score, double* out_score64, hipStream_t stream);
 void launch_rank_all(const float* scores, int64_t ld, int64_t n, int32_t nq, uint32_t* keys_a, uint32_t* idx_a,
                      uint32_t* keys_b, uint32_t* idx_b, int64_t row_offset, int64_t* out_idx, float* out_score,
                      hipStream_t stream);

@@ -90,6 +90,62 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe(const f16x8* __re
   }
 }
 
+
+// the same ping-pong / free-running stream with v_mfma_f32_32x32x16_f16: wave tile 128 x 64 = 4 x 2 blocks, two k halves per
+// 32-deep slice -> 16 MFMAs of 8 passes per slice instead of 32 of 4 passes; half the operand-register reads per flop
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe32(const f16x8* __restrict__ src, float* __restrict__ sink,
+                                                                 unsigned long long* __restrict__ clk, int iters) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = (WAVES == 8) ? (w >> 2) : 0;
+  f16x8 af[4][2], bf[2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[i >> 1][i & 1] = src[(blockIdx.x * 12 + i) * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bf[i >> 1][i & 1] = src[(blockIdx.x * 12 + 8 + i) * 64 + lane];
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
+  __syncthreads();
+  if (MODE != 0 && grp == 1) __builtin_amdgcn_s_barrier();
+  const unsigned long long c0 = stamp(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+    if (MODE != 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb][kh], bf[nb][kh], acc[mb][nb], 0, 0, 0);
+    if (MODE != 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(af[i >> 1][i & 1]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(bf[i >> 1][i & 1]));
+  }
+  const unsigned long long c1 = stamp(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (MODE != 0 && grp == 0) __builtin_amdgcn_s_barrier();
+  float s = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[mb][nb][e];
+  sink[blockIdx.x * WAVES * 64 + tid] = s;
+  if (lane == 0) {
+    clk[(blockIdx.x * WAVES + w) * 2] = c1 - c0;
+    clk[(blockIdx.x * WAVES + w) * 2 + 1] = r1 - r0;
+  }
+}
+
 __global__ void fill(uint16_t* p, size_t n, float scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned long long x = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
@@ -103,7 +159,7 @@ __global__ void fill(uint16_t* p, size_t n, float scale) {
   }
 }
 
-template <int WAVES, int MODE, int ORDER>
+template <int WAVES, int MODE, int ORDER, int SHAPE = 0>
 static void run(const char* name, const f16x8* src, float* sink, unsigned long long* clk, int iters, int grid) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -111,7 +167,10 @@ static void run(const char* name, const f16x8* src, float* sink, unsigned long l
   std::vector<float> ms;
   for (int r = 0; r < 4; ++r) {
     CK(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL((probe<WAVES, MODE, ORDER>), dim3(grid), dim3(WAVES * 64), 0, nullptr, src, sink, clk, iters);
+    if (SHAPE == 0)
+      hipLaunchKernelGGL((probe<WAVES, MODE, ORDER>), dim3(grid), dim3(WAVES * 64), 0, nullptr, src, sink, clk, iters);
+    else
+      hipLaunchKernelGGL((probe32<WAVES, MODE>), dim3(grid), dim3(WAVES * 64), 0, nullptr, src, sink, clk, iters);
     CK(hipEventRecord(e1, nullptr));
     CK(hipEventSynchronize(e1));
     float t;
@@ -132,7 +191,7 @@ static void run(const char* name, const f16x8* src, float* sink, unsigned long l
   const int per_it = (MODE == 2 ? 64 : 32);
   const double mfma_per_simd = (double)iters * per_it * (WAVES / 4);
   const double flops = (double)grid * WAVES * iters * per_it * 16384.0;
-  printf("%-34s waves/SIMD=%d  %.3f ms  %7.1f TF  clock %.0f MHz  cycles per MFMA on the SIMD %.2f\n", name, WAVES / 4,
+  printf("%-34s waves/SIMD=%d  %.3f ms  %7.1f TF  clock %.0f MHz  cycles per 16 Kflop on the SIMD %.2f\n", name, WAVES / 4,
          ms[ms.size() / 2], flops / ms[ms.size() / 2] / 1e9, mhz[mhz.size() / 2], cyc[cyc.size() / 2] / mfma_per_simd);
 }
 
@@ -154,5 +213,9 @@ int main() {
   run<8, 1, 0>("2 waves/SIMD ping-pong 32", src, sink, clk, iters, grid);
   run<8, 2, 0>("2 waves/SIMD ping-pong 64", src, sink, clk, iters / 2, grid);
   run<8, 2, 1>("2 waves/SIMD ping-pong 64 (B x8)", src, sink, clk, iters / 2, grid);
+  run<8, 0, 0, 1>("32x32x16: 2 waves/SIMD free", src, sink, clk, iters, grid);
+  run<8, 1, 0, 1>("32x32x16: 2 waves/SIMD ping-pong 32", src, sink, clk, iters, grid);
+  run<8, 1, 0>("2 waves/SIMD ping-pong 32 (again)", src, sink, clk, iters, grid);
+  run<8, 1, 0, 1>("32x32x16: ping-pong 32 (again)", src, sink, clk, iters, grid);
   return 0;
 }
