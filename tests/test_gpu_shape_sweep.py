@@ -143,3 +143,117 @@ def test_massive_ties_take_the_dense_f64_path(lib, k):
         pos = [p for p, v in enumerate(idx[r]) if int(v) in dup]
         got = [int(idx[r, p]) for p in pos]
         assert got == sorted(got)
+
+
+def _simulated_shards(g, qh, k, nshards, norm_mode, options=()):
+    """The sharded protocol with every shard on this GPU (stack == all-gather), including the agreement on the error
+    norms and the image type that ShardedGallery.__init__ performs with two all-reduces."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import shard_bounds
+    n, nq = g.shape[0], qh.shape[0]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    q = torch.from_numpy(qh).to(dev)
+    shards = []
+    for r in range(nshards):
+        lo, hi = shard_bounds(n, nshards, r)
+        shards.append(_lib.Gallery.from_host(g[lo:hi], norm_mode=norm_mode, row_offset=lo))
+    try:
+        f16 = min(int(sh.get_option("image_dtype")) for sh in shards)
+        for sh in shards:
+            if int(sh.get_option("image_dtype")) != f16:
+                sh.set_image_dtype(f16)
+        bounds = np.max(np.array([sh.norm_bounds() for sh in shards]), axis=0)
+        for sh in shards:
+            sh.norm_bounds(raise_to=[float(v) for v in bounds])
+            for name, val in options:
+                sh.set_option(name, val)
+        approx = torch.empty((nshards, nq, k), dtype=torch.float32, device=dev)
+        for r, sh in enumerate(shards):
+            sh.phase1_device(q.data_ptr(), nq, k, approx[r].data_ptr(), stream)
+        L = torch.empty((nq,), dtype=torch.float32, device=dev)
+        _lib.kth_of_gathered_device(approx.data_ptr(), nshards, nq, k, L.data_ptr(), stream)
+        idx = torch.empty((nshards, nq, k), dtype=torch.int64, device=dev)
+        sc = torch.empty((nshards, nq, k), dtype=torch.float32, device=dev)
+        sc64 = torch.empty((nshards, nq, k), dtype=torch.float64, device=dev)
+        for r, sh in enumerate(shards):
+            sh.phase2_device(nq, k, L.data_ptr(), idx[r].data_ptr(), sc[r].data_ptr(), sc64[r].data_ptr(), stream)
+        oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        os_ = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        _lib.topk_merge_device(sc64.data_ptr(), idx.data_ptr(), nshards, nq, k, oi.data_ptr(), os_.data_ptr(), stream)
+        torch.cuda.synchronize()
+        flags = [sh.flags() for sh in shards]
+    finally:
+        for sh in shards:
+            sh.close()
+    return oi.cpu().numpy(), os_.cpu().numpy(), flags
+
+
+@pytest.mark.parametrize("nq", [40, 300])
+@pytest.mark.parametrize("nshards", [2, 5])
+def test_heterogeneous_shards_equal_the_single_gallery(lib, nshards, nq):
+    """Rows sorted by cluster: one shard holds all of a query's neighbours, the others none, so the shards' local K-th
+    scores are far apart and only the gathered L prunes the poor shards' candidates."""
+    from isehr_amd._lib import Gallery
+    rng = np.random.default_rng(31)
+    n, d, k = 60000, 128, 100
+    c = rng.standard_normal((12, d))
+    lab = np.sort(rng.integers(0, 12, n))
+    g = (c[lab] + 0.8 * rng.standard_normal((n, d))).astype(np.float32)
+    qh = (c[rng.integers(0, 12, nq)] + 0.5 * rng.standard_normal((nq, d))).astype(np.float32)
+    single = Gallery.from_host(g)
+    ref_idx, ref_sc, _ = single.search(qh, k)
+    single.close()
+    oi, os_, flags = _simulated_shards(g, qh, k, nshards, lib.NORM_L2)
+    assert not any(flags), flags
+    assert np.array_equal(oi, ref_idx)
+    assert np.array_equal(os_, ref_sc)
+    assert oracle.check_topk_parity(oi, oracle.exact_scores_f64(g, qh), k, TAU) == []
+
+
+@pytest.mark.parametrize("scale", [1.0, 300.0])
+def test_raw_inner_product_with_heavy_tailed_norms(lib, scale):
+    """src/main_retrieve.py:175-176 on un-normalised vectors whose norms span two decades (and, scaled by 300, leave the
+    fp16 range: the image falls back to bf16): the error margin follows the LARGEST norms, single gallery and shards."""
+    from isehr_amd._lib import Gallery
+    rng = np.random.default_rng(41)
+    n, d, nq, k = 40000, 96, 150, 50
+    g = rng.standard_normal((n, d)) * np.exp(1.5 * rng.standard_normal((n, 1)))
+    g = (scale * g).astype(np.float32)
+    qh = rng.standard_normal((nq, d)).astype(np.float32)
+    G = Gallery.from_host(g, norm_mode=lib.NORM_NONE)
+    try:
+        idx, sc, _ = G.search(qh, k)
+        f16 = int(G.get_option("image_dtype"))
+    finally:
+        G.close()
+    assert f16 == 0                                          # rows far longer than 4: the image is bf16 at either scale
+    s = oracle.exact_scores_f64(g, qh, normalize=False)
+    tol = TAU * float(np.abs(s).max())                       # the tolerance is stated on the score scale
+    assert oracle.check_topk_parity(idx, s, k, tol) == []
+    assert np.abs(np.take_along_axis(s, idx, 1) - sc).max() <= 2e-7 * float(np.abs(s).max())
+    # shards whose largest norms differ: identical answer after the agreement on the norm bounds
+    order = np.argsort(np.linalg.norm(g, axis=1), kind="stable")
+    gs = g[order]                                            # shard 0 = the small rows, the last shard = the large ones
+    Gs = Gallery.from_host(gs, norm_mode=lib.NORM_NONE)
+    ref_idx, ref_sc, _ = Gs.search(qh, k)
+    Gs.close()
+    # the shard of small rows cannot filter with a margin that follows the largest norms of the gallery: its buffers
+    # overflow and raise the sticky flags; ShardedGallery.search(verify=True) then answers again with these fallbacks
+    for options in ((), (("speculative", 0),), (("force_exact", 1),)):
+        oi, os_, flags = _simulated_shards(gs, qh, k, 3, lib.NORM_NONE, options)
+        if not any(flags):
+            break
+    assert not any(flags), flags
+    assert options, "expected the small-norm shard to need a fallback"
+    assert np.array_equal(oi, ref_idx)
+    assert np.array_equal(os_, ref_sc)
+
+
+@pytest.mark.parametrize("n,k", [(2048, 2048), (2300, 2048), (5000, 1), (257, 256), (70000, 2048)])
+def test_k_extremes_on_the_tile_kernel(lib, n, k):
+    rng = np.random.default_rng(n + k)
+    g = rng.standard_normal((n, 64)).astype(np.float32)
+    q = rng.standard_normal((260, 64)).astype(np.float32)
+    _check(lib, g, q, k, True)
