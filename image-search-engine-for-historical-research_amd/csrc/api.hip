@@ -97,7 +97,8 @@ struct mi_gallery {
   hipStream_t stream = nullptr;
   Workspace ws;
   // options
-  int chunk0_tiles = 32, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0, speculative = 1;
+  int chunk0_tiles = 0 /* 0 = default, bootstrap_tiles() */, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0,
+      speculative = 1, rescore_grid_x = 0;
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
@@ -268,6 +269,12 @@ static int32_t spec_rank(double lambda) {
   return r;
 }
 
+// Rows of the bootstrap chunk / threshold sample, in tiles of 256: 8192 rows unless option "chunk0_tiles" says otherwise
+// (2048 and 4096 rows have their own threshold kernels).  Measured on the 125 750-row shards of an 8-way 1M gallery, same
+// box: a 2048-row sample saves 21 us of bootstrap + selection and costs 38 us in the scoring launch (twice the survivors
+// in its filter); 4096 and 8192 rows tie.  So the size does not follow the shard size.
+static int64_t bootstrap_tiles(const mi_gallery* g) { return g->chunk0_tiles > 0 ? g->chunk0_tiles : 32; }
+
 // (re)build the bootstrap sample image for the current number of rows
 static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
   if (g->samp_img && g->samp_tiles == tiles && g->samp_for_n == g->n) return MI_OK;
@@ -295,7 +302,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   QueryState st = make_state(ws);
   const int64_t ntiles = g->npad / TILE;
   // bootstrap chunk: stored completely (no threshold yet); must hold >= K rows and fit the survivor buffer
-  int64_t t0 = std::max<int64_t>(g->chunk0_tiles, (2 * (int64_t)k + TILE - 1) / TILE);
+  int64_t t0 = std::max<int64_t>(bootstrap_tiles(g), (2 * (int64_t)k + TILE - 1) / TILE);
   t0 = std::min<int64_t>(t0, ws.cap / TILE);
   t0 = std::min<int64_t>(t0, ntiles);
   // Single-launch schedule?  The speculative threshold is an order statistic of the scores of a SAMPLE: t0 * 256
@@ -390,7 +397,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       lad_r = std::max<int32_t>(1, std::min<int32_t>(lad_r, samp_r - 1));
     }
     if (sample_threshold_applies(first_cnt, k, samp_r)) {
-      launch_sample_threshold(st, nq, k, samp_r, s, lad_r);
+      launch_sample_threshold(st, nq, k, samp_r, first_cnt, s, lad_r);
       ladder_on = lad_r > 0;
     } else {
       launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
@@ -454,7 +461,8 @@ static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev
   QueryState st = make_state(ws);
   if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
   if (resident) launch_rescore_resident(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
-  else launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
+  else launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
+                      (uint32_t)g->rescore_grid_x);
   launch_emit(ws.cand_rows, ws.cand_cnt, ws.cand_score, ws.rcap, nq, k, g->row_offset, out_idx, out_score,
               out_score64, s);
   HIPC(hipGetLastError());
@@ -1805,6 +1813,8 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   REQUIRE(g && name && out_value, "null");
   const std::string n(name);
   if (n == "chunk0_tiles") *out_value = g->chunk0_tiles;
+  else if (n == "sample_rows") *out_value = (double)(bootstrap_tiles(g) * TILE);
+  else if (n == "rescore_grid_x") *out_value = g->rescore_grid_x;
   else if (n == "chunk_growth") *out_value = g->chunk_growth;
   else if (n == "survivor_cap") *out_value = g->surv_cap;
   else if (n == "rescore_cap") *out_value = g->rescore_cap;
@@ -1826,7 +1836,8 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
 int mi_set_option(mi_gallery* g, const char* name, double value) {
   REQUIRE(g && name, "null");
   const std::string n(name);
-  if (n == "chunk0_tiles") { REQUIRE(value >= 1, "chunk0_tiles >= 1"); g->chunk0_tiles = (int)value; }
+  if (n == "chunk0_tiles") { REQUIRE(value >= 0, "chunk0_tiles >= 0 (0 = default)"); g->chunk0_tiles = (int)value; }
+  else if (n == "rescore_grid_x") { REQUIRE(value >= 0 && value <= 4096, "rescore_grid_x in [0, 4096]"); g->rescore_grid_x = (int)value; }
   else if (n == "chunk_growth") { REQUIRE(value >= 1, "chunk_growth >= 1"); g->chunk_growth = (int)value; }
   else if (n == "survivor_cap") {
     const uint32_t v = (uint32_t)value;

@@ -70,9 +70,10 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
                              int use_img_terms, uint32_t first_cnt, QueryState st, hipStream_t stream);
 // mode 0: maintain (threshold <- K-th largest - margin, compact survivors)
 // mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
-// thresholds from the 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
+// thresholds from the 2048 / 4096 / 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
-void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream, int32_t lad_r = 0);
+void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
+                             int32_t lad_r = 0);
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows = nullptr, uint32_t* cand_cnt = nullptr,
@@ -80,7 +81,8 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_t* cand_rows, uint32_t* cand_cnt,
                               uint32_t rcap, uint64_t* stats2, hipStream_t stream);
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream);
+                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
+                    uint32_t grid_x = 0);
 void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                              const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream);
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,

@@ -329,10 +329,11 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 // of the 512 maxima (W = 4r) is a lower bound of the W-th largest overall, so the values >= it (W plus a few) are
 // gathered and ranked exactly by counting.  Falls back to the plain select if more than 256 values qualify (ties).
 // The sample entries are dropped afterwards (cnt = 0), like select_maintain_kernel<0> with spec != 0.
-constexpr int SAMP_THREADS = 512, SAMP_PER_THREAD = 16;    // 8192 sample scores
+constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (4, 8, 16) = 2048, 4096, 8192 sample scores
+template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
                                                                         int32_t lad_r) {
-  __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (32 KiB)
+  __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sh[8];
   const uint32_t q = blockIdx.x;
@@ -406,12 +407,18 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
 }
 
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
-  return first_cnt == (uint32_t)(SAMP_THREADS * SAMP_PER_THREAD) && spec_r >= 1 && spec_r < k && 4 * spec_r <= 256 &&
-         (int64_t)first_cnt >= k;
+  const bool size_ok = first_cnt == SAMP_THREADS * 4u || first_cnt == SAMP_THREADS * 8u || first_cnt == SAMP_THREADS * 16u;
+  return size_ok && spec_r >= 1 && spec_r < k && 4 * spec_r <= 256 && (int64_t)first_cnt >= k;
 }
 
-void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, hipStream_t stream, int32_t lad_r) {
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
+                             int32_t lad_r) {
+  if (first_cnt == SAMP_THREADS * 4u)
+    hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+  else if (first_cnt == SAMP_THREADS * 8u)
+    hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+  else
+    hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -595,11 +602,13 @@ void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t
                      cand_cnt, rcap, cand_score, sub);
 }
 
+// grid_x: workgroups (of 2 candidates) per query and sweep, 0 = default.  Workgroups beyond a query's count exit at once and
+// queries with more candidates than one sweep covers take further sweeps.
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
-  hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>),
-                     dim3(std::min<uint32_t>(RESCORE_GRID_X, (rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG), nq),
-                     dim3(RESCORE_THREADS), 0, stream, gal_f32,
+                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream, uint32_t grid_x) {
+  uint32_t gx = grid_x ? grid_x : RESCORE_GRID_X;
+  gx = std::max<uint32_t>(1u, std::min<uint32_t>(gx, (rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG));
+  hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>), dim3(gx, nq), dim3(RESCORE_THREADS), 0, stream, gal_f32,
                      qry_f32, dp, cand_rows, cand_cnt, rcap, cand_score);
 }
 
@@ -701,42 +710,90 @@ void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, 
 
 // ------------------------------------------------------------------------------------------------
 // merge of the shards' exact top-K lists by (score64 desc, idx asc); padded entries carry idx -1 / -inf.
-__global__ __launch_bounds__(256) void merge_kernel(const double* __restrict__ score64, const int64_t* __restrict__ idx,
+// Every list arrives sorted in exactly that order (emit_kernel) and the ids of different shards are disjoint, so the
+// place of an entry in the merged order is its place in its own list plus, for every other list, the number of entries
+// that come before it there -- one binary search per (entry, other list), no sorting network.  One workgroup per query;
+// the lists are staged in LDS when they fit (nshards * k * 16 bytes <= 48 KiB), else searched where they lie.
+__device__ __forceinline__ bool merged_before(double sa, long long ia, double sb, long long ib) {
+  // "a comes before b": higher score first, NaN last, padding (id < 0) last of all, ties to the lower id
+  if (ia < 0 || ib < 0) return ib < 0 && ia >= 0;
+  const bool a_nan = (sa != sa), b_nan = (sb != sb);
+  if (a_nan || b_nan) return (!a_nan) || (b_nan && ia < ib);
+  return (sa > sb) || (sa == sb && ia < ib);
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(1024) void merge_kernel(const double* __restrict__ score64, const int64_t* __restrict__ idx,
                                                     int32_t nshards, int64_t nq, int32_t k, int64_t shard_stride,
                                                     int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t q = blockIdx.x;
   const uint32_t n = (uint32_t)nshards * (uint32_t)k;
-  uint32_t n2 = 2;
-  while (n2 < n) n2 <<= 1;
-  double* s = reinterpret_cast<double*>(smem);
-  unsigned long long* id = reinterpret_cast<unsigned long long*>(smem + (size_t)n2 * 8);
-  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
-    if (i < n) {
+  double* ls = reinterpret_cast<double*>(smem);
+  long long* li = reinterpret_cast<long long*>(smem + (IN_LDS ? (size_t)n * 8 : 0));
+  if (IN_LDS) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
       const uint32_t sh = i / k, e = i % k;
       const uint64_t src = (uint64_t)sh * shard_stride + (uint64_t)q * k + e;
-      const int64_t v = idx[src];
-      s[i] = (v < 0) ? -INFINITY : score64[src];
-      id[i] = (unsigned long long)v;          // -1 -> max, sorts last among equals
-    } else {
-      s[i] = -INFINITY;
-      id[i] = ~0ull;
+      ls[i] = score64[src];
+      li[i] = idx[src];
     }
+    __syncthreads();
   }
-  bitonic_sort_desc<unsigned long long>(s, id, n2);
+  auto entry = [&](uint32_t sh, uint32_t e, double& sc, long long& id) {
+    if (IN_LDS) {
+      sc = ls[sh * k + e];
+      id = li[sh * k + e];
+    } else {
+      const uint64_t src = (uint64_t)sh * shard_stride + (uint64_t)q * k + e;
+      sc = score64[src];
+      id = idx[src];
+    }
+  };
+  // positions nobody claims (fewer than k valid entries in all lists together) read as padding
   for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
-    out_idx[(uint64_t)q * k + i] = (int64_t)id[i];
-    if (out_score) out_score[(uint64_t)q * k + i] = (float)s[i];
+    out_idx[(uint64_t)q * k + i] = -1;
+    if (out_score) out_score[(uint64_t)q * k + i] = -INFINITY;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t sh = i / k, e = i % k;
+    double sc;
+    long long id;
+    entry(sh, e, sc, id);
+    if (id < 0) continue;
+    uint32_t rank = e;
+    for (uint32_t t = 0; t < (uint32_t)nshards && rank < (uint32_t)k; ++t) {
+      if (t == sh) continue;
+      uint32_t lo = 0, hi = (uint32_t)k;                   // first entry of list t that does NOT come before mine
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        double so;
+        long long io;
+        entry(t, mid, so, io);
+        if (merged_before(so, io, sc, id)) lo = mid + 1;
+        else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < (uint32_t)k) {
+      out_idx[(uint64_t)q * k + rank] = (int64_t)id;
+      if (out_score) out_score[(uint64_t)q * k + rank] = (float)sc;
+    }
   }
 }
 
 void launch_merge(const double* score64, const int64_t* idx, int32_t nshards, int64_t nq, int32_t k, int64_t shard_stride,
                   int64_t* out_idx, float* out_score, hipStream_t stream) {
-  uint32_t n2 = 2;
-  while (n2 < (uint32_t)nshards * (uint32_t)k) n2 <<= 1;
-  ensure_dynamic_lds((const void*)merge_kernel);
-  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(256), (size_t)n2 * 16, stream, score64, idx, nshards, nq,
-                     k, shard_stride, out_idx, out_score);
+  const size_t bytes = (size_t)nshards * (size_t)k * 16;
+  // one entry per thread where possible: a thread's work is a chain of dependent look-ups (latency, not throughput)
+  const unsigned threads = (unsigned)std::min<size_t>(1024, std::max<size_t>(256, round_up((size_t)nshards * (size_t)k, 64)));
+  if (bytes <= 48 * 1024)
+    hipLaunchKernelGGL(merge_kernel<true>, dim3((unsigned)nq), dim3(threads), bytes, stream, score64, idx, nshards, nq, k,
+                       shard_stride, out_idx, out_score);
+  else
+    hipLaunchKernelGGL(merge_kernel<false>, dim3((unsigned)nq), dim3(threads), 0, stream, score64, idx, nshards, nq, k,
+                       shard_stride, out_idx, out_score);
 }
 
 }  // namespace mi

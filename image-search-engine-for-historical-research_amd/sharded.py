@@ -49,6 +49,9 @@ class ShardedGallery:
         self._join = True
         if self.world > 1:
             self._agree()
+            # a shard of a G-way gallery expects ~127 / G candidates per query: size the re-score launch for that (a grid
+            # for 128 per query is mostly workgroups that exit at once, 23 us of dispatch at G = 8); larger counts loop
+            self.g.set_option("rescore_grid_x", max(8, min(64, round(96 / self.world))))
 
     def _agree(self):
         """One error margin for all shards: the certificate's eps must cover the rows of EVERY shard (a row at the

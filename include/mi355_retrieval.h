@@ -119,7 +119,8 @@ int mi_kth_of_gathered_device(const float* gathered_dev, int32_t nshards, int64_
 int mi_knn_phase2_device(mi_gallery* g, int64_t nq, int32_t k, const float* L_dev,
                          int64_t* out_idx_dev, float* out_score_dev, double* out_score64_dev,
                          void* stream);
-/* merge of [nshards][nq][k] exact lists -> [nq][k] by (score64 desc, idx asc). */
+/* merge of [nshards][nq][k] exact lists -> [nq][k] by (score64 desc, idx asc).  Every list must be what phase 2 emits:
+ * sorted in that order, padded with -1 / -inf at the end; row ids of different shards are disjoint (row shards). */
 int mi_topk_merge_device(const double* score64_dev, const int64_t* idx_dev, int32_t nshards,
                          int64_t nq, int32_t k, int64_t* out_idx_dev, float* out_score_dev,
                          void* stream);

@@ -206,6 +206,8 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
     for j, r in enumerate(rows):
         g[r] = q[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
     G = Gallery.from_host(g)
+    G.set_option("chunk0_tiles", 32)                        # the 8192-row sample the planted rows were drawn from
+    assert G.get_option("sample_rows") == 8192
     idx, sc, _ = G.search(q, k)
     st = G.status()
     G.close()

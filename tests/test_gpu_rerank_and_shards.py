@@ -241,6 +241,7 @@ def test_sharded_search_verify_falls_back_on_sticky_flags():
     for j, r in enumerate(rows):
         g[r] = qh[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
     G = _lib.Gallery.from_host(g)
+    G.set_option("chunk0_tiles", 32)               # the 8192-row sample the planted rows were drawn from
     sg = ShardedGallery(G)
     q = torch.from_numpy(qh).to("cuda:0")
     s = oracle.exact_scores_f64(g, qh)

@@ -198,3 +198,29 @@ def test_ladder_thresholds_keep_the_answer_and_cut_the_survivors(lib):
         assert np.array_equal(res[1][0], idx_e) and np.array_equal(res[1][1], sc_e)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("tiles", [8, 16, 32])
+def test_sample_sizes_2048_4096_8192(tiles):
+    """The threshold sample is 8192 rows by default; option "chunk0_tiles" selects 2048 / 4096 (each has its own threshold
+    kernel).  Every size takes the single-launch schedule with the ladder and returns the exact answer."""
+    from isehr_amd._lib import Gallery
+    from isehr_amd.synth import synth_rows
+    n, d, nq, k = 150000, 64, 300, 100
+    g = synth_rows(300, 0, n, d)
+    q = synth_rows(301, 0, nq, d)
+    G = Gallery.from_host(g)
+    try:
+        assert G.get_option("sample_rows") == 8192
+        G.set_option("chunk0_tiles", tiles)
+        assert G.get_option("sample_rows") == tiles * 256
+        i1, s1, _ = G.search(q, k)
+        st = G.status(reset=True)
+        G.set_option("force_exact", 1)
+        i2, s2, _ = G.search(q, k)
+    finally:
+        G.close()
+    assert st["overflow_batches"] == 0
+    assert st["survivors"] / st["queries"] < 2500            # one filtered launch with a useful threshold
+    assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+    assert oracle.check_topk_parity(i1, oracle.exact_scores_f64(g, q), k, TAU) == []
