@@ -257,3 +257,22 @@ def test_k_extremes_on_the_tile_kernel(lib, n, k):
     g = rng.standard_normal((n, 64)).astype(np.float32)
     q = rng.standard_normal((260, 64)).astype(np.float32)
     _check(lib, g, q, k, True)
+
+
+@pytest.mark.parametrize("nshards,k", [(4, 1000), (3, 2048), (8, 384)])
+def test_merge_of_long_lists(lib, nshards, k):
+    """nshards * k entries per query beyond what the merge stages in LDS (48 KiB = 3072 entries): the ranks are then
+    searched in the gathered lists where they lie.  Same answer as the single gallery, bit for bit."""
+    from isehr_amd._lib import Gallery
+    rng = np.random.default_rng(nshards * 1000 + k)
+    n, d, nq = 50000, 64, 37
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    g[5000:5040] = g[4999]                                   # a tie block that straddles nothing but must keep index order
+    qh = rng.standard_normal((nq, d)).astype(np.float32)
+    single = Gallery.from_host(g)
+    ref_idx, ref_sc, _ = single.search(qh, k)
+    single.close()
+    oi, os_, flags = _simulated_shards(g, qh, k, nshards, lib.NORM_L2)
+    assert not any(flags), flags
+    assert np.array_equal(oi, ref_idx)
+    assert np.array_equal(os_, ref_sc)
