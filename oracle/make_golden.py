@@ -224,6 +224,30 @@ def main():
         torch.Tensor.cuda = orig_cuda
     np.savez_compressed(os.path.join(GOLD, "kr_rerank.npz"), indices=np.asarray(kr_idx))
 
+    # ---- a5 (the part that runs here): Diffusion.get_affinity / get_laplacian (src/utils/diffusion.py:87-116) are plain
+    # numpy / scipy.sparse methods that never touch `self`; the class's __init__ builds faiss indexes (absent), so the
+    # methods are called on an instance made with __new__.  Inputs: the exact inner-product k-NN lists of a clustered,
+    # L2-normalised feature set (what knn.search returns for an IndexFlatIP), with a few negative similarities so that
+    # the clipping at :103 acts.  get_offline_result's `linalg.cg(tol=...)` (:18) is a TypeError on scipy 1.15: unpinned.
+    import src.utils.diffusion as rdf
+    vd = synth_rows(61, 0, 300, 24).astype(np.float64)
+    cd = synth_rows(62, 0, 12, 24).astype(np.float64)
+    vd = 0.8 * vd + 1.1 * cd[np.arange(300) % 12]
+    vd /= np.linalg.norm(vd, axis=1, keepdims=True)
+    vd = vd.astype(np.float32)
+    sd = vd @ vd.T
+    ids_d = np.argsort(-sd, axis=1, kind="stable")[:, :40]
+    sims_d = np.take_along_axis(sd, ids_d, axis=1)
+    sims_d[::7, -3:] = -0.05                                   # negative entries (clipped to 0 by :103)
+    obj = rdf.Diffusion.__new__(rdf.Diffusion)
+    aff = rdf.Diffusion.get_affinity(obj, sims_d.copy(), ids_d).tocsr()
+    lap = rdf.Diffusion.get_laplacian(obj, sims_d[:, :15].copy(), ids_d[:, :15]).tocsr()
+    aff.sort_indices()
+    lap.sort_indices()
+    np.savez_compressed(os.path.join(GOLD, "diffusion_graph.npz"), sims=sims_d, ids=ids_d,
+                        aff_data=aff.data, aff_indices=aff.indices, aff_indptr=aff.indptr,
+                        lap_data=lap.data, lap_indices=lap.indices, lap_indptr=lap.indptr)
+
     # ---- f-2: descriptor tail (GeM -> L2N -> whiten Linear -> L2N), multi-scale average, SOA block -- the reference's
     # own layer functions / classes on seeded feature maps and weights
     import src.networks.networks as rnet

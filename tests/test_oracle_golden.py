@@ -171,3 +171,20 @@ def test_kr_reranking_bitexact(golden_dir):
     # the re-ranking is not the plain cosine order (the Jaccard term moves images)
     plain = np.argsort(-(qk @ vk.T), axis=1, kind="stable")
     assert (idx != plain).mean() > 0.05
+
+
+def test_diffusion_graph_vs_reference_golden(golden_dir):
+    """a5, the part of src/utils/diffusion.py that runs under today's scipy: Diffusion.get_affinity / get_laplacian
+    (:87-116) called on the reference's own class (oracle/make_golden.py) -- the oracle's restatement must build the same
+    sparse matrices entry for entry."""
+    z = np.load(os.path.join(golden_dir, "diffusion_graph.npz"))
+    sims, ids = z["sims"], z["ids"]
+    aff = oracle.get_affinity(sims.copy(), ids).tocsr()
+    aff.sort_indices()
+    assert np.array_equal(aff.indptr, z["aff_indptr"]) and np.array_equal(aff.indices, z["aff_indices"])
+    assert aff.data.dtype == z["aff_data"].dtype and np.array_equal(aff.data, z["aff_data"])
+    assert (sims[::7, -3:] < 0).all() and aff.data.min() >= 0          # the negative similarities were clipped, not cubed
+    lap = oracle.get_laplacian(sims[:, :15].copy(), ids[:, :15]).tocsr()
+    lap.sort_indices()
+    assert np.array_equal(lap.indptr, z["lap_indptr"]) and np.array_equal(lap.indices, z["lap_indices"])
+    assert lap.data.dtype == z["lap_data"].dtype and np.array_equal(lap.data, z["lap_data"])
