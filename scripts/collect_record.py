@@ -4,7 +4,7 @@ import glob, json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
-for name in ("q1", "q70", "bf16", "aqe", "10m"):
+for name in ("q1", "q70", "bf16", "aqe", "aqe_rparis", "10m"):
     src = os.path.join(go, f"{tag}_{name}_bench.json")
     if os.path.exists(src):
         lines = [l for l in open(src) if l.startswith("{")]
@@ -14,7 +14,8 @@ for name in ("q1", "q70", "bf16", "aqe", "10m"):
     if st:
         shutil.copy(max(st, key=os.path.getmtime), os.path.join(pr, f"{tag}_{name}_kernel_stats.csv"))
 for f in ("timeline_full.txt", "timeline_s8.txt", "rank_all.txt", "host_api.txt", "gallery_io.json", "xcc_report.txt",
-          "diffusion_refsize.txt", "mfma_probe.txt", "kbench.txt", "rehearse2.txt", "rehearse4.txt"):
+          "diffusion_refsize.txt", "mfma_probe.txt", "kbench.txt", "rehearse2.txt", "rehearse4.txt", "ladder_probe.txt",
+          "shard_model.txt"):
     src = os.path.join(go, f"{tag}_{f}")
     if os.path.exists(src) and os.path.getsize(src) < 200000:
         text = open(src, errors="replace").read()
