@@ -148,3 +148,44 @@ def test_non_finite_and_huge_inputs(lib):
     ok = np.setdiff1d(np.arange(n), bad)
     s = oracle.exact_scores_f64(g[ok], q)
     assert oracle.check_topk_parity(np.searchsorted(ok, idx), s, k, TAU) == []
+
+
+def test_concurrent_searches_from_threads(lib):
+    """src/online.py:163 serves queries from a threaded Flask app: several threads search the same gallery (serialised per
+    handle by the wrapper's lock) while others search a second gallery on the same device.  Every answer must equal the
+    single-threaded one."""
+    import threading
+    from isehr_amd._lib import Gallery
+    rng = np.random.default_rng(17)
+    ga = rng.standard_normal((60000, 96)).astype(np.float32)
+    gb = rng.standard_normal((45000, 160)).astype(np.float32)
+    qa = [rng.standard_normal((n, 96)).astype(np.float32) for n in (1, 7, 130, 300)]
+    qb = [rng.standard_normal((n, 160)).astype(np.float32) for n in (3, 64, 129, 257)]
+    A, B = Gallery.from_host(ga), Gallery.from_host(gb)
+    try:
+        ref_a = [A.search(q, 50)[:2] for q in qa]
+        ref_b = [B.search(q, 20)[:2] for q in qb]
+        errors = []
+
+        def worker(G, queries, refs, k, seed):
+            try:
+                order = np.random.default_rng(seed).permutation(len(queries) * 6) % len(queries)
+                for j in order:
+                    idx, sc, _ = G.search(queries[j], k)
+                    if not (np.array_equal(idx, refs[j][0]) and np.array_equal(sc, refs[j][1])):
+                        errors.append((seed, int(j)))
+            except Exception as e:                           # noqa: BLE001
+                errors.append((seed, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(A, qa, ref_a, 50, s)) for s in range(3)]
+        threads += [threading.Thread(target=worker, args=(B, qb, ref_b, 20, 10 + s)) for s in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in threads)
+        assert errors == []
+    finally:
+        A.close()
+        B.close()
+    assert oracle.check_topk_parity(ref_a[2][0], oracle.exact_scores_f64(ga, qa[2]), 50, TAU) == []
