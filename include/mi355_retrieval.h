@@ -243,12 +243,17 @@ typedef struct mi_search_stats {
 } mi_search_stats;
 int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches with hipEvents */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
-/* Tunables: "chunk0_tiles", "chunk_growth", "survivor_cap", "rescore_cap", "exact_fallback",
+/* Tunables: "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
+ * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
+ * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "xcc_balance" (XCD shares by measured
+ * speed), "async_tail" (re-score + sort on the handle's own stream, see mi_search_join), "rescore_grid_x" (workgroups of 2
+ * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
  * already normalised expanded queries of alpha-QE), "kernel_variant" (structure of the tile kernel, A/B only).
- * mi_get_option also answers "image_dtype" (1 = fp16, 0 = bf16; read-only, see mi_gallery_set_image_dtype). */
+ * mi_get_option also answers "image_dtype" (1 = fp16, 0 = bf16; read-only, see mi_gallery_set_image_dtype) and
+ * "sample_rows" (rows of the threshold sample in effect). */
 int mi_set_option(mi_gallery* g, const char* name, double value);
 int mi_get_option(const mi_gallery* g, const char* name, double* out_value);   /* same names as mi_set_option */
 /* Synchronises the handle's work, returns the sticky device flags raised by the asynchronous _device entry points since
