@@ -81,6 +81,8 @@ SIGNATURES = {
                                C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     "mi_diffusion_offline": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_diffusion_offline_nodes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double,
+                                             C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_diffusion_set_offline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mi_diffusion_online": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -356,6 +358,16 @@ class Gallery:
                                               ids.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
                                               sims.ctypes.data_as(C.c_void_p) if return_sims else None))
         return (ids, vals, sims) if return_sims else (ids, vals)
+
+    def diffusion_offline_nodes(self, n_trunc, kd, node0, node1, alpha=0.99, gamma=3, maxiter=20, tol=1e-6):
+        """The offline rows of the nodes [node0, node1) only: -> (ids int64 [N,n_trunc], vals float32 [node1-node0,n_trunc])."""
+        ids = np.empty((self.n, n_trunc), dtype=np.int64)
+        vals = np.empty((max(0, node1 - node0), n_trunc), dtype=np.float32)
+        with self._lock:
+            check(load().mi_diffusion_offline_nodes(self._h, n_trunc, kd, float(alpha), gamma, maxiter, float(tol),
+                                                    int(node0), int(node1), ids.ctypes.data_as(C.c_void_p),
+                                                    vals.ctypes.data_as(C.c_void_p), None))
+        return ids, vals
 
     def diffusion_set_offline(self, ids, vals):
         ids = np.ascontiguousarray(ids, dtype=np.int64)

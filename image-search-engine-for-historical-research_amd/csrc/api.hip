@@ -1610,6 +1610,14 @@ int mi_kr_rerank(const void* qvecs, int64_t nq, int64_t q_row_stride, int64_t q_
 int mi_diffusion_offline(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma, int32_t maxiter,
                          double tol, int64_t* out_ids, float* out_vals, float* out_knn_sims) {
   REQUIRE(g, "null handle");
+  return mi_diffusion_offline_nodes(g, n_trunc, kd, alpha, gamma, maxiter, tol, 0, g->n, out_ids, out_vals, out_knn_sims);
+}
+
+int mi_diffusion_offline_nodes(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma, int32_t maxiter,
+                               double tol, int64_t node0, int64_t node1, int64_t* out_ids, float* out_vals,
+                               float* out_knn_sims) {
+  REQUIRE(g, "null handle");
+  REQUIRE(node0 >= 0 && node0 <= node1 && node1 <= g->n, "node range must lie inside [0, N]");
   REQUIRE(n_trunc >= 2 && (int64_t)n_trunc <= g->n && n_trunc <= 4096, "n_trunc must be in [2, min(N, 4096)]");
   REQUIRE(kd >= 1 && kd <= n_trunc, "kd must be in [1, n_trunc]");
   REQUIRE(g->n < ((int64_t)1 << 31), "too many rows");
@@ -1641,11 +1649,16 @@ int mi_diffusion_offline(mi_gallery* g, int32_t n_trunc, int32_t kd, double alph
   HIPC(hipMalloc((void**)&g->dif_ids, (size_t)n * T * 4));
   HIPC(hipMalloc((void**)&g->dif_vals, (size_t)n * T * 4));
   g->dif_T = T;
-  launch_diffusion_cg(ids, T, n, T, kd, lap, diag, maxiter, tol, map_all, grid, g->dif_ids, g->dif_vals, s);
+  // rows outside [node0, node1) stay zero until mi_diffusion_set_offline installs the gathered result
+  HIPC(hipMemsetAsync(g->dif_vals, 0, (size_t)n * T * 4, s));
+  HIPC(hipMemsetAsync(g->dif_ids, 0, (size_t)n * T * 4, s));
+  if (node1 > node0)
+    launch_diffusion_cg(ids, T, n, T, kd, lap, diag, maxiter, tol, map_all, grid, g->dif_ids, g->dif_vals, s, node0, node1);
   HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(s));
   if (out_ids) HIPC(hipMemcpy(out_ids, ids, (size_t)n * T * 8, hipMemcpyDeviceToHost));
-  if (out_vals) HIPC(hipMemcpy(out_vals, g->dif_vals, (size_t)n * T * 4, hipMemcpyDeviceToHost));
+  if (out_vals && node1 > node0)
+    HIPC(hipMemcpy(out_vals, g->dif_vals + (size_t)node0 * T, (size_t)(node1 - node0) * T * 4, hipMemcpyDeviceToHost));
   if (out_knn_sims) HIPC(hipMemcpy(out_knn_sims, sims, (size_t)n * T * 4, hipMemcpyDeviceToHost));
   return MI_OK;
 }

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void diffusion_cg_kernel(const int64_t* __rest
                                                            const float* __restrict__ diag, int32_t maxiter, double tol,
                                                            int32_t* __restrict__ map_all /*[grid][n], all -1*/,
                                                            int32_t* __restrict__ out_ids /*[n][T]*/,
-                                                           float* __restrict__ out_vals /*[n][T]*/) {
+                                                           float* __restrict__ out_vals /*[n][T]*/, int64_t node0,
+                                                           int64_t node1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t* lids = reinterpret_cast<int32_t*>(smem);
   double* x = reinterpret_cast<double*>(smem + (((size_t)T * 4 + 15) / 16) * 16);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void diffusion_cg_kernel(const int64_t* __rest
   double* red = qv + T;
   int32_t* map = map_all + (int64_t)blockIdx.x * n;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int64_t node = blockIdx.x; node < n; node += gridDim.x) {
+  for (int64_t node = node0 + blockIdx.x; node < node1; node += gridDim.x) {   // the solves are independent: any node range
     for (int c = threadIdx.x; c < T; c += blockDim.x) {
       const int32_t gid = (int32_t)ids[node * ld + c];
       lids[c] = gid;
@@ -188,11 +189,12 @@ void launch_affinity(const int64_t* ids, const float* sims, int64_t ld, int64_t 
 
 void launch_diffusion_cg(const int64_t* ids, int64_t ld, int64_t n, int32_t T, int32_t kd, const float* lap,
                          const float* diag, int32_t maxiter, double tol, int32_t* map_all, unsigned grid,
-                         int32_t* out_ids, float* out_vals, hipStream_t stream) {
+                         int32_t* out_ids, float* out_vals, hipStream_t stream, int64_t node0, int64_t node1) {
+  if (node1 < 0) node1 = n;
   const size_t lds = (((size_t)T * 4 + 15) / 16) * 16 + (size_t)T * 8 * 4 + 64;
   ensure_dynamic_lds((const void*)diffusion_cg_kernel);
   hipLaunchKernelGGL(diffusion_cg_kernel, dim3(grid), dim3(256), lds, stream, ids, ld, n, T, kd, lap, diag, maxiter,
-                     tol, map_all, out_ids, out_vals);
+                     tol, map_all, out_ids, out_vals, node0, node1);
 }
 
 void launch_diffusion_combine(const int64_t* nn_idx, const float* nn_sims, int32_t kq, int32_t gamma,

@@ -115,7 +115,8 @@ void launch_affinity(const int64_t* ids, const float* sims, int64_t ld, int64_t 
                      float alpha, float* lap, float* dinv, float* diag, hipStream_t stream);
 void launch_diffusion_cg(const int64_t* ids, int64_t ld, int64_t n, int32_t T, int32_t kd, const float* lap,
                          const float* diag, int32_t maxiter, double tol, int32_t* map_all, unsigned grid,
-                         int32_t* out_ids, float* out_vals, hipStream_t stream);
+                         int32_t* out_ids, float* out_vals, hipStream_t stream, int64_t node0 = 0,
+                         int64_t node1 = -1);
 void launch_diffusion_combine(const int64_t* nn_idx, const float* nn_sims, int32_t kq, int32_t gamma,
                               const int32_t* off_ids, const float* off_vals, int32_t T, int64_t n, int32_t nq,
                               float* dense, hipStream_t stream);

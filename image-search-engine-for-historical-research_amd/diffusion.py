@@ -21,8 +21,9 @@ from ._lib import Gallery, NORM_NONE
 
 
 class Diffusion:
-    def __init__(self, features, cache_dir=None, device=0):
+    def __init__(self, features, cache_dir=None, device=0, group=None):
         features = np.asarray(features)
+        self.group = group
         self.N = len(features)
         self.cache_dir = cache_dir
         # (for N >= 110000 the reference switches its kNN graph to an approximate IVFPQ index, src/utils/diffusion.py:47-49,
@@ -54,17 +55,46 @@ class Diffusion:
             self.gallery.diffusion_set_offline(ids, csr.data.reshape(self.N, -1))
             self.n_trunc = ids.shape[1]
             return offline
-        ids, vals = self.gallery.diffusion_offline(int(n_trunc), int(kd))
+        ids, vals = self._offline(int(n_trunc), int(kd))
         self.n_trunc = int(n_trunc)
         rows = np.repeat(np.arange(self.N), n_trunc)
         offline = sparse.csr_matrix((vals.reshape(-1), (rows, ids.reshape(-1))), shape=(self.N, self.N),
                                     dtype=np.float32)
         print("Obtaining cache: {} costs {:.2f}s".format(path, time.time() - t0))
-        if path:
+        if path and self._rank() == 0:                      # one writer when several ranks share the cache directory
             import joblib
             os.makedirs(self.cache_dir, exist_ok=True)
             joblib.dump(offline, path)
         return offline
+
+    def _rank(self):
+        import torch.distributed as dist
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+
+    def _offline(self, n_trunc, kd):
+        """One process: every node here.  Under torch.distributed (one process per GPU, every rank holding the same
+        features -- the reference diffuses on N < 120 000 only): the N CG solves are independent
+        (src/utils/diffusion.py:15-19,73-76 runs them as joblib tasks), so rank r solves the nodes of
+        shard_bounds(N, world, r), the parts are all-gathered (N * n_trunc * 4 bytes in all) and every rank installs the
+        complete result.  Bit-identical to the single-process result."""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            return self.gallery.diffusion_offline(n_trunc, kd)
+        import torch
+        from .sharded import shard_bounds
+        rank = dist.get_rank(self.group)
+        lo, hi = shard_bounds(self.N, world, rank)
+        ids, part = self.gallery.diffusion_offline_nodes(n_trunc, kd, lo, hi)
+        per = -(-self.N // world)
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = torch.zeros((per, n_trunc), dtype=torch.float32, device=dev)
+        mine[:hi - lo] = torch.from_numpy(part).to(dev)
+        out = torch.empty((world * per, n_trunc), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        vals = out[:self.N].cpu().numpy()                    # shard r occupies rows [r * per, r * per + its count)
+        self.gallery.diffusion_set_offline(ids, vals)
+        return ids, vals
 
     def search_online(self, queries, k_query=3, truncation_number=2000):
         """-> (ranks_dfs int64 [truncation_number, Q], scores float32 [Q, truncation_number])."""

@@ -183,6 +183,13 @@ int mi_kr_rerank(const void* qvecs, int64_t nq, int64_t q_row_stride, int64_t q_
  * on the device for mi_diffusion_online. */
 int mi_diffusion_offline(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma,
                          int32_t maxiter, double tol, int64_t* out_ids, float* out_vals, float* out_knn_sims);
+/* The same for the nodes [node0, node1) only (the N truncated CG solves of src/utils/diffusion.py:15-19 are
+ * independent, so the ranks of a multi-GPU run each take a node range of the replicated feature set; the k-NN graph and
+ * the Laplacian are computed in full on every rank).  out_ids [n][n_trunc] as above; out_vals [node1 - node0][n_trunc] =
+ * those rows of the offline matrix.  Gather the parts and install them with mi_diffusion_set_offline. */
+int mi_diffusion_offline_nodes(mi_gallery* g, int32_t n_trunc, int32_t kd, double alpha, int32_t gamma,
+                               int32_t maxiter, double tol, int64_t node0, int64_t node1, int64_t* out_ids,
+                               float* out_vals, float* out_knn_sims);
 /* Re-installs a cached offline result (the reference caches it as offline.jbl, src/utils/diffusion.py:21-40). */
 int mi_diffusion_set_offline(mi_gallery* g, const int64_t* ids, const float* vals, int32_t n_trunc);
 /* Online stage (src/utils/Reranking.py:238-253): top-k_query neighbours of each query, sims**gamma, weighted sum of

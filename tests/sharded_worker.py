@@ -22,7 +22,11 @@ def main():
     ap.add_argument("--hetero", action="store_true",
                     help="un-normalised gallery whose later rows are 60x larger: shards with different norm bounds, "
                          "the large-row shards fall back to a bf16 image on their own")
+    ap.add_argument("--diffusion", action="store_true",
+                    help="node-sharded offline diffusion (isehr_amd.diffusion.Diffusion under torch.distributed) instead")
     a = ap.parse_args()
+    if a.diffusion:
+        return diffusion_main(a)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -77,6 +81,37 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     shard.close()
+
+
+def diffusion_main(a):
+    """Every rank holds the same (clustered) features; the CG solves are split by node range and all-gathered."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import isehr_amd  # noqa: F401
+    from isehr_amd.diffusion import Diffusion
+    from isehr_amd.synth import synth_rows
+    rank = int(os.environ["RANK"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    n, d, T, kd = 1501, 48, 300, 40                 # N not a multiple of the world size: ragged last node range
+    f = synth_rows(5, 0, n, d) * 0.7 + 1.2 * synth_rows(6, 0, 30, d)[np.arange(n) % 30]
+    f = (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+    q = f[::211][:6] + 0.1 * synth_rows(7, 0, 6, d)
+    D = Diffusion(f, cache_dir=None)
+    off = D.get_offline_results(T, kd).tocsr()
+    off.sort_indices()
+    ranks, scores = D.search_online(q, 3, 200)
+    out = dict(data=off.data, indices=off.indices, indptr=off.indptr, ranks=ranks, scores=scores)
+    if rank == 0:
+        ids, vals = D.gallery.diffusion_offline(T, kd)          # all nodes in this process
+        out.update(ref_ids=ids, ref_vals=vals)
+        r2, s2 = D.search_online(q, 3, 200)
+        out.update(ref_ranks=r2, ref_scores=s2)
+    np.savez(a.out + ".%d.npz" % rank, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

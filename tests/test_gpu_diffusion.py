@@ -129,3 +129,26 @@ def test_diffusion_offline_at_the_reference_size():
     assert np.abs(ref_scores).max() > 0.5
     print("diffusion offline N=%d T=%d kd=%d: GPU %.2f s, oracle %.1f s, identical supports %.4f, max |d| %.2e"
           % (n, T, kd, t_gpu, t_cpu, same.mean(), err))
+
+
+def test_offline_diffusion_by_node_ranges():
+    """mi_diffusion_offline_nodes: any partition of the nodes gives the rows of the full result, bit for bit (the CG solves
+    are independent, src/utils/diffusion.py:15-19); an empty range is legal."""
+    from isehr_amd._lib import Gallery, NORM_NONE
+    from isehr_amd.synth import synth_rows
+    n, d, T, kd = 1203, 40, 256, 32
+    f = synth_rows(15, 0, n, d) * 0.7 + 1.1 * synth_rows(16, 0, 25, d)[np.arange(n) % 25]
+    f = (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+    G = Gallery.from_host(f, norm_mode=NORM_NONE)
+    try:
+        ids, vals = G.diffusion_offline(T, kd)
+        parts = []
+        for lo, hi in ((0, 1), (1, 400), (400, 400), (400, 1203)):
+            pid, pv = G.diffusion_offline_nodes(T, kd, lo, hi)
+            assert np.array_equal(pid, ids) and pv.shape == (hi - lo, T)
+            parts.append(pv)
+        assert np.array_equal(np.concatenate(parts), vals)
+        with pytest.raises(RuntimeError):
+            G.diffusion_offline_nodes(T, kd, 5, n + 1)
+    finally:
+        G.close()

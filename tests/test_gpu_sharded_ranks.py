@@ -57,3 +57,21 @@ def test_sharded_ranks_with_unequal_norm_bounds(tmp_path):
     for z in res:
         assert np.array_equal(z["idx"], z0["ref_idx"]) and np.array_equal(z["sc"], z0["ref_sc"])
         assert np.array_equal(z["aidx"], z0["ref_aidx"]) and np.array_equal(z["asc"], z0["ref_asc"])
+
+
+def test_node_sharded_diffusion_equals_single_process(tmp_path):
+    """SURVEY 8e, diffusion: the N truncated CG solves (src/utils/diffusion.py:15-19) split over 3 rank processes by
+    node range and all-gathered; every rank ends with the offline matrix and the online ranks of the one-process run."""
+    import scipy.sparse as sparse
+    res = _run(3, tmp_path, ("--diffusion",))
+    z0 = res[0]
+    n, T = z0["ref_ids"].shape
+    rows = np.repeat(np.arange(n), T)
+    ref = sparse.csr_matrix((z0["ref_vals"].reshape(-1), (rows, z0["ref_ids"].reshape(-1))), shape=(n, n),
+                            dtype=np.float32)
+    ref.sort_indices()
+    assert np.abs(ref.data).max() > 0.1
+    for z in res:
+        assert np.array_equal(z["indptr"], ref.indptr) and np.array_equal(z["indices"], ref.indices)
+        assert np.array_equal(z["data"], ref.data)
+        assert np.array_equal(z["ranks"], z0["ref_ranks"]) and np.array_equal(z["scores"], z0["ref_scores"])
