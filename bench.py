@@ -266,6 +266,9 @@ def main():
                        "tail": "re-score + sort of batch i on a second stream beside the scoring launch of batch i+1; "
                                "joined inside the timed region" if pipelined else "same stream", "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        "ingest_s": round(ingest_s, 3),
+                       # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
+                       # the rate of ONE call that prepares the resident gallery and answers one batch
+                       "queries_per_s_incl_gallery_ingest": nq / (ms_step * 1e-3 + ingest_s),
                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                        "survivors_per_query": st["survivors"] / max(1, st["queries"]),
                        "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e" % (k, worst)
