@@ -36,8 +36,6 @@ def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0):
     ranks = match_idx.T
     print(">> {}: average matching time: {}".format(dataset, time_per_query))
     res = {"map": evaluate.compute_map_and_print(dataset, ranks, gnd)}
-    if blocks:                # the re-ranking functions take the [D, N] array like the reference's
-        vecs = np.concatenate(vecs.blocks, axis=1)
     res["qge"] = QGE_hip(ranks, qvecs, vecs, dataset, gnd, K=min(K, 2048), device=device)
     return res
 

@@ -56,12 +56,15 @@ def QGE_hip(ranks, qvecs, vecs, dataset, gnd, cache_dir=None, gnd_path2=None, AQ
     N < 120000: alpha-QE with k=10, w=4 followed by truncated graph diffusion
     (src/utils/Reranking.py:212-264, implemented in diffusion.py).  Returns a dict with the rankings and
     mAP values (the reference prints and returns None)."""
-    vecs = np.asarray(vecs)
-    n = vecs.shape[1]
+    from .nnsearch import ColumnBlocks
+    blocks = isinstance(vecs, ColumnBlocks)       # [D, N] given as the column blocks the reference concatenates on the host
+    if not blocks:
+        vecs = np.asarray(vecs)
+    n = vecs.shape[0] if blocks else vecs.shape[1]
     out = {}
     if n >= 120000:
         Kq = int(K) if K else min(n, 1000)
-        g = get_gallery(vecs.T, None, False, NORM_NONE, device)
+        g = get_gallery(vecs if blocks else vecs.T, None, False, NORM_NONE, device)
         try:
             qx, ranks_aqe = feature_enhancement_hip(3, ranks, g, 8.0 / 2, Kq, None, False, device)
             out.update(qvecs_qe=qx, ranks_aqe=ranks_aqe)
@@ -97,6 +100,8 @@ def QGE_hip(ranks, qvecs, vecs, dataset, gnd, cache_dir=None, gnd_path2=None, AQ
             g.close()
         return out
     from . import diffusion
+    if blocks:
+        vecs = np.concatenate([np.asarray(b) for b in vecs.blocks], axis=1)
     return diffusion.qge_small_hip(ranks, qvecs, vecs, dataset, gnd, AQE=AQE, K=K, device=device, quiet=quiet)
 
 

@@ -478,3 +478,18 @@ def test_distractor_tensor_and_block_ingest(tmp_path):
     a, _ = matching_HIP(25, cat.T, q)
     b, _ = matching_HIP(25, ColumnBlocks([small, v1m]), q)
     assert np.array_equal(a, b)
+
+
+def test_qge_large_branch_accepts_column_blocks():
+    """QGE on [rOxford | 1M distractors] (src/test_rOP1m.py:136-139,168) without the host concatenation: the column blocks
+    go to the device one by one; rankings and mAP equal those of the concatenated array."""
+    from isehr_amd.nnsearch import matching_HIP, ColumnBlocks
+    from isehr_amd.reranking import QGE_hip
+    from isehr_amd.synth import planted_dataset
+    vecs, qvecs, gnd = planted_dataset(5, 130000, 32, 12)
+    ranks = matching_HIP(100, vecs.T, qvecs.T)[0].T
+    a = QGE_hip(ranks, qvecs, vecs, "roxford5k", gnd, K=100, quiet=True)
+    b = QGE_hip(ranks, qvecs, ColumnBlocks([vecs[:, :4993], vecs[:, 4993:]]), "roxford5k", gnd, K=100, quiet=True)
+    assert np.array_equal(a["ranks_aqe"], b["ranks_aqe"])
+    assert a["map_aqe"] == b["map_aqe"]
+    assert np.array_equal(a["qvecs_qe"], b["qvecs_qe"])
