@@ -50,10 +50,11 @@ def parse():
                     help="element type of the streamed 16-bit operand image (MFMA input type)")
     ap.add_argument("--with-aqe", action="store_true",
                     help="BASELINE configs[4]: every step = search + alpha-QE (k=3, w=4) re-search of the expanded queries")
-    ap.add_argument("--async-tail", action="store_true",
-                    help="single GPU: re-score + sort of batch i on the handle's second stream beside the scoring launch of "
-                         "batch i+1 (measured: no gain -- the chip is power-limited and the scoring launch slows down by what "
-                         "the overlap hides; off by default, the roofline is quoted on the undisturbed launch)")
+    ap.add_argument("--async-tail", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+                    help="single GPU: re-score + sort of batch i on the handle's second stream.  1: beside the scoring launch "
+                         "of batch i+1 (measured: no gain -- the board is at its power cap and the scoring launch slows "
+                         "down by what the overlap hides).  2: beside the query ingest + bootstrap of batch i+1 only; its "
+                         "scoring launch waits for the tail.  Results of every batch are joined inside the timed region")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -158,9 +159,9 @@ def main():
 
     # single GPU: the exact re-score + sort of a batch runs on the handle's second stream beside the scoring launch of the
     # next batch (mi_set_option "async_tail"); every batch's results are complete after gal.join(), inside the timed region
-    pipelined = world == 1 and args.async_tail
+    pipelined = world == 1 and args.async_tail > 0
     if pipelined:
-        gal.set_option("async_tail", 1)
+        gal.set_option("async_tail", args.async_tail)
 
     def one_step(qb):
         idx_, sc_ = sg.search(qb, k, join=not pipelined or args.with_aqe)
@@ -263,8 +264,10 @@ def main():
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
                        "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
                        "parallelism": "row-shard x%d" % world, "alpha_qe": bool(args.with_aqe),
-                       "tail": "re-score + sort of batch i on a second stream beside the scoring launch of batch i+1; "
-                               "joined inside the timed region" if pipelined else "same stream", "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
+                       "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "
+                                "the timed region" % ("scoring launch" if args.async_tail == 1 else
+                                                      "query ingest + bootstrap (not the scoring launch)"))
+                               if pipelined else "same stream", "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        "ingest_s": round(ingest_s, 3),
                        # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
                        # the rate of ONE call that prepares the resident gallery and answers one batch

@@ -111,6 +111,7 @@ struct mi_gallery {
   hipStream_t tail_stream = nullptr;
   hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
   bool ev_tail_valid[2] = {false, false};
+  hipEvent_t gate_before_scoring = nullptr;   // async_tail 2: the filtered scoring launch of a batch waits for this event
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -402,6 +403,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     } else {
       launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
     }
+    if (g->gate_before_scoring) {               // the previous batch's tail ran beside this batch's ingest / bootstrap
+      HIPC(hipStreamWaitEvent(s, g->gate_before_scoring, 0));
+      g->gate_before_scoring = nullptr;
+    }
     score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
     ladder_on = false;
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 0, nullptr, s, fc_rows, fc_cnt, ws.rcap);
@@ -412,6 +417,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s, fc_rows, fc_cnt, ws.rcap);
     HIPC(hipGetLastError());
     return MI_OK;
+  }
+  if (g->gate_before_scoring) {                 // other schedules: no bootstrap worth overlapping, wait up front
+    HIPC(hipStreamWaitEvent(s, g->gate_before_scoring, 0));
+    g->gate_before_scoring = nullptr;
   }
   // chunk schedule (shards too small or too large for the sample-based single launch): thresholds come from the rows
   // scored and kept so far; once those are >= 1/160 of the shard the rest goes out as one speculative launch
@@ -506,6 +515,9 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
       g->tail_set ^= 1;
       tail = g->tail_stream;
       if (g->ev_tail_valid[set]) HIPC(hipStreamWaitEvent(s, g->ev_tail[set], 0));   // the tail that last read this set is done
+      // mode 2: the previous batch's tail (other set) may run beside this batch's query ingest and bootstrap -- both
+      // latency-bound, the board far below its power cap -- but not beside its scoring launch (power-capped: nothing to gain)
+      if (g->async_tail == 2 && g->ev_tail_valid[set ^ 1]) g->gate_before_scoring = g->ev_tail[set ^ 1];
     }
     ws.q_f32 = ws.q_f32_set[set];
     ws.cand_rows = ws.cand_rows_set[set];
@@ -518,7 +530,7 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     }
     if ((rc = phase2_batch(g, b, k, g->ws.L, out_idx + q0 * k, out_score ? out_score + q0 * k : nullptr,
                            out_score64 ? out_score64 + q0 * k : nullptr, tail, /*have_cand=*/true,
-                           /*resident=*/async && b > STREAM_MAX_QUERIES)) != MI_OK)
+                           /*resident=*/async && g->async_tail == 1 && b > STREAM_MAX_QUERIES)) != MI_OK)
       return rc;
     if (async) {
       HIPC(hipEventRecord(g->ev_tail[set], tail));
@@ -1868,7 +1880,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
   else if (n == "ladder") g->ladder = value != 0;
-  else if (n == "async_tail") g->async_tail = value != 0;
+  else if (n == "async_tail") { REQUIRE(value == 0 || value == 1 || value == 2, "async_tail: 0, 1 or 2"); g->async_tail = (int)value; }
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
     g->qnorm_override = (int)value;

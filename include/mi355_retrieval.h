@@ -253,7 +253,8 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
 /* Tunables: "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
  * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "xcc_balance" (XCD shares by measured
- * speed), "async_tail" (re-score + sort on the handle's own stream, see mi_search_join), "rescore_grid_x" (workgroups of 2
+ * speed), "async_tail" (1 | 2: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
+ * query ingest and bootstrap only; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),

@@ -123,10 +123,12 @@ def test_large_shard_chunk_schedule_equals_exact_path(lib, img):
         g.close()
 
 
-def test_async_tail_gives_the_same_answers(lib):
-    """mi_set_option("async_tail", 1): re-score + sort of batch i on the handle's own stream beside the scoring launch of
-    batch i + 1.  Several different batches in flight, distinct output buffers: after mi_search_join every batch equals
-    the synchronous answer bit for bit; a synchronous host search on the same handle in between is unaffected."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_async_tail_gives_the_same_answers(lib, mode):
+    """mi_set_option("async_tail", 1 | 2): re-score + sort of batch i on the handle's own stream beside the scoring launch
+    (1) or only beside the query ingest + bootstrap (2) of batch i + 1.  Several different batches in flight, distinct
+    output buffers: after mi_search_join every batch equals the synchronous answer bit for bit; a synchronous host search
+    on the same handle in between is unaffected."""
     import torch
     n, d, k = 300000, 256, 100
     raw = _device_rows(lib, 61, n, d)
@@ -134,7 +136,7 @@ def test_async_tail_gives_the_same_answers(lib):
     try:
         qs = [_device_rows(lib, 70 + i, 1024 if i % 2 == 0 else 300, d) for i in range(5)]
         ref = [_search(g, q, k) for q in qs]
-        g.set_option("async_tail", 1)
+        g.set_option("async_tail", mode)
         stream = torch.cuda.current_stream().cuda_stream
         outs = []
         for rep in range(2):
@@ -153,7 +155,7 @@ def test_async_tail_gives_the_same_answers(lib):
         big = _device_rows(lib, 90, 2500, d)
         g.set_option("async_tail", 0)
         bi, bs = _search(g, big, k)
-        g.set_option("async_tail", 1)
+        g.set_option("async_tail", mode)
         idx = torch.empty((2500, k), dtype=torch.int64, device=big.device)
         sc = torch.empty((2500, k), dtype=torch.float32, device=big.device)
         g.search_device(big.data_ptr(), 2500, k, idx.data_ptr(), sc.data_ptr(), None, stream)
