@@ -189,3 +189,37 @@ def test_concurrent_searches_from_threads(lib):
         A.close()
         B.close()
     assert oracle.check_topk_parity(ref_a[2][0], oracle.exact_scores_f64(ga, qa[2]), 50, TAU) == []
+
+
+def test_handles_release_their_device_memory(lib):
+    """A server that rebuilds its gallery (--ifgenerate) must not leak: create / search (every path: filtered, exact, dense
+    fallback, full ranking, alpha-QE, diffusion) / close in a loop and compare the free device memory."""
+    import torch
+    from isehr_amd._lib import Gallery, NORM_NONE
+    rng = np.random.default_rng(2)
+    g = rng.standard_normal((40000, 128)).astype(np.float32)
+    q = rng.standard_normal((200, 128)).astype(np.float32)
+    small = rng.standard_normal((1500, 32)).astype(np.float32)
+
+    def cycle():
+        G = Gallery.from_host(g)
+        idx, _, _ = G.search(q, 50)
+        G.aqe_search(np.ascontiguousarray(idx.T), 3, 4.0, 50)
+        G.rank_prefix(q[:4], 300)
+        G.dense_search(q[:8], 400)
+        G.set_option("force_exact", 1)
+        G.search(q[:16], 10)
+        G.close()
+        S = Gallery.from_host(small, norm_mode=NORM_NONE)
+        S.diffusion_offline(128, 16)
+        S.diffusion_online(small[:3], 3, 3, 100)
+        S.close()
+
+    cycle()                                                  # first use: code objects, torch's own pools
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 32 * 2**20, (free0, free1)
