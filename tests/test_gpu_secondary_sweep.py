@@ -90,3 +90,24 @@ def test_kr_rerank_rejects_k1_beyond_its_buffers():
     v = synth_rows(1, 0, 300, 16)
     with pytest.raises(RuntimeError, match="k1 too large"):
         kr_reranking_hip(v[:4].T.copy(), v.T.copy(), k1=30)
+
+
+@pytest.mark.parametrize("b,c,cout,h,w,p", [(4, 2048, 2048, 24, 32, 3.0), (1, 2048, 2048, 32, 43, 3.0), (5, 512, 128, 7, 9, 2.2),
+                                           (2, 100, 100, 1, 1, 3.0), (3, 2048, 512, 16, 16, 1.0)])
+def test_descriptor_tail_at_real_shapes(b, c, cout, h, w, p):
+    """GeM(p, eps) -> L2N -> whiten Linear -> L2N (src/networks/imageretrievalnet.py:183-187, src/layers/functional.py) at
+    the network's real shape (2048 channels, 2048 outputs, feature maps of a 1024-pixel image) and odd ones, against the
+    same chain in float64."""
+    import torch
+    from isehr_amd.extractor import DescriptorTail
+    g = torch.Generator().manual_seed(b * 1000 + c + h)
+    feat = torch.rand((b, c, h, w), generator=g) * 2.0 - 0.3          # post-ReLU-like, with values below eps to clamp
+    W = torch.randn((cout, c), generator=g) / c ** 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    got = DescriptorTail(p, 1e-6, W.cuda(), bias.cuda())(feat.cuda()).cpu().double()
+    x = feat.double().clamp(min=1e-6).pow(p).mean(dim=(2, 3)).pow(1.0 / p)               # LF.gem
+    x = x / (x.norm(dim=1, keepdim=True) + 1e-6)                                          # LF.l2n
+    y = x @ W.double().t() + bias.double()
+    y = y / (y.norm(dim=1, keepdim=True) + 1e-6)
+    assert got.shape == (b, cout)
+    assert (got - y).abs().max().item() < 2e-6
