@@ -98,7 +98,7 @@ struct mi_gallery {
   Workspace ws;
   // options
   int chunk0_tiles = 0 /* 0 = default, bootstrap_tiles() */, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0,
-      speculative = 1, rescore_grid_x = 0;
+      speculative = 1, rescore_grid_x = 0, spec_max_ratio = 160;
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
@@ -313,7 +313,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   // probability 1e-7 per query (Poisson tail) and keeps the expected survivors at r * N / n_s.  The sample entries
   // are dropped once the threshold is taken (the scoring launch visits every tile, sample rows included).
   int32_t samp_r = 0;
-  if (g->speculative && !exact && ntiles >= 2 * t0 && g->n / (t0 * TILE) <= 160) {
+  if (g->speculative && !exact && ntiles >= 2 * t0 && g->n / (t0 * TILE) <= g->spec_max_ratio) {
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
     const int32_t r = spec_rank(lambda);
     if (r < k) samp_r = r;
@@ -1840,6 +1840,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   if (n == "chunk0_tiles") *out_value = g->chunk0_tiles;
   else if (n == "sample_rows") *out_value = (double)(bootstrap_tiles(g) * TILE);
   else if (n == "rescore_grid_x") *out_value = g->rescore_grid_x;
+  else if (n == "spec_max_ratio") *out_value = g->spec_max_ratio;
   else if (n == "chunk_growth") *out_value = g->chunk_growth;
   else if (n == "survivor_cap") *out_value = g->surv_cap;
   else if (n == "rescore_cap") *out_value = g->rescore_cap;
@@ -1862,6 +1863,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   REQUIRE(g && name, "null");
   const std::string n(name);
   if (n == "chunk0_tiles") { REQUIRE(value >= 0, "chunk0_tiles >= 0 (0 = default)"); g->chunk0_tiles = (int)value; }
+  else if (n == "spec_max_ratio") { REQUIRE(value >= 1 && value <= 4096, "spec_max_ratio in [1, 4096]"); g->spec_max_ratio = (int)value; }
   else if (n == "rescore_grid_x") { REQUIRE(value >= 0 && value <= 4096, "rescore_grid_x in [0, 4096]"); g->rescore_grid_x = (int)value; }
   else if (n == "chunk_growth") { REQUIRE(value >= 1, "chunk_growth >= 1"); g->chunk_growth = (int)value; }
   else if (n == "survivor_cap") {

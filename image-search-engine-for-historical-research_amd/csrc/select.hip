@@ -329,7 +329,7 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 // of the 512 maxima (W = 4r) is a lower bound of the W-th largest overall, so the values >= it (W plus a few) are
 // gathered and ranked exactly by counting.  Falls back to the plain select if more than 256 values qualify (ties).
 // The sample entries are dropped afterwards (cnt = 0), like select_maintain_kernel<0> with spec != 0.
-constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (4, 8, 16) = 2048, 4096, 8192 sample scores
+constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
                                                                         int32_t lad_r) {
@@ -407,13 +407,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
 }
 
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
-  const bool size_ok = first_cnt == SAMP_THREADS * 4u || first_cnt == SAMP_THREADS * 8u || first_cnt == SAMP_THREADS * 16u;
+  const bool size_ok = first_cnt == SAMP_THREADS * 2u || first_cnt == SAMP_THREADS * 4u || first_cnt == SAMP_THREADS * 8u ||
+                       first_cnt == SAMP_THREADS * 16u;
   return size_ok && spec_r >= 1 && spec_r < k && 4 * spec_r <= 256 && (int64_t)first_cnt >= k;
 }
 
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
                              int32_t lad_r) {
-  if (first_cnt == SAMP_THREADS * 4u)
+  if (first_cnt == SAMP_THREADS * 2u)
+    hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+  else if (first_cnt == SAMP_THREADS * 4u)
     hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
   else if (first_cnt == SAMP_THREADS * 8u)
     hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
