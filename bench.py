@@ -55,6 +55,9 @@ def parse():
                          "of batch i+1 (measured: no gain -- the board is at its power cap and the scoring launch slows "
                          "down by what the overlap hides).  2: beside the query ingest + bootstrap of batch i+1 only; its "
                          "scoring launch waits for the tail.  Results of every batch are joined inside the timed region")
+    ap.add_argument("--force-protocol", action="store_true",
+                    help="one GPU: run the sharded two-phase protocol with its RCCL collectives on a group of ONE rank "
+                         "(what a rank of a multi-GPU run executes, collectives included); diagnostic, not the headline")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -121,6 +124,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    if world == 1 and args.force_protocol:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
     dev = torch.device("cuda", dev_index)
     n_total = args.rows or WORKLOADS[args.workload][0]
     d, nq, k = args.dim, args.queries, args.topk
@@ -142,7 +150,7 @@ def main():
     for opt in args.option:
         name, val = opt.split("=")
         gal.set_option(name, float(val))
-    sg = ShardedGallery(gal)
+    sg = ShardedGallery(gal, force_protocol=args.force_protocol)
 
     # a small pool of query batches (seeded), cycled over the steps
     pool = []
@@ -263,7 +271,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
                        "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
-                       "parallelism": "row-shard x%d" % world, "alpha_qe": bool(args.with_aqe),
+                       "parallelism": "row-shard x%d" % world + (" (two-phase protocol over RCCL forced on one rank)"
+                                                                  if args.force_protocol and world == 1 else ""),
+                       "alpha_qe": bool(args.with_aqe),
                        "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "
                                 "the timed region" % ("scoring launch" if args.async_tail == 1 else
                                                       "query ingest + bootstrap (not the scoring launch)"))
@@ -281,7 +291,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gal, pool[(args.steps - 1) % len(pool)].cpu().numpy(), n_total, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or (args.force_protocol and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
     gal.close()

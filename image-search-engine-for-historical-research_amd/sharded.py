@@ -40,14 +40,17 @@ def all_gather_stacked(t, group=None):
 class ShardedGallery:
     """`gallery` is this rank's shard (created with row_offset = shard_bounds(...)[0])."""
 
-    def __init__(self, gallery, group=None):
+    def __init__(self, gallery, group=None, force_protocol=False):
+        """force_protocol: run the two-phase protocol and its collectives even when the group has ONE rank (a process group
+        must be initialised) -- the way to exercise the RCCL path itself on a one-GPU box."""
         import torch.distributed as dist
         self.g = gallery
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._buf = {}
         self._join = True
-        if self.world > 1:
+        self._protocol = self.world > 1 or (force_protocol and dist.is_available() and dist.is_initialized())
+        if self._protocol:
             self._agree()
             # a shard of a G-way gallery expects ~127 / G candidates per query: size the re-score launch for that (a grid
             # for 128 per query is mostly workgroups that exit at once, 23 us of dispatch at G = 8); larger counts loop
@@ -86,7 +89,8 @@ class ShardedGallery:
 
     def search(self, q, k, query_norm_none=False, verify=False, join=True):
         """q: [Q, D] float32 cuda tensor (same on every rank), Q <= 1024.
-        Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.
+        Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.  They are this object's
+        buffers for (Q, k): the next search of the same shape overwrites them (clone what must outlive it).
         query_norm_none: use the queries as they are (expanded queries of alpha-QE).
 
         The device entry points run asynchronously and report buffer overflows / a failed speculative threshold
@@ -127,7 +131,7 @@ class ShardedGallery:
         """True on every rank iff any shard raised a sticky flag since the last call (synchronises; the handle's
         statistics accumulators are left alone)."""
         bad = 1 if self.g.flags() else 0
-        if self.world > 1:
+        if self._protocol:
             import torch
             import torch.distributed as dist
             dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
@@ -141,7 +145,7 @@ class ShardedGallery:
         nq = q.shape[0]
         b = self._buffers(nq, k, q.device)
         stream = torch.cuda.current_stream().cuda_stream
-        if self.world == 1:
+        if not self._protocol:
             self.g.search_device(q.data_ptr(), nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), None, stream)
             if self._join:
                 self.g.join(stream)
@@ -172,7 +176,7 @@ class ShardedGallery:
         part = torch.empty((nq, d), dtype=torch.float64, device=ranks.device)
         self.g.aqe_partial_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, w, part.data_ptr(),
                                   stream)
-        if self.world > 1:
+        if self._protocol:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
         qx = torch.empty((nq, d), dtype=torch.float32, device=ranks.device)
         _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)

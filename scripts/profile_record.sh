@@ -30,6 +30,7 @@ python scripts/xcc_report.py > $o/${tag}_xcc_report.txt 2>&1 || true
 python -m pytest tests/test_gpu_diffusion.py -q -s -k reference_size > $o/${tag}_diffusion_refsize.txt 2>&1 || true
 python scripts/ladder_probe.py > $o/${tag}_ladder_probe.txt 2> /dev/null || true
 (for g in 2 4 8; do python scripts/shard_step_model.py $g 1005994 rescore_grid_x=$((96 / g)) 2> /dev/null | tail -2; done) > $o/${tag}_shard_model.txt || true
+(for f in "" "--force-protocol"; do python bench.py --no-cpu-baseline --rows 125750 $f 2> /dev/null | tail -1 | cut -c1-700; done) > $o/${tag}_protocol_rccl1.txt || true
 echo "scripts done"
 # 4. kernel A/B driver and MFMA probe (C++, no torch)
 bash scripts/kbench_build.sh > /dev/null 2>&1 || true    # the driver shares struct layouts with the library: never run a stale one

@@ -24,9 +24,13 @@ def main():
                          "the large-row shards fall back to a bf16 image on their own")
     ap.add_argument("--diffusion", action="store_true",
                     help="node-sharded offline diffusion (isehr_amd.diffusion.Diffusion under torch.distributed) instead")
+    ap.add_argument("--rccl1", action="store_true",
+                    help="ONE rank over RCCL (backend nccl): the two-phase protocol with its real collectives on a one-GPU box")
     a = ap.parse_args()
     if a.diffusion:
         return diffusion_main(a)
+    if a.rccl1:
+        return rccl1_main(a)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -78,6 +82,67 @@ def main():
                    single_dtype=int(single.get_option("image_dtype")))
         single.close()
     np.savez(a.out + ".%d.npz" % rank, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    shard.close()
+
+
+def rccl1_main(a):
+    """RCCL refuses two ranks on one device, so the collectives themselves (all_gather_into_tensor / all_reduce on device
+    tensors, RCCL's own stream ordered against the stream the library launches on) are exercised with a group of ONE rank:
+    ShardedGallery(force_protocol=True) runs phase 1 -> all-gather -> K-th -> phase 2 -> all-gather -> merge exactly as it
+    does on 8 GPUs.  Ten different batches are issued back to back without a host synchronisation, on a side stream."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import isehr_amd  # noqa: F401
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    backend = os.environ.get("ISEHR_RCCL1_BACKEND", "nccl")             # "gloo": the same flow with host collectives
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    n, d, nq, k = 200000, 128, a.queries, a.topk
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        stream = torch.cuda.current_stream().cuda_stream
+        raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(raw.data_ptr(), 77, 0, n, d, stream)
+        qs = []
+        for i in range(10):
+            q = torch.empty((nq, d), dtype=torch.float32, device=dev)
+            _lib.synth_fill_device(q.data_ptr(), 100 + i, 0, nq, d, stream)
+            qs.append(q)
+        torch.cuda.synchronize()
+        shard = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+        plain = ShardedGallery(shard)                                   # world == 1: the single-shard path
+        ref = []
+        for q in qs:
+            i_, s_ = plain.search(q, k)
+            ref.append((i_.clone(), s_.clone()))
+        r_aidx, r_asc, r_qx = plain.aqe_search(ref[0][0].t(), 3, 4.0, k)
+        r_aidx, r_asc, r_qx = r_aidx.clone(), r_asc.clone(), r_qx.clone()
+        torch.cuda.synchronize()
+        sg = ShardedGallery(shard, force_protocol=True)                 # the protocol + RCCL collectives, one rank
+        got = []
+        for q in qs:                                                    # no host synchronisation between batches
+            i_, s_ = sg.search(q, k)
+            got.append((i_.clone(), s_.clone()))
+        aidx, asc, qx = (t.clone() for t in sg.aqe_search(got[0][0].t(), 3, 4.0, k))   # results live in shared buffers
+        vi, vs = sg.search(qs[3], k, verify=True)
+        torch.cuda.synchronize()
+        flagged = sg.any_flag()
+    eq = [int(torch.equal(g[0], r[0]) and torch.equal(g[1], r[1])) for g, r in zip(got, ref)]
+    eq_aqe = [int(torch.equal(aidx, r_aidx)), int(torch.equal(asc, r_asc)), int(torch.equal(qx, r_qx))]
+    eq_ver = int(torch.equal(vi, ref[3][0]) and torch.equal(vs, ref[3][1]))
+    ok = all(eq) and all(eq_aqe) and eq_ver
+    np.savez(a.out + ".0.npz", ok=int(ok), flagged=int(flagged), backend=dist.get_backend(), eq=np.array(eq),
+             eq_aqe=np.array(eq_aqe), eq_ver=eq_ver,
+             mism=np.array([int((g[0] != r[0]).sum().item()) for g, r in zip(got, ref)]))
     dist.barrier()
     dist.destroy_process_group()
     shard.close()

@@ -75,3 +75,13 @@ def test_node_sharded_diffusion_equals_single_process(tmp_path):
         assert np.array_equal(z["indptr"], ref.indptr) and np.array_equal(z["indices"], ref.indices)
         assert np.array_equal(z["data"], ref.data)
         assert np.array_equal(z["ranks"], z0["ref_ranks"]) and np.array_equal(z["scores"], z0["ref_scores"])
+
+
+def test_protocol_over_rccl_with_one_rank(tmp_path):
+    """The collectives of the sharded search over RCCL itself (backend "nccl"), which a one-GPU box can only run with a
+    group of one rank: ten batches back to back on a side stream, alpha-QE and a verified search -- equal to the
+    single-shard path bit for bit."""
+    res = _run(1, tmp_path, ("--rccl1",))
+    z = res[0]
+    assert str(z["backend"]) == os.environ.get("ISEHR_RCCL1_BACKEND", "nccl")
+    assert int(z["ok"]) == 1 and int(z["flagged"]) == 0, (z["eq"], z["eq_aqe"], z["eq_ver"], z["mism"])
