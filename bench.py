@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--force-protocol", action="store_true",
                     help="one GPU: run the sharded two-phase protocol with its RCCL collectives on a group of ONE rank "
                          "(what a rank of a multi-GPU run executes, collectives included); diagnostic, not the headline")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="sharded runs (--gpus N > 1 or --force-protocol): ShardedGallery.search_stream -- asynchronous "
+                         "all-gathers, three batches in flight -- instead of one synchronous search per step")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -179,8 +182,23 @@ def main():
             idx_, sc_, one_step.last_queries = sg.aqe_search(idx_.t(), 3, 4.0, k, join=not pipelined)
         return idx_, sc_
 
-    for i in range(args.warmup):
-        one_step(pool[i % len(pool)])
+    use_stream = args.pipeline and (world > 1 or args.force_protocol) and not args.with_aqe
+
+    def run_steps(count):
+        """`count` steps; returns the results of the last one"""
+        if not use_stream:
+            out_ = None
+            for i in range(count):
+                out_ = one_step(pool[i % len(pool)])
+            return out_
+        out_ = None
+        for out_ in sg.search_stream((pool[i % len(pool)] for i in range(count)), k):
+            pass
+        one_step.last_queries = pool[(count - 1) % len(pool)]
+        return out_
+
+    if args.warmup:
+        run_steps(args.warmup)
     if pipelined:
         gal.join(stream)
     barrier()
@@ -188,8 +206,7 @@ def main():
     gal.profile(True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        idx, sc = one_step(pool[i % len(pool)])
+    idx, sc = run_steps(args.steps)
     if pipelined:
         gal.join(stream)
     barrier()
@@ -274,6 +291,8 @@ def main():
                        "parallelism": "row-shard x%d" % world + (" (two-phase protocol over RCCL forced on one rank)"
                                                                   if args.force_protocol and world == 1 else ""),
                        "alpha_qe": bool(args.with_aqe),
+                       "collectives": ("asynchronous, three batches in flight (search_stream)" if use_stream else
+                                       "synchronous per batch") if (world > 1 or args.force_protocol) else None,
                        "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "
                                 "the timed region" % ("scoring launch" if args.async_tail == 1 else
                                                       "query ingest + bootstrap (not the scoring launch)"))

@@ -96,6 +96,11 @@ struct mi_gallery {
   int64_t hbm_bytes = 0;
   hipStream_t stream = nullptr;
   Workspace ws;
+  // option "workspace_slot": the phase API of batch i + 1 may run in the other workspace while batch i waits for its
+  // collectives (sharded search, two batches in flight).  `ws` is always the active one; `ws_alt` the parked one.  The
+  // sticky flags, the statistics, the kernel clocks and the XCD shares are ONE set: the second workspace aliases them.
+  Workspace ws_alt;
+  int ws_slot = 0;
   // options
   int chunk0_tiles = 0 /* 0 = default, bootstrap_tiles() */, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0,
       speculative = 1, rescore_grid_x = 0, spec_max_ratio = 160;
@@ -149,8 +154,14 @@ static int dev_alloc(Workspace& ws, T** p, size_t count) {
 static int ws_ensure(mi_gallery* g, int32_t k) {
   Workspace& ws = g->ws;
   if (ws.qcap >= QB && ws.kcap >= k && ws.cap == g->surv_cap && ws.rcap == g->rescore_cap) return MI_OK;
-  const int32_t kcap = std::max<int32_t>(k, ws.kcap);
+  const int32_t kcap = std::max<int32_t>(k, std::max(ws.kcap, g->ws_alt.kcap));
+  // (re)allocation of the active workspace.  The parked one survives only if this is the active one's FIRST allocation
+  // (then it owns the shared flags / statistics and the new one aliases them); any other re-allocation may free what
+  // the parked one aliases, so it is dropped too and rebuilt when it is next switched in.
+  const bool first_alloc = ws.allocs.empty();
   ws_free(ws);
+  if (!first_alloc || g->ws_alt.kcap < kcap || g->ws_alt.cap != g->surv_cap || g->ws_alt.rcap != g->rescore_cap)
+    ws_free(g->ws_alt);
   ws.qcap = QB;
   ws.kcap = kcap;
   ws.cap = g->surv_cap;
@@ -205,6 +216,12 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
     XccBalance hb;
     init_xcc_balance_host(&hb);
     HIPC(hipMemcpy(ws.bal, &hb, sizeof hb, hipMemcpyHostToDevice));
+  }
+  if (g->ws_alt.flags) {                   // one set of flags / statistics / clocks / XCD shares per handle
+    ws.flags = g->ws_alt.flags;
+    ws.stats2 = g->ws_alt.stats2;
+    ws.dbg = g->ws_alt.dbg;
+    ws.bal = g->ws_alt.bal;
   }
   return MI_OK;
 }
@@ -578,6 +595,7 @@ int mi_gallery_destroy(mi_gallery* g) {
   }
   if (g->tail_stream) (void)hipStreamDestroy(g->tail_stream);
   ws_free(g->ws);
+  ws_free(g->ws_alt);
   for (auto& e : g->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -1749,25 +1767,26 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
   HIPC(hipStreamSynchronize(g->stream));
   HIPC(hipDeviceSynchronize());
   prof_collect(g);
-  if (g->ws.qcap) {
+  Workspace& sw = sw.qcap ? g->ws : g->ws_alt;          // flags / statistics / clocks are ONE set for both slots
+  if (sw.qcap) {
     uint64_t s2[2] = {0, 0};
-    HIPC(hipMemcpy(s2, g->ws.stats2, 16, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(s2, sw.stats2, 16, hipMemcpyDeviceToHost));
     g->stats.survivors += (int64_t)s2[0];
     g->stats.candidates += (int64_t)s2[1];
-    HIPC(hipMemset(g->ws.stats2, 0, 16));
+    HIPC(hipMemset(sw.stats2, 0, 16));
     uint32_t flags = 0;
-    HIPC(hipMemcpy(&flags, g->ws.flags, 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(&flags, sw.flags, 4, hipMemcpyDeviceToHost));
     if (flags) {
       // sticky device flag: a device-API batch overflowed since the last status call.  Counted once and cleared, so
       // that polling without reset does not count the same event again.
       g->stats.overflow_batches += 1;
-      HIPC(hipMemset(g->ws.flags, 0, 4));
+      HIPC(hipMemset(sw.flags, 0, 4));
     }
     // in-kernel clock of the last tile-kernel launch: median over its waves of cycles / (10 ns ticks) x 100 MHz
-    std::vector<unsigned long long> c((size_t)g->ws.nseg * 8);
-    HIPC(hipMemcpy(c.data(), g->ws.dbg, c.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> c((size_t)sw.nseg * 8);
+    HIPC(hipMemcpy(c.data(), sw.dbg, c.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> mhz;
-    for (size_t w = 0; w < g->ws.nseg; ++w)
+    for (size_t w = 0; w < sw.nseg; ++w)
       if (c[w * 8 + 7] > 0 && c[w * 8 + 6] > 0) mhz.push_back((double)c[w * 8 + 6] / (double)c[w * 8 + 7] * 100.0);
     if (!mhz.empty()) {
       std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
@@ -1817,6 +1836,7 @@ int mi_gallery_set_image_dtype(mi_gallery* g, int f16) {
   g->img_f16 = f16;
   g->samp_for_n = -1;          // the bootstrap sample image is rebuilt from the new image
   ws_free(g->ws);              // the query image buffers follow the element type
+  ws_free(g->ws_alt);
   return MI_OK;
 }
 
@@ -1826,10 +1846,13 @@ int mi_search_flags(mi_gallery* g, uint32_t* out_flags) {
   HIPC(hipStreamSynchronize(g->stream));
   HIPC(hipDeviceSynchronize());
   *out_flags = 0;
-  if (g->ws.qcap) {
-    int rc = read_and_clear_flags(g, out_flags);
-    if (rc != MI_OK) return rc;
-    if (*out_flags) g->stats.overflow_batches += 1;
+  Workspace& sw = g->ws.qcap ? g->ws : g->ws_alt;          // one set of flags for both workspace slots
+  if (sw.qcap) {
+    HIPC(hipMemcpy(out_flags, sw.flags, 4, hipMemcpyDeviceToHost));
+    if (*out_flags) {
+      HIPC(hipMemset(sw.flags, 0, 4));
+      g->stats.overflow_batches += 1;
+    }
   }
   return MI_OK;
 }
@@ -1840,6 +1863,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   if (n == "chunk0_tiles") *out_value = g->chunk0_tiles;
   else if (n == "sample_rows") *out_value = (double)(bootstrap_tiles(g) * TILE);
   else if (n == "rescore_grid_x") *out_value = g->rescore_grid_x;
+  else if (n == "workspace_slot") *out_value = g->ws_slot;
   else if (n == "spec_max_ratio") *out_value = g->spec_max_ratio;
   else if (n == "chunk_growth") *out_value = g->chunk_growth;
   else if (n == "survivor_cap") *out_value = g->surv_cap;
@@ -1864,6 +1888,13 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   const std::string n(name);
   if (n == "chunk0_tiles") { REQUIRE(value >= 0, "chunk0_tiles >= 0 (0 = default)"); g->chunk0_tiles = (int)value; }
   else if (n == "spec_max_ratio") { REQUIRE(value >= 1 && value <= 4096, "spec_max_ratio in [1, 4096]"); g->spec_max_ratio = (int)value; }
+  else if (n == "workspace_slot") {
+    REQUIRE(value == 0 || value == 1, "workspace_slot: 0 or 1");
+    if ((int)value != g->ws_slot) {
+      std::swap(g->ws, g->ws_alt);
+      g->ws_slot = (int)value;
+    }
+  }
   else if (n == "rescore_grid_x") { REQUIRE(value >= 0 && value <= 4096, "rescore_grid_x in [0, 4096]"); g->rescore_grid_x = (int)value; }
   else if (n == "chunk_growth") { REQUIRE(value >= 1, "chunk_growth >= 1"); g->chunk_growth = (int)value; }
   else if (n == "survivor_cap") {

@@ -72,9 +72,9 @@ class ShardedGallery:
         dist.all_reduce(b, op=dist.ReduceOp.MAX, group=self.group)
         self.g.norm_bounds(raise_to=[float(v) for v in b.tolist()])
 
-    def _buffers(self, nq, k, device):
+    def _buffers(self, nq, k, device, slot=0):
         import torch
-        key = (nq, k)
+        key = (nq, k, slot)
         if key not in self._buf:
             self._buf[key] = dict(
                 approx=torch.empty((nq, k), dtype=torch.float32, device=device),
@@ -124,6 +124,76 @@ class ShardedGallery:
                                        "(massive ties: use the dense path)")
             return out
         finally:
+            if query_norm_none:
+                self.g.set_option("query_norm_override", -1)
+
+    def search_stream(self, batches, k, query_norm_none=False):
+        """Pipelined search over an iterable of query batches (each [Q, D] float32 cuda, Q <= 1024): a generator of
+        (idx, score) in the order of the batches.  Both all-gathers of a batch are asynchronous and are waited for only
+        after phase 1 of the NEXT batch (and phase 2 of the one between) has been enqueued, so their latency hides behind
+        compute instead of idling the GPU twice per batch.  Three batches are in flight; the handle keeps two
+        workspaces (option "workspace_slot").  The yielded tensors are this object's buffers of the batch's slot: they stay
+        valid until two further batches have been yielded (clone what must live longer).  Same answers as search()."""
+        import torch
+        import torch.distributed as dist
+        if not self._protocol:
+            for q in batches:
+                yield self.search(q, k, query_norm_none=query_norm_none)
+            return
+        stream = torch.cuda.current_stream().cuda_stream
+        G = self.world
+
+        def gather_async(t):
+            t = t.contiguous()
+            out = torch.empty((G * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            return out, dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+
+        def finish1(rec):                       # first collective done -> L -> phase 2 -> second collective (async)
+            slot, b, nq, g1, w1 = rec
+            w1.wait()
+            self.g.set_option("workspace_slot", slot)
+            _lib.kth_of_gathered_device(g1.data_ptr(), G, nq, k, b["L"].data_ptr(), stream)
+            pack = b["pack"]
+            self.g.phase2_device(nq, k, b["L"].data_ptr(), pack[1].data_ptr(), b["sc"].data_ptr(), pack[0].data_ptr(), stream)
+            g2, w2 = gather_async(pack)
+            return slot, b, nq, g2, w2
+
+        def finish2(rec):                       # second collective done -> merge
+            slot, b, nq, g2, w2 = rec
+            w2.wait()
+            g2 = g2.view((G,) + tuple(b["pack"].shape))
+            _lib.topk_merge_strided_device(g2[0, 0].data_ptr(), g2[0, 1].data_ptr(), 2 * nq * k, G, nq, k,
+                                           b["oidx"].data_ptr(), b["osc"].data_ptr(), stream)
+            return b["oidx"], b["osc"]
+
+        if query_norm_none:
+            self.g.set_option("query_norm_override", _lib.NORM_NONE)
+        try:
+            stage1 = stage2 = None
+            for i, q in enumerate(batches):
+                slot, nq = i & 1, q.shape[0]
+                self.g.set_option("workspace_slot", slot)
+                b = self._buffers(nq, k, q.device, slot)
+                self.g.phase1_device(q.data_ptr(), nq, k, b["approx"].data_ptr(), stream)
+                g1, w1 = gather_async(b["approx"])
+                done = None
+                if stage1 is not None:
+                    nxt = finish1(stage1)
+                    if stage2 is not None:
+                        done = finish2(stage2)
+                    stage2 = nxt
+                stage1 = (slot, b, nq, g1, w1)
+                if done is not None:
+                    yield done
+            if stage1 is not None:
+                nxt = finish1(stage1)
+                if stage2 is not None:
+                    yield finish2(stage2)
+                yield finish2(nxt)
+            elif stage2 is not None:
+                yield finish2(stage2)
+        finally:
+            self.g.set_option("workspace_slot", 0)
             if query_norm_none:
                 self.g.set_option("query_norm_override", -1)
 

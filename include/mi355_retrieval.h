@@ -251,6 +251,8 @@ typedef struct mi_search_stats {
 int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches with hipEvents */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
 /* Tunables: "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
+ * "workspace_slot" (0 | 1: which of the handle's two per-batch workspaces the phase API uses -- phase 1 of batch i + 1 may
+ * be enqueued before phase 2 of batch i; sticky flags and statistics are one set for both),
  * "spec_max_ratio" (largest shard rows / sample rows for which the single-launch sample schedule is taken; default 160),
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
  * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "xcc_balance" (XCD shares by measured

@@ -63,12 +63,28 @@ def main():
     idx, sc = sg.search(q, k, verify=True)
     idx, sc = idx.clone(), sc.clone()
     aidx, asc, qx = sg.aqe_search(idx.t(), 3, 4.0, k)
+    aidx, asc, qx = aidx.clone(), asc.clone(), qx.clone()
+    # pipelined search (asynchronous all-gathers, two workspace slots): five different batches, answers of every one
+    qs5 = []
+    for i in range(5):
+        t = torch.empty((nq if i % 2 == 0 else max(1, nq // 3), d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(t.data_ptr(), 200 + i, 0, t.shape[0], d, stream)
+        if a.hetero:
+            t *= 0.1
+        qs5.append(t)
+    seq = []
+    for t in qs5:
+        i_, s_ = sg.search(t, k)
+        seq.append((i_.clone(), s_.clone()))
+    pipe = [(i_.clone(), s_.clone()) for i_, s_ in sg.search_stream(qs5, k)]
     torch.cuda.synchronize()
+    stream_ok = int(len(pipe) == 5 and all(torch.equal(p_[0], r_[0]) and torch.equal(p_[1], r_[1])
+                                           for p_, r_ in zip(pipe, seq)))
     flagged = sg.any_flag()
     out = dict(idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), aidx=aidx.cpu().numpy(), asc=asc.cpu().numpy(),
                qx=qx.cpu().numpy(), own_dtype=own_dtype, agreed_dtype=int(shard.get_option("image_dtype")),
                own_bounds=np.array(own_bounds), agreed_bounds=np.array(shard.norm_bounds()), flagged=int(flagged),
-               lo=lo, hi=hi)
+               lo=lo, hi=hi, stream_ok=stream_ok)
     if rank == 0:
         single = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d, norm_mode=norm)
         ridx = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -134,14 +150,19 @@ def rccl1_main(a):
             got.append((i_.clone(), s_.clone()))
         aidx, asc, qx = (t.clone() for t in sg.aqe_search(got[0][0].t(), 3, 4.0, k))   # results live in shared buffers
         vi, vs = sg.search(qs[3], k, verify=True)
+        vi, vs = vi.clone(), vs.clone()
+        pipe = [(i_.clone(), s_.clone()) for i_, s_ in sg.search_stream(qs, k)]     # asynchronous collectives, 2 slots
+        one = [(i_.clone(), s_.clone()) for i_, s_ in sg.search_stream(qs[:1], k)]
         torch.cuda.synchronize()
         flagged = sg.any_flag()
     eq = [int(torch.equal(g[0], r[0]) and torch.equal(g[1], r[1])) for g, r in zip(got, ref)]
     eq_aqe = [int(torch.equal(aidx, r_aidx)), int(torch.equal(asc, r_asc)), int(torch.equal(qx, r_qx))]
     eq_ver = int(torch.equal(vi, ref[3][0]) and torch.equal(vs, ref[3][1]))
-    ok = all(eq) and all(eq_aqe) and eq_ver
+    eq_pipe = [int(torch.equal(g[0], r[0]) and torch.equal(g[1], r[1])) for g, r in zip(pipe, ref)]
+    eq_pipe.append(int(len(pipe) == len(ref) and len(one) == 1 and torch.equal(one[0][0], ref[0][0])))
+    ok = all(eq) and all(eq_aqe) and eq_ver and all(eq_pipe)
     np.savez(a.out + ".0.npz", ok=int(ok), flagged=int(flagged), backend=dist.get_backend(), eq=np.array(eq),
-             eq_aqe=np.array(eq_aqe), eq_ver=eq_ver,
+             eq_aqe=np.array(eq_aqe), eq_ver=eq_ver, eq_pipe=np.array(eq_pipe),
              mism=np.array([int((g[0] != r[0]).sum().item()) for g, r in zip(got, ref)]))
     dist.barrier()
     dist.destroy_process_group()

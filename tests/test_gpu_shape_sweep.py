@@ -276,3 +276,54 @@ def test_merge_of_long_lists(lib, nshards, k):
     assert not any(flags), flags
     assert np.array_equal(oi, ref_idx)
     assert np.array_equal(os_, ref_sc)
+
+
+def test_two_workspace_slots_keep_two_batches_apart(lib):
+    """Option "workspace_slot": phase 1 of a second batch may run before phase 2 of the first (the pipelined sharded search
+    does exactly that while a batch waits for its collective).  Interleaved on one shard: both answers equal the
+    sequential ones; flags and statistics stay one set."""
+    import torch
+    from isehr_amd._lib import Gallery
+    rng = np.random.default_rng(9)
+    n, d, k = 50000, 96, 64
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    qa = rng.standard_normal((300, d)).astype(np.float32)
+    qb = rng.standard_normal((77, d)).astype(np.float32)
+    G = Gallery.from_host(g)
+    try:
+        ra, rb = G.search(qa, k), G.search(qb, k)
+        dev = torch.device("cuda", 0)
+        stream = torch.cuda.current_stream().cuda_stream
+        ta, tb = torch.from_numpy(qa).to(dev), torch.from_numpy(qb).to(dev)
+
+        def bufs(nq):
+            return dict(approx=torch.empty((nq, k), dtype=torch.float32, device=dev),
+                        L=torch.empty((nq,), dtype=torch.float32, device=dev),
+                        idx=torch.empty((nq, k), dtype=torch.int64, device=dev),
+                        sc=torch.empty((nq, k), dtype=torch.float32, device=dev),
+                        sc64=torch.empty((nq, k), dtype=torch.float64, device=dev))
+        A, B = bufs(300), bufs(77)
+        G.set_option("workspace_slot", 0)
+        G.phase1_device(ta.data_ptr(), 300, k, A["approx"].data_ptr(), stream)
+        G.set_option("workspace_slot", 1)
+        G.phase1_device(tb.data_ptr(), 77, k, B["approx"].data_ptr(), stream)       # before phase 2 of the first batch
+        for slot, X, nq in ((0, A, 300), (1, B, 77)):
+            G.set_option("workspace_slot", slot)
+            lib.kth_of_gathered_device(X["approx"].data_ptr(), 1, nq, k, X["L"].data_ptr(), stream)
+            G.phase2_device(nq, k, X["L"].data_ptr(), X["idx"].data_ptr(), X["sc"].data_ptr(), X["sc64"].data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert G.get_option("workspace_slot") == 1
+        G.set_option("workspace_slot", 0)
+        assert G.flags() == 0
+        assert np.array_equal(A["idx"].cpu().numpy(), ra[0]) and np.array_equal(A["sc"].cpu().numpy(), ra[1])
+        assert np.array_equal(B["idx"].cpu().numpy(), rb[0]) and np.array_equal(B["sc"].cpu().numpy(), rb[1])
+        # a larger K re-allocates the active workspace and drops the parked one: both slots keep working
+        G.set_option("workspace_slot", 1)
+        i2, s2, _ = G.search(qb, 200)
+        G.set_option("workspace_slot", 0)
+        i3, s3, _ = G.search(qb, 200)
+        assert np.array_equal(i2, i3) and np.array_equal(s2, s3)
+        st = G.status()
+        assert st["overflow_batches"] == 0 and st["queries"] > 0
+    finally:
+        G.close()

@@ -36,6 +36,7 @@ def test_sharded_ranks_equal_single_shard(world, tmp_path):
         assert np.array_equal(z["idx"], z0["ref_idx"]) and np.array_equal(z["sc"], z0["ref_sc"])
         assert np.array_equal(z["aidx"], z0["ref_aidx"]) and np.array_equal(z["asc"], z0["ref_asc"])
         assert np.abs(z["qx"].astype(np.float64) - z0["ref_qx"]).max() < 1e-7        # f32 rounding of the f64 query
+        assert int(z["stream_ok"]) == 1                      # the pipelined search gives the answers of the sequential one
     assert res[-1]["hi"] == 60000 and all(int(a["hi"]) == int(b["lo"]) for a, b in zip(res, res[1:]))
 
 
@@ -57,6 +58,7 @@ def test_sharded_ranks_with_unequal_norm_bounds(tmp_path):
     for z in res:
         assert np.array_equal(z["idx"], z0["ref_idx"]) and np.array_equal(z["sc"], z0["ref_sc"])
         assert np.array_equal(z["aidx"], z0["ref_aidx"]) and np.array_equal(z["asc"], z0["ref_asc"])
+        assert int(z["stream_ok"]) == 1
 
 
 def test_node_sharded_diffusion_equals_single_process(tmp_path):
@@ -84,4 +86,4 @@ def test_protocol_over_rccl_with_one_rank(tmp_path):
     res = _run(1, tmp_path, ("--rccl1",))
     z = res[0]
     assert str(z["backend"]) == os.environ.get("ISEHR_RCCL1_BACKEND", "nccl")
-    assert int(z["ok"]) == 1 and int(z["flagged"]) == 0, (z["eq"], z["eq_aqe"], z["eq_ver"], z["mism"])
+    assert int(z["ok"]) == 1 and int(z["flagged"]) == 0, (z["eq"], z["eq_aqe"], z["eq_ver"], z["eq_pipe"], z["mism"])
