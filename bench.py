@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--force-protocol", action="store_true",
                     help="one GPU: run the sharded two-phase protocol with its RCCL collectives on a group of ONE rank "
                          "(what a rank of a multi-GPU run executes, collectives included); diagnostic, not the headline")
+    ap.add_argument("--layout", default="auto",
+                    help="N GPUs as QGxRS: QG query groups (each answers 1/QG of every batch, no exchange between groups) times "
+                         "RS row shards of the gallery per group (two-phase protocol with all-gathers inside the group); "
+                         "isehr_amd.sharded.job_layout.  'auto': 2 x N/2 for an even N and batches of >= 512 queries, else "
+                         "1 x N.  Measured per-rank steps of every layout: scripts/layout_model.sh")
     ap.add_argument("--pipeline", action="store_true",
                     help="sharded runs (--gpus N > 1 or --force-protocol): ShardedGallery.search_stream -- asynchronous "
                          "all-gathers, three batches in flight -- instead of one synchronous search per step")
@@ -111,7 +116,7 @@ def main():
     import torch.distributed as dist
     import isehr_amd  # noqa: F401
     from isehr_amd import _lib
-    from isehr_amd.sharded import ShardedGallery, shard_bounds
+    from isehr_amd.sharded import ShardedGallery, shard_bounds, job_layout, layout_groups
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +140,17 @@ def main():
     dev = torch.device("cuda", dev_index)
     n_total = args.rows or WORKLOADS[args.workload][0]
     d, nq, k = args.dim, args.queries, args.topk
-    lo, hi = shard_bounds(n_total, world, rank)
+    # ---- layout of the job: gq query groups x gs row shards (gq * gs = world).  Every batch is split into gq slices of
+    # queries; the gs ranks of a group shard the gallery rows among themselves and run the two-phase protocol inside the
+    # group.  Groups never exchange anything: a query's answer lives with the group that computed it.
+    try:
+        gq, gs, qgroup, shard = job_layout(world, rank, nq, args.layout)
+    except ValueError as e:
+        raise SystemExit(str(e))
+    group = layout_groups(gq, gs)[qgroup] if world > 1 else None
+    nq_job, nq = nq, nq // gq                     # nq: queries THIS rank answers per step
+    q_lo = qgroup * nq
+    lo, hi = shard_bounds(n_total, gs, shard)
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- synthetic shard, generated on device (rows are a pure function of (seed, row))
@@ -153,13 +168,13 @@ def main():
     for opt in args.option:
         name, val = opt.split("=")
         gal.set_option(name, float(val))
-    sg = ShardedGallery(gal, force_protocol=args.force_protocol)
+    sg = ShardedGallery(gal, group=group, force_protocol=args.force_protocol)
 
     # a small pool of query batches (seeded), cycled over the steps
     pool = []
     for i in range(4):
-        qb = torch.empty((nq, d), dtype=torch.float32, device=dev)
-        _lib.synth_fill_device(qb.data_ptr(), args.seed + 1 + i, 0, nq, d, stream)
+        qb = torch.empty((nq, d), dtype=torch.float32, device=dev)        # this query group's slice of job batch i
+        _lib.synth_fill_device(qb.data_ptr(), args.seed + 1 + i, q_lo, nq, d, stream)
         pool.append(qb)
     torch.cuda.synchronize()
 
@@ -182,7 +197,7 @@ def main():
             idx_, sc_, one_step.last_queries = sg.aqe_search(idx_.t(), 3, 4.0, k, join=not pipelined)
         return idx_, sc_
 
-    use_stream = args.pipeline and (world > 1 or args.force_protocol) and not args.with_aqe
+    use_stream = args.pipeline and sg._protocol and not args.with_aqe
 
     def run_steps(count):
         """`count` steps; returns the results of the last one"""
@@ -282,17 +297,20 @@ def main():
             roof["peak_at_clock"] = MFMA_BF16_PEAK_TFLOPS * clock / 2400.0
             roof["frac_at_clock"] = achieved / roof["peak_at_clock"] if achieved else None
         out = {
-            "metric": "queries/sec", "value": nq * args.steps / elapsed, "unit": "queries/s",
+            "metric": "queries/sec", "value": nq_job * args.steps / elapsed, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.image_dtype,
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
-                       "gallery_rows": n_total, "dim": d, "queries_per_step": nq, "topk": k,
-                       "parallelism": "row-shard x%d" % world + (" (two-phase protocol over RCCL forced on one rank)"
-                                                                  if args.force_protocol and world == 1 else ""),
+                       "gallery_rows": n_total, "dim": d, "queries_per_step": nq_job, "topk": k,
+                       "parallelism": ("row-shard x%d" % world if gq == 1 else
+                                       "%d query groups (%d queries of every batch each, no exchange between groups) x %d "
+                                       "row shards per group" % (gq, nq, gs)) +
+                                      (" (two-phase protocol over RCCL forced on one rank)"
+                                       if args.force_protocol and world == 1 else ""),
                        "alpha_qe": bool(args.with_aqe),
                        "collectives": ("asynchronous, three batches in flight (search_stream)" if use_stream else
-                                       "synchronous per batch") if (world > 1 or args.force_protocol) else None,
+                                       "synchronous per batch") if sg._protocol else None,
                        "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "
                                 "the timed region" % ("scoring launch" if args.async_tail == 1 else
                                                       "query ingest + bootstrap (not the scoring launch)"))

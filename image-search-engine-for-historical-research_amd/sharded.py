@@ -25,6 +25,32 @@ def shard_bounds(n, world, rank):
     return lo, min(n, lo + per)
 
 
+def job_layout(world, rank, nq, layout="auto"):
+    """A strong-scaling job on `world` GPUs as gq query groups x gs row shards (gq * gs = world): every batch of nq queries
+    is cut into gq slices, the gs ranks of a group shard the gallery rows among themselves (two-phase protocol with
+    all-gathers INSIDE the group), and groups never exchange anything -- a query's answer lives with the group that
+    computed it.  Fewer ranks per collective and per-query kernels of nq / gq queries per rank; each rank streams a gallery
+    shard gq times larger, which 288 GB per GPU has room for.  'auto' = 2 x world/2 for an even world and batches of >= 512
+    queries (measured per-rank steps of every layout of 2, 4, 8 GPUs: scripts/layout_model.sh), else 1 x world.
+    Returns (gq, gs, query group of `rank`, row shard of `rank` inside its group)."""
+    if layout == "auto":
+        gq = 2 if (world % 2 == 0 and nq >= 512 and nq % 2 == 0) else 1
+    else:
+        a, b = (int(v) for v in str(layout).lower().split("x"))
+        if a * b != world or nq % a:
+            raise ValueError("layout %s does not fit %d ranks / %d queries" % (layout, world, nq))
+        gq = a
+    gs = world // gq
+    return gq, gs, rank // gs, rank % gs
+
+
+def layout_groups(gq, gs):
+    """The process groups of a layout: group g = ranks [g * gs, (g + 1) * gs).  Every rank must call this (collective
+    creation); returns the list of all gq groups."""
+    import torch.distributed as dist
+    return [dist.new_group(list(range(g * gs, (g + 1) * gs))) for g in range(gq)]
+
+
 def all_gather_stacked(t, group=None):
     """[...] tensor -> [world, ...] tensor, same on every rank (RCCL on GPU, gloo on CPU)."""
     import torch

@@ -31,6 +31,7 @@ python -m pytest tests/test_gpu_diffusion.py -q -s -k reference_size > $o/${tag}
 python scripts/ladder_probe.py > $o/${tag}_ladder_probe.txt 2> /dev/null || true
 (for g in 2 4 8; do python scripts/shard_step_model.py $g 1005994 rescore_grid_x=$((96 / g)) 2> /dev/null | tail -2; done) > $o/${tag}_shard_model.txt || true
 (for f in "" "--force-protocol"; do python bench.py --no-cpu-baseline --rows 125750 $f 2> /dev/null | tail -1 | cut -c1-700; done) > $o/${tag}_protocol_rccl1.txt || true
+bash scripts/layout_model.sh > $o/${tag}_layout_model.txt 2> /dev/null || true
 echo "scripts done"
 # 4. kernel A/B driver and MFMA probe (C++, no torch)
 bash scripts/kbench_build.sh > /dev/null 2>&1 || true    # the driver shares struct layouts with the library: never run a stale one
@@ -39,4 +40,5 @@ bash scripts/kbench_build.sh > /dev/null 2>&1 || true    # the driver shares str
 # 5. multi-rank rehearsal of bench.py (ranks share the GPU, gloo)
 bash scripts/rehearse_sharded.sh 2 > $o/${tag}_rehearse2.txt 2>&1 || true
 bash scripts/rehearse_sharded.sh 4 > $o/${tag}_rehearse4.txt 2>&1 || true
+bash scripts/rehearse_sharded.sh 4 --layout 1x4 --pipeline > $o/${tag}_rehearse4_rows_pipelined.txt 2>&1 || true
 echo "all done"

@@ -24,6 +24,9 @@ def main():
                          "the large-row shards fall back to a bf16 image on their own")
     ap.add_argument("--diffusion", action="store_true",
                     help="node-sharded offline diffusion (isehr_amd.diffusion.Diffusion under torch.distributed) instead")
+    ap.add_argument("--layout", default="",
+                    help="QGxRS: the job as query groups x row shards (isehr_amd.sharded.job_layout); every rank answers its "
+                         "group's slice of the queries against its row shard")
     ap.add_argument("--rccl1", action="store_true",
                     help="ONE rank over RCCL (backend nccl): the two-phase protocol with its real collectives on a one-GPU box")
     a = ap.parse_args()
@@ -31,6 +34,8 @@ def main():
         return diffusion_main(a)
     if a.rccl1:
         return rccl1_main(a)
+    if a.layout:
+        return layout_main(a)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -101,6 +106,55 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     shard.close()
+
+
+def layout_main(a):
+    """gq query groups x gs row shards: the rank's answers for ITS slice of the batch; rank 0 adds the single-GPU answers
+    of the whole batch, so the test can check every group's slice for completeness (not just self-consistency)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import isehr_amd  # noqa: F401
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery, shard_bounds, job_layout, layout_groups
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, d, nq, k = a.rows, a.dim, a.queries, a.topk
+    gq, gs, qgroup, shard = job_layout(world, rank, nq, a.layout)
+    group = layout_groups(gq, gs)[qgroup]
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), 77, 0, n, d, stream)
+    q = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(q.data_ptr(), 78, 0, nq, d, stream)
+    torch.cuda.synchronize()
+    lo, hi = shard_bounds(n, gs, shard)
+    g = _lib.Gallery.from_device_ptr(raw[lo:hi].data_ptr(), hi - lo, d, row_offset=lo)
+    sg = ShardedGallery(g, group=group)
+    per = nq // gq
+    mine = q[qgroup * per:(qgroup + 1) * per].contiguous()
+    idx, sc = sg.search(mine, k, verify=True)
+    idx, sc = idx.clone(), sc.clone()
+    pipe = [(i_.clone(), s_.clone()) for i_, s_ in sg.search_stream([mine, mine[: max(1, per // 2)]], k)]
+    torch.cuda.synchronize()
+    out = dict(idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), qgroup=qgroup, shard=shard, gq=gq, gs=gs, lo=lo, hi=hi,
+               group_size=sg.world, flagged=int(sg.any_flag()),
+               stream_ok=int(torch.equal(pipe[0][0], idx) and torch.equal(pipe[0][1], sc) and
+                             torch.equal(pipe[1][0], idx[: max(1, per // 2)])))
+    if rank == 0:
+        single = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+        ridx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        rsc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        single.search_device(q.data_ptr(), nq, k, ridx.data_ptr(), rsc.data_ptr(), None, stream)
+        torch.cuda.synchronize()
+        out.update(ref_idx=ridx.cpu().numpy(), ref_sc=rsc.cpu().numpy())
+        single.close()
+    np.savez(a.out + ".%d.npz" % rank, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    g.close()
 
 
 def rccl1_main(a):

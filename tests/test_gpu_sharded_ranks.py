@@ -87,3 +87,25 @@ def test_protocol_over_rccl_with_one_rank(tmp_path):
     z = res[0]
     assert str(z["backend"]) == os.environ.get("ISEHR_RCCL1_BACKEND", "nccl")
     assert int(z["ok"]) == 1 and int(z["flagged"]) == 0, (z["eq"], z["eq_aqe"], z["eq_ver"], z["eq_pipe"], z["mism"])
+
+
+@pytest.mark.parametrize("world,layout", [(4, "2x2"), (4, "4x1"), (2, "2x1"), (4, "auto")])
+def test_query_groups_times_row_shards(world, layout, tmp_path):
+    """The 2-D layout of bench.py --gpus N (isehr_amd.sharded.job_layout): query groups answer disjoint slices of the batch,
+    the ranks of a group shard the gallery and exchange inside the group only.  Every rank's slice must be THE single-GPU
+    answer of those queries (completeness, not just self-consistency), synchronous and pipelined."""
+    res = _run(world, tmp_path, ("--layout", layout, "--queries", "640", "--rows", "90000", "--dim", "128"))
+    z0 = res[0]
+    gq, gs = int(z0["gq"]), int(z0["gs"])
+    assert gq * gs == world and (layout == "auto" or layout == "%dx%d" % (gq, gs))
+    if layout == "auto":
+        assert (gq, gs) == (2, 2)
+    per = 640 // gq
+    seen = set()
+    for z in res:
+        qg = int(z["qgroup"])
+        assert int(z["group_size"]) == gs and int(z["flagged"]) == 0 and int(z["stream_ok"]) == 1
+        assert np.array_equal(z["idx"], z0["ref_idx"][qg * per:(qg + 1) * per])
+        assert np.array_equal(z["sc"], z0["ref_sc"][qg * per:(qg + 1) * per])
+        seen.add((qg, int(z["shard"])))
+    assert seen == {(a, b) for a in range(gq) for b in range(gs)}

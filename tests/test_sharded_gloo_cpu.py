@@ -79,3 +79,24 @@ def test_two_rank_exchange_matches_global_topk():
         p.join(100)
         assert p.exitcode == 0
     assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_job_layout_covers_every_query_and_row_once():
+    """isehr_amd.sharded.job_layout: for every world size and layout the (query group, row shard) pairs of the ranks tile
+    the job exactly once; 'auto' is 2 x N/2 for an even N and batches of >= 512 queries."""
+    from isehr_amd.sharded import job_layout, shard_bounds
+    for world in (1, 2, 3, 4, 6, 8):
+        for layout in ["auto", "1x%d" % world] + (["2x%d" % (world // 2)] if world % 2 == 0 else []):
+            nq, n = 1024, 1005994
+            cells = [job_layout(world, r, nq, layout) for r in range(world)]
+            gq, gs = cells[0][0], cells[0][1]
+            assert gq * gs == world and all(c[:2] == (gq, gs) for c in cells)
+            assert sorted((c[2], c[3]) for c in cells) == [(a, b) for a in range(gq) for b in range(gs)]
+            if layout == "auto":
+                assert gq == (2 if world % 2 == 0 else 1)
+            covered = sum(shard_bounds(n, gs, b)[1] - shard_bounds(n, gs, b)[0] for b in range(gs))
+            assert covered == n and nq % gq == 0
+    assert job_layout(8, 5, 100, "auto")[:2] == (1, 8)          # small batches: row shards only
+    import pytest
+    with pytest.raises(ValueError):
+        job_layout(4, 0, 1024, "3x1")
