@@ -112,6 +112,12 @@ def cpu_baseline(gallery, q_host, n_total, args):
 
 def main():
     args = parse()
+    # stdout carries the ONE JSON line and nothing else: libraries write banners to file descriptor 1 (RCCL prints its
+    # version block there when a communicator is created, on every rank), so fd 1 is pointed at stderr for the whole run
+    # and the JSON line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import isehr_amd  # noqa: F401
@@ -327,7 +333,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gal, pool[(args.steps - 1) % len(pool)].cpu().numpy(), n_total, args)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or (args.force_protocol and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
