@@ -78,7 +78,9 @@ def _check(lib, g, q, k, image_f16, options=()):
 
 
 def _draw_cases():
-    rng = np.random.default_rng(20261004)
+    # ISEHR_SWEEP_SEED draws another set of shapes (wider fuzzing by hand; the default set is what CI runs)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("ISEHR_SWEEP_SEED", "20261004")))
     kinds = ["uniform", "clustered", "few_big_clusters", "duplicates"]
     cases = []
     for i in range(24):
@@ -97,7 +99,8 @@ def _draw_cases():
     c[0], c[1], c[2], c[3], c[4], c[5], "f16" if c[6] else "bf16"))
 def test_shape_sweep_against_oracle(lib, case):
     i, kind, n, d, nq, k, f16 = case
-    rng = np.random.default_rng(1000 + i)
+    import os
+    rng = np.random.default_rng(1000 + i + 7919 * (int(os.environ.get("ISEHR_SWEEP_SEED", "20261004")) % 1000))
     g, q = _case(rng, kind, n, d, nq, k)
     _check(lib, g, q, k, f16)
 
