@@ -245,7 +245,9 @@ static void launch_stream_mode(const ScoreArgs& a, bool first, hipStream_t strea
 bool stream_bootstrap_applies(const ScoreArgs& a) { return a.small_batch_kernel && a.debug == 0; }
 
 void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream) {
-  if (a.nq <= 64) a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
+  // bootstrap launches are one workgroup per (sample tile, group of NQB * 16 queries): with <= 512 queries the narrower
+  // group fills the 256 CUs (32 tiles x 8 groups) where the wider one would leave half of them idle for a whole tile time
+  if (a.nq <= 64 || (first && a.nq <= 512)) a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
   else a.img_f16 ? launch_stream_mode<8, true>(a, first, stream) : launch_stream_mode<8, false>(a, first, stream);
 }
 
