@@ -4,16 +4,26 @@
 Workload (BASELINE.json configs[2]): synthetic rOxford5k + 1M distractors gallery,
 N = 1,005,994 x D = 2048 f32 descriptors (seeded counter-based generator, L2-normalised by the
 ingest kernel), one step = one batch of 1024 queries -> exact top-100 per query.  Inputs are
-resident in HBM when the timed region starts.  With --gpus N the SAME gallery is row-sharded over N
-ranks (strong scaling; one process per GPU, RCCL all-gathers of the per-shard top-K).
+resident in HBM when the timed region starts.
+
+`--gpus N` is the number of ranks of the job, one process per GPU over RCCL.  Started bare
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) this file starts the N rank processes
+itself -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD
+process, before torch is imported or the GPU touched -- relays their output and exits with their
+code.  Started by a launcher (WORLD_SIZE set) it is one rank; WORLD_SIZE != --gpus is an error.
+The SAME gallery is sharded over the ranks (strong scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task description): metric/value/unit, `roofline`
-(dominant kernel = the bf16 MFMA scoring kernel, HIP-event timed inside the timed region) and
-`cpu_baseline` (the oracle's matching_L2 restatement timed on a bounded sample on the host).
+(dominant kernel = the 16-bit MFMA scoring kernel, HIP-event timed inside the timed region),
+`cpu_baseline` (the oracle's matching_L2 restatement timed on a bounded sample on the host) and
+`scale_10m`: BASELINE configs[3] -- a synthetic 10,000,000 x 2048 gallery with a bf16 image,
+row-sharded 1 x N over the same ranks with the RCCL all-gathers of the per-shard top-K -- measured
+in the same process after the headline (10 steps).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +43,9 @@ HBM_PEAK_GBS = 8000.0
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of the job (one per GPU).  Without WORLD_SIZE in the environment and N > 1 this process "
+                         "starts the N ranks itself (torch.distributed.run as a child process)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="roxford5k+1m", choices=sorted(WORKLOADS))
@@ -66,14 +78,48 @@ def parse():
     ap.add_argument("--pipeline", action="store_true",
                     help="sharded runs (--gpus N > 1 or --force-protocol): ShardedGallery.search_stream -- asynchronous "
                          "all-gathers, three batches in flight -- instead of one synchronous search per step")
+    ap.add_argument("--scale-10m", default="auto", choices=["auto", "on", "off"],
+                    help="secondary block `scale_10m` (BASELINE configs[3]: 10 M x 2048 rows, bf16 image, row-sharded 1 x N "
+                         "over the job's ranks), measured after the headline.  auto: on for the default workload without "
+                         "--rows / --queries / --dim overrides and without diagnostic modes")
+    ap.add_argument("--scale-10m-steps", type=int, default=10)
+    ap.add_argument("--scale-10m-rows", type=int, default=10000000)
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) as a CHILD process group
+    -- this process has not imported torch nor touched the GPU, and it does not exec -- pass their output through (rank 0
+    prints the one JSON line) and return their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def cpu_baseline(gallery, q_host, n_total, args):
     """Oracle (numpy restatement of matching_L2, src/utils/nnsearch.py:687-706) on a bounded sample:
     the first `cpu_sample_rows` gallery rows and `cpu_sample_queries` queries; its cost is linear in
-    the number of gallery rows, so queries/s at the full gallery = measured * sample_rows / N."""
+    the number of gallery rows, so queries/s at the full gallery = measured * sample_rows / N.
+    Beside it the BLAS exhaustive baseline -- sgemm + partial selection, the stand-in for
+    faiss-CPU IndexFlatIP -- at Q in {1, 70, 1024}, at numpy's full BLAS width and on one thread."""
     import numpy as np
     import oracle
     ns = min(args.cpu_sample_rows, gallery.n)
@@ -87,91 +133,134 @@ def cpu_baseline(gallery, q_host, n_total, args):
         import threadpoolctl
         blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
-        blas_threads = None
-    # SURVEY.md 8d's second CPU baseline: the strongest fair exhaustive CPU path (multi-threaded sgemm + partial
-    # selection = what faiss-CPU IndexFlatIP does; faiss itself is not installable offline), at the BLAS width numpy
-    # has on this host, on the same row sample with more queries (a GEMM needs a batch to be fair to the CPU)
-    nqb = min(1024, q_host.shape[0])
+        threadpoolctl, blas_threads = None, None
     gn = g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30)
-    qn = q_host[:nqb] / np.maximum(np.linalg.norm(q_host[:nqb], axis=1, keepdims=True), 1e-30)
-    oracle.knn_flat_ip_blas(gn[:4096], qn, args.topk)          # BLAS warm-up
-    t0 = time.time()
-    oracle.knn_flat_ip_blas(gn, qn, args.topk)
-    dtb = time.time() - t0
-    blas = {"value": nqb / dtb * ns / n_total, "unit": "queries/s", "cores": blas_threads,
+    qall = q_host / np.maximum(np.linalg.norm(q_host, axis=1, keepdims=True), 1e-30)
+    oracle.knn_flat_ip_blas(gn[:4096], qall, args.topk)          # BLAS warm-up
+
+    def blas_point(nqb, rows, threads):
+        nqb = min(nqb, qall.shape[0])
+        qn = np.ascontiguousarray(qall[:nqb])
+        gs = gn[:rows]
+        reps = 3 if nqb <= 128 else 1
+        best = None
+        for _ in range(reps):
+            t0_ = time.time()
+            if threads is not None and threadpoolctl is not None:
+                with threadpoolctl.threadpool_limits(limits=threads):
+                    oracle.knn_flat_ip_blas(gs, qn, args.topk)
+            else:
+                oracle.knn_flat_ip_blas(gs, qn, args.topk)
+            dt_ = time.time() - t0_
+            best = dt_ if best is None else min(best, dt_)
+        return {"queries": nqb, "threads": threads if threads is not None else blas_threads, "sample_rows": int(rows),
+                "seconds": round(best, 4), "value": nqb / best * rows / n_total, "unit": "queries/s"}
+
+    points = [blas_point(1024, ns, None), blas_point(70, ns, None), blas_point(1, ns, None)]
+    if threadpoolctl is not None:
+        # one thread: a quarter of the rows for the 1024-query GEMM keeps the leg at a few seconds
+        points += [blas_point(1024, max(4096, ns // 4), 1), blas_point(70, ns, 1), blas_point(1, ns, 1)]
+    full = points[0]
+    blas = {"value": full["value"], "unit": "queries/s", "cores": blas_threads,
             "sample": "oracle.knn_flat_ip_blas (numpy sgemm + argpartition, f32) on the first %d gallery rows x %d "
-                      "queries, K=%d: %.2f s; scaled by rows" % (ns, nqb, args.topk, dtb)}
+                      "queries, K=%d: %.2f s; scaled by rows" % (ns, full["queries"], args.topk, full["seconds"]),
+            "points": points}
     return {
         "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port", "blas": blas,
         "sample": "oracle.matching_l2 (numpy, f32, single thread like the reference) on the first %d of %d gallery "
                   "rows x %d queries, K=%d: %.2f s; scaled by rows (cost is linear in N)" % (ns, n_total, nqs,
                                                                                             args.topk, dt),
-        "host_cpus": os.cpu_count(), "blas_threads": blas_threads, "numpy": np.__version__,
+        "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "blas_threads": blas_threads, "numpy": np.__version__,
     }
 
 
-def main():
-    args = parse()
-    # stdout carries the ONE JSON line and nothing else: libraries write banners to file descriptor 1 (RCCL prints its
-    # version block there when a communicator is created, on every rank), so fd 1 is pointed at stderr for the whole run
-    # and the JSON line goes to the saved descriptor at the end.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+class Job:
+    """The process-wide state of one rank: device, process group, stream."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # ISEHR_DIST_BACKEND=gloo + ISEHR_SHARE_GPU=1: rehearsal of the multi-rank flow with all ranks on one GPU
+        # (RCCL refuses two ranks on one device); the real run is one rank per GPU over RCCL.
+        self.backend = os.environ.get("ISEHR_DIST_BACKEND", "nccl")
+        self.dev_index = 0 if os.environ.get("ISEHR_SHARE_GPU") == "1" else local_rank
+        torch.cuda.set_device(self.dev_index)
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+            else:
+                dist.init_process_group(self.backend)
+        if self.world == 1 and args.force_protocol:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29571")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", self.dev_index))
+        self.dev = torch.device("cuda", self.dev_index)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        # what the communicator itself says (the answer to "did RCCL see N ranks")
+        self.comm_ranks = dist.get_world_size() if dist.is_initialized() else 1
+        self.comm_backend = dist.get_backend() if dist.is_initialized() else None
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_aqe=False, async_tail=0, pipeline=False,
+                 options=(), check=True, warm_ingest=False, keep=False):
+    """Ingests this rank's shard of an n_total-row synthetic gallery and times `steps` steps of nq_job queries.
+    Returns a dict of measurements (+ the gallery and the last query batch when keep=True)."""
+    import numpy as np
     import torch
     import torch.distributed as dist
-    import isehr_amd  # noqa: F401
     from isehr_amd import _lib
     from isehr_amd.sharded import ShardedGallery, shard_bounds, job_layout, layout_groups
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # ISEHR_DIST_BACKEND=gloo + ISEHR_SHARE_GPU=1: rehearsal of the multi-rank flow with all ranks on one GPU
-    # (RCCL refuses two ranks on one device); the real run is one rank per GPU over RCCL.
-    backend = os.environ.get("ISEHR_DIST_BACKEND", "nccl")
-    dev_index = 0 if os.environ.get("ISEHR_SHARE_GPU") == "1" else local_rank
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
-    if world == 1 and args.force_protocol:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29571")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
-    dev = torch.device("cuda", dev_index)
-    n_total = args.rows or WORKLOADS[args.workload][0]
-    d, nq, k = args.dim, args.queries, args.topk
+    args, world, rank, dev, stream = job.args, job.world, job.rank, job.dev, job.stream
+    d, k = args.dim, args.topk
     # ---- layout of the job: gq query groups x gs row shards (gq * gs = world).  Every batch is split into gq slices of
     # queries; the gs ranks of a group shard the gallery rows among themselves and run the two-phase protocol inside the
     # group.  Groups never exchange anything: a query's answer lives with the group that computed it.
     try:
-        gq, gs, qgroup, shard = job_layout(world, rank, nq, args.layout)
+        gq, gs, qgroup, shard = job_layout(world, rank, nq_job, layout)
     except ValueError as e:
         raise SystemExit(str(e))
     group = layout_groups(gq, gs)[qgroup] if world > 1 else None
-    nq_job, nq = nq, nq // gq                     # nq: queries THIS rank answers per step
+    nq = nq_job // gq                             # queries THIS rank answers per step
     q_lo = qgroup * nq
     lo, hi = shard_bounds(n_total, gs, shard)
-    stream = torch.cuda.current_stream().cuda_stream
 
     # ---- synthetic shard, generated on device (rows are a pure function of (seed, row))
     raw = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
     _lib.synth_fill_device(raw.data_ptr(), args.seed, lo, hi - lo, d, stream)
     torch.cuda.synchronize()
-    _lib.set_global_option("image_dtype", 1 if args.image_dtype == "f16" else 0)
+    _lib.set_global_option("image_dtype", 1 if image_dtype == "f16" else 0)
     t0 = time.time()
-    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=dev_index,
+    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
                                        row_offset=lo)
     torch.cuda.synchronize()
-    ingest_s = time.time() - t0
+    ingest_first_s = time.time() - t0
+    ingest_s = ingest_first_s
+    if warm_ingest:
+        # the first ingest of a process also initialises the library (code objects, workspaces): the reference-style
+        # per-call normalisation (matching_L2 normalises the gallery inside its timer, src/utils/nnsearch.py:688-705) is
+        # what a SECOND ingest of the same rows costs
+        t0 = time.time()
+        g2 = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
+                                          row_offset=lo)
+        torch.cuda.synchronize()
+        ingest_s = time.time() - t0
+        g2.close()
     del raw
     torch.cuda.empty_cache()
-    for opt in args.option:
+    for opt in options:
         name, val = opt.split("=")
         gal.set_option(name, float(val))
     sg = ShardedGallery(gal, group=group, force_protocol=args.force_protocol)
@@ -184,26 +273,22 @@ def main():
         pool.append(qb)
     torch.cuda.synchronize()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # single GPU: the exact re-score + sort of a batch runs on the handle's second stream beside the scoring launch of the
     # next batch (mi_set_option "async_tail"); every batch's results are complete after gal.join(), inside the timed region
-    pipelined = world == 1 and args.async_tail > 0
+    pipelined = world == 1 and async_tail > 0
     if pipelined:
-        gal.set_option("async_tail", args.async_tail)
+        gal.set_option("async_tail", async_tail)
+    last = {}
 
     def one_step(qb):
-        idx_, sc_ = sg.search(qb, k, join=not pipelined or args.with_aqe)
-        one_step.last_queries = qb
-        if args.with_aqe:
+        idx_, sc_ = sg.search(qb, k, join=not pipelined or with_aqe)
+        last["q"] = qb
+        if with_aqe:
             # ranks[K,Q] view of the [Q,K] result, like `ranks = match_idx.T` (src/test_rOP1m.py:157) -> QGE (N >= 120000)
-            idx_, sc_, one_step.last_queries = sg.aqe_search(idx_.t(), 3, 4.0, k, join=not pipelined)
+            idx_, sc_, last["q"] = sg.aqe_search(idx_.t(), 3, 4.0, k, join=not pipelined)
         return idx_, sc_
 
-    use_stream = args.pipeline and sg._protocol and not args.with_aqe
+    use_stream = pipeline and sg._protocol and not with_aqe
 
     def run_steps(count):
         """`count` steps; returns the results of the last one"""
@@ -215,22 +300,22 @@ def main():
         out_ = None
         for out_ in sg.search_stream((pool[i % len(pool)] for i in range(count)), k):
             pass
-        one_step.last_queries = pool[(count - 1) % len(pool)]
+        last["q"] = pool[(count - 1) % len(pool)]
         return out_
 
-    if args.warmup:
-        run_steps(args.warmup)
+    if warmup:
+        run_steps(warmup)
     if pipelined:
         gal.join(stream)
-    barrier()
+    job.barrier()
     gal.status(reset=True)
     gal.profile(True)
-    barrier()
+    job.barrier()
     t0 = time.perf_counter()
-    idx, sc = run_steps(args.steps)
+    idx, sc = run_steps(steps)
     if pipelined:
         gal.join(stream)
-    barrier()
+    job.barrier()
     elapsed = time.perf_counter() - t0
     gal.profile(False)
     st = gal.status(reset=True)
@@ -245,17 +330,17 @@ def main():
         overflow = st["overflow_batches"]
 
     # result sanity on the last batch (size-independent properties; the oracle cannot run at this size)
-    sc_h = sc.cpu().numpy()
-    idx_h = idx.cpu().numpy()
-    import numpy as np
-    if not args.diagnostic:
+    worst = None
+    if check:
+        sc_h = sc.cpu().numpy()
+        idx_h = idx.cpu().numpy()
         assert (np.diff(sc_h, axis=1) <= 0).all(), "scores not sorted"
         assert all(len(set(r)) == k for r in idx_h), "duplicate indices"
         assert idx_h.min() >= 0 and idx_h.max() < n_total
         # the returned scores are the exact cosines: recompute those of 16 queries in float64 from the stored rows
-        # (each rank checks the rows of its own shard); with --with-aqe the last search ran on the expanded queries
-        q_last = one_step.last_queries.double()
-        if not args.with_aqe:
+        # (each rank checks the rows of its own shard); with alpha-QE the last search ran on the expanded queries
+        q_last = last["q"].double()
+        if not with_aqe:
             q_last = q_last / q_last.norm(dim=1, keepdim=True)
         q_last = q_last.cpu().numpy()
         worst = 0.0
@@ -264,81 +349,160 @@ def main():
             if len(mine):
                 rows = np.stack([gal.get_rows(int(r) - lo, 1)[0] for r in idx_h[qi, mine]]).astype(np.float64)
                 worst = max(worst, float(np.abs(rows @ q_last[qi] - sc_h[qi, mine]).max()))
-        assert worst < 3e-7 * max(1.0, float(np.abs(sc_h).max())), "returned scores differ from the float64 re-computation: %g" % worst
-    if overflow and not args.diagnostic:
-        raise SystemExit("bench invalid: %d batches overflowed the candidate buffers" % overflow)
+        assert worst < 3e-7 * max(1.0, float(np.abs(sc_h).max())), \
+            "returned scores differ from the float64 re-computation: %g" % worst
+        if overflow:
+            raise SystemExit("bench invalid: %d batches overflowed the candidate buffers" % overflow)
 
+    res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
+               ingest_s=ingest_s, ingest_first_s=ingest_first_s, worst=worst, use_stream=use_stream,
+               protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype)
+    if keep:
+        res["gal"], res["q_last_pool"] = gal, pool[(steps - 1) % len(pool)]
+    else:
+        gal.close()
+        del sg, gal, pool
+        torch.cuda.empty_cache()
+    return res
+
+
+def roofline_of(res, args, world, with_traffic):
+    st, nq, elapsed = res["st"], res["nq"], res["elapsed"]
+    gemm_s = st["gemm_ms"] * 1e-3
+    # the scoring launch: MFMA-bound on the 256 x 256-tile kernel, HBM-bound (2*D bytes per gallery row) when the
+    # batch is small enough for the streaming kernel (<= 128 queries, csrc/stream_select.hip)
+    hbm_bound = nq <= 128
+    if gemm_s > 0:
+        achieved = st["gemm_bytes"] / gemm_s / 1e9 if hbm_bound else st["gemm_flops"] / gemm_s / 1e12
+    else:
+        achieved = None
+    peak = HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TFLOPS
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if with_traffic and os.path.exists(tp) and not hbm_bound:
+        try:
+            tj = json.load(open(tp))
+            traffic = tj.get("gemm_select_hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                          "command, not measured by this run" % tj.get("source", "?")
+        except Exception:
+            traffic = None
+    clock = st.get("kernel_clock_mhz") or None
+    roof = {"bound": "hbm" if hbm_bound else "mfma", "achieved": achieved, "peak": peak,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (achieved / peak) if achieved else None,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "stream_select_kernel" if hbm_bound else "gemm_tile_kernel", "launches": st["gemm_launches"],
+            "avg_launch_ms": st["gemm_ms"] / max(1, st["gemm_launches"]),
+            "kernel_share_of_step": gemm_s / elapsed}
+    if clock and not hbm_bound:
+        # the chip lowers its shader clock under MFMA load (DVFS): the dense peak it offers at the clock measured
+        # INSIDE the timed launches (s_memtime / s_memrealtime, median over waves) next to the nominal 2.4 GHz peak
+        roof["in_kernel_clock_mhz"] = clock
+        roof["peak_at_clock"] = MFMA_BF16_PEAK_TFLOPS * clock / 2400.0
+        roof["frac_at_clock"] = achieved / roof["peak_at_clock"] if achieved else None
+    return roof
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher: be the launcher.  Nothing below this line has run yet -- torch is not imported, the GPU untouched.
+        sys.exit(launch_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n" % (args.gpus, env_world))
+        sys.exit(2)
+    # stdout carries the ONE JSON line and nothing else: libraries write banners to file descriptor 1 (RCCL prints its
+    # version block there when a communicator is created, on every rank), so fd 1 is pointed at stderr for the whole run
+    # and the JSON line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    import isehr_amd  # noqa: F401
+
+    job = Job(args)
+    world, rank = job.world, job.rank
+    n_total = args.rows or WORKLOADS[args.workload][0]
+    d, k = args.dim, args.topk
+    default_shape = (args.workload == "roxford5k+1m" and not args.rows and args.queries == 1024 and d == 2048)
+    scale_10m = args.scale_10m == "on" or (
+        args.scale_10m == "auto" and default_shape and not (args.diagnostic or args.force_protocol or args.with_aqe
+                                                            or args.async_tail or args.option))
+
+    res = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, args.layout,
+                       with_aqe=args.with_aqe, async_tail=args.async_tail, pipeline=args.pipeline, options=args.option,
+                       check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True)
+    gal = res.pop("gal")
+    q_last_pool = res.pop("q_last_pool")
+    out = None
     if rank == 0:
+        elapsed, st, nq, gq, gs = res["elapsed"], res["st"], res["nq"], res["gq"], res["gs"]
         ms_step = elapsed / args.steps * 1e3
-        gemm_s = st["gemm_ms"] * 1e-3
-        # the scoring launch: MFMA-bound on the 256 x 256-tile kernel, HBM-bound (2*D bytes per gallery row) when the
-        # batch is small enough for the streaming kernel (<= 128 queries, csrc/stream_select.hip)
-        hbm_bound = nq <= 128
-        if gemm_s > 0:
-            achieved = st["gemm_bytes"] / gemm_s / 1e9 if hbm_bound else st["gemm_flops"] / gemm_s / 1e12
-        else:
-            achieved = None
-        peak = HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TFLOPS
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp) and not hbm_bound and args.workload == "roxford5k+1m" and not args.rows and world == 1:
-            try:
-                tj = json.load(open(tp))
-                traffic = tj.get("gemm_select_hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
-                              "command, not measured by this run" % tj.get("source", "?")
-            except Exception:
-                traffic = None
-        clock = st.get("kernel_clock_mhz") or None
-        roof = {"bound": "hbm" if hbm_bound else "mfma", "achieved": achieved, "peak": peak,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (achieved / peak) if achieved else None,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "stream_select_kernel" if hbm_bound else "gemm_tile_kernel", "launches": st["gemm_launches"],
-                "avg_launch_ms": st["gemm_ms"] / max(1, st["gemm_launches"]),
-                "kernel_share_of_step": gemm_s / elapsed}
-        if clock and not hbm_bound:
-            # the chip lowers its shader clock under MFMA load (DVFS): the dense peak it offers at the clock measured
-            # INSIDE the timed launches (s_memtime / s_memrealtime, median over waves) next to the nominal 2.4 GHz peak
-            roof["in_kernel_clock_mhz"] = clock
-            roof["peak_at_clock"] = MFMA_BF16_PEAK_TFLOPS * clock / 2400.0
-            roof["frac_at_clock"] = achieved / roof["peak_at_clock"] if achieved else None
+        roof = roofline_of(res, args, world, with_traffic=default_shape and world == 1)
         out = {
-            "metric": "queries/sec", "value": nq_job * args.steps / elapsed, "unit": "queries/s",
+            "metric": "queries/sec", "value": args.queries * args.steps / elapsed, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.image_dtype,
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
-                       "gallery_rows": n_total, "dim": d, "queries_per_step": nq_job, "topk": k,
+                       "gallery_rows": n_total, "dim": d, "queries_per_step": args.queries, "topk": k,
+                       "rccl_ranks": job.comm_ranks, "comm_backend": job.comm_backend,
                        "parallelism": ("row-shard x%d" % world if gq == 1 else
                                        "%d query groups (%d queries of every batch each, no exchange between groups) x %d "
                                        "row shards per group" % (gq, nq, gs)) +
                                       (" (two-phase protocol over RCCL forced on one rank)"
                                        if args.force_protocol and world == 1 else ""),
                        "alpha_qe": bool(args.with_aqe),
-                       "collectives": ("asynchronous, three batches in flight (search_stream)" if use_stream else
-                                       "synchronous per batch") if sg._protocol else None,
+                       "collectives": ("asynchronous, three batches in flight (search_stream)" if res["use_stream"] else
+                                       "synchronous per batch") if res["protocol"] else None,
                        "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "
                                 "the timed region" % ("scoring launch" if args.async_tail == 1 else
                                                       "query ingest + bootstrap (not the scoring launch)"))
-                               if pipelined else "same stream", "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
-                       "ingest_s": round(ingest_s, 3),
+                               if res["pipelined"] else "same stream",
+                       "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
-                       # the rate of ONE call that prepares the resident gallery and answers one batch
-                       "queries_per_s_incl_gallery_ingest": nq / (ms_step * 1e-3 + ingest_s),
+                       # ingest_s = one normalisation + layout pass over the resident raw rows in a warm process (the second
+                       # ingest of this run; the first one, which also initialises the library, is ingest_first_s), and the
+                       # rate of ONE call that prepares the gallery and answers one batch
+                       "ingest_s": round(res["ingest_s"], 4), "ingest_first_s": round(res["ingest_first_s"], 3),
+                       "queries_per_s_incl_gallery_ingest": nq / (ms_step * 1e-3 + res["ingest_s"]),
                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                        "survivors_per_query": st["survivors"] / max(1, st["queries"]),
-                       "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e" % (k, worst)
+                       "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e" % (k, res["worst"])
                                       if not args.diagnostic else None},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gal, pool[(args.steps - 1) % len(pool)].cpu().numpy(), n_total, args)
+            out["cpu_baseline"] = cpu_baseline(gal, q_last_pool.cpu().numpy(), n_total, args)
+    gal.close()
+    del gal, q_last_pool
+    torch.cuda.empty_cache()
+
+    if scale_10m:
+        # BASELINE configs[3]: 10 M x 2048 rows, bf16 image, 1024-query batches, row-sharded over the job's ranks
+        # (1 x N: every rank scores all queries against its rows; the two all-gathers of the protocol per batch)
+        r10 = run_workload(job, args.scale_10m_rows, 1024, "bf16", args.scale_10m_steps, 2, "1x%d" % world,
+                           check=True, keep=False)
+        if rank == 0:
+            roof10 = roofline_of(r10, args, world, with_traffic=False)
+            out["scale_10m"] = {
+                "gallery_rows": r10["n_total"], "rows_per_rank": r10["hi"] - r10["lo"], "image": "bf16",
+                "queries_per_step": 1024, "steps": r10["steps"], "ms_per_step": r10["elapsed"] / r10["steps"] * 1e3,
+                "value": 1024 * r10["steps"] / r10["elapsed"], "unit": "queries/s", "n_gpus": world,
+                "rccl_ranks": job.comm_ranks, "parallelism": "row-shard x%d" % world,
+                "ingest_s": round(r10["ingest_first_s"], 3),
+                "scoring_frac_of_mfma_peak": roof10["frac"], "scoring_share_of_step": roof10["kernel_share_of_step"],
+                "scoring_launches_per_step": r10["st"]["gemm_launches"] / max(1, r10["steps"]),
+                "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e" % (k, r10["worst"])}
+
+    if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or (args.force_protocol and dist.is_initialized()):
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    gal.close()
 
 
 if __name__ == "__main__":

@@ -486,9 +486,11 @@ static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev
   Workspace& ws = g->ws;
   QueryState st = make_state(ws);
   if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
-  if (resident) launch_rescore_resident(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s);
+  const uint32_t last_row = (uint32_t)std::max<int64_t>(0, g->n - 1);
+  if (resident) launch_rescore_resident(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
+                                        last_row);
   else launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
-                      (uint32_t)g->rescore_grid_x);
+                      (uint32_t)g->rescore_grid_x, last_row);
   launch_emit(ws.cand_rows, ws.cand_cnt, ws.cand_score, ws.rcap, nq, k, g->row_offset, out_idx, out_score,
               out_score64, s);
   HIPC(hipGetLastError());

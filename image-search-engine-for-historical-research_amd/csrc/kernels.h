@@ -82,9 +82,10 @@ void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_
                               uint32_t rcap, uint64_t* stats2, hipStream_t stream);
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                     const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
-                    uint32_t grid_x = 0);
+                    uint32_t grid_x, uint32_t last_row);   // last_row: n - 1 of the shard (row ids are clamped to it)
 void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                             const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream);
+                             const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
+                             uint32_t last_row);
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
                  int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score,
                  double* out_score64, hipStream_t stream);

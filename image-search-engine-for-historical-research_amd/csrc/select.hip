@@ -469,9 +469,12 @@ template <int UNROLL, int ROWS_PER_WG>
 __global__ __launch_bounds__(RESCORE_MAX_THREADS) void rescore_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
                                                       int32_t dp, const uint32_t* __restrict__ cand_rows,
                                                       const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
-                                                      double* __restrict__ cand_score) {
+                                                      double* __restrict__ cand_score, uint32_t last_row) {
   const uint32_t q = blockIdx.y;
-  const uint32_t nc = cand_cnt[q];
+  // the count is clamped to the list's capacity and every row id to the shard's last row, like the sibling kernels: a
+  // stale or undefined count / id ("the abort of round 2") can then cost a wrong candidate, never a
+  // read outside cand_rows or the gallery
+  const uint32_t nc = min(cand_cnt[q], rcap);
   if (blockIdx.x * ROWS_PER_WG >= nc) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4* qv = reinterpret_cast<const float4*>(qry + (uint64_t)q * dp);
@@ -484,8 +487,8 @@ __global__ __launch_bounds__(RESCORE_MAX_THREADS) void rescore_kernel(const floa
   const uint32_t cend = min(nc, c0 + ROWS_PER_WG);
   for (uint32_t c = c0 + w * 2; c < cend; c += 2 * (blockDim.x >> 6)) {
     const bool two = (c + 1 < cend);
-    const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
-    const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
+    const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[c], last_row) * dp);
+    const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[two ? c + 1 : c], last_row) * dp);
     double a0 = 0.0, a1 = 0.0;
     int v = lane;
     // 4 column steps at a time with all 12 loads issued before the first use (the rolled loop keeps only 3 loads of
@@ -543,7 +546,8 @@ constexpr uint32_t RESCORE_GRID_X = 64;     // 128 candidates per query and swee
 __global__ __launch_bounds__(256, 5) void rescore_resident_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
                                                                int32_t dp, int32_t nq, const uint32_t* __restrict__ cand_rows,
                                                                const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
-                                                               double* __restrict__ cand_score, uint32_t sub) {
+                                                               double* __restrict__ cand_score, uint32_t sub,
+                                                               uint32_t last_row) {
   const int lane = threadIdx.x & 63;
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int nvec = dp >> 2;
@@ -555,8 +559,8 @@ __global__ __launch_bounds__(256, 5) void rescore_resident_kernel(const float* _
     double* outs = cand_score + (uint64_t)q * rcap;
     for (uint32_t c = part * 2; c < nc; c += 2 * sub) {
       const bool two = (c + 1 < nc);
-      const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[c] * dp);
-      const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)rows[two ? c + 1 : c] * dp);
+      const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[c], last_row) * dp);
+      const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[two ? c + 1 : c], last_row) * dp);
       double a0 = 0.0, a1 = 0.0;
       int v = lane;
       for (; v + 192 < nvec; v += 256) {
@@ -597,22 +601,24 @@ __global__ __launch_bounds__(256, 5) void rescore_resident_kernel(const float* _
 }
 
 void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                             const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream) {
+                             const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
+                             uint32_t last_row) {
   const unsigned grid = (unsigned)current_device_cus();
   uint32_t sub = 1;
   while ((uint64_t)nq * sub * 2 <= (uint64_t)grid * 4) sub *= 2;      // every wave of the grid gets a share
   hipLaunchKernelGGL(rescore_resident_kernel, dim3(grid), dim3(256), 0, stream, gal_f32, qry_f32, dp, nq, cand_rows,
-                     cand_cnt, rcap, cand_score, sub);
+                     cand_cnt, rcap, cand_score, sub, last_row);
 }
 
 // grid_x: workgroups (of 2 candidates) per query and sweep, 0 = default.  Workgroups beyond a query's count exit at once and
 // queries with more candidates than one sweep covers take further sweeps.
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream, uint32_t grid_x) {
+                    const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream, uint32_t grid_x,
+                    uint32_t last_row) {
   uint32_t gx = grid_x ? grid_x : RESCORE_GRID_X;
   gx = std::max<uint32_t>(1u, std::min<uint32_t>(gx, (rcap + RESCORE_ROWS_PER_WG - 1) / RESCORE_ROWS_PER_WG));
   hipLaunchKernelGGL((rescore_kernel<1, RESCORE_ROWS_PER_WG>), dim3(gx, nq), dim3(RESCORE_THREADS), 0, stream, gal_f32,
-                     qry_f32, dp, cand_rows, cand_cnt, rcap, cand_score);
+                     qry_f32, dp, cand_rows, cand_cnt, rcap, cand_score, last_row);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -228,7 +228,7 @@ def main():
     # numpy / scipy.sparse methods that never touch `self`; the class's __init__ builds faiss indexes (absent), so the
     # methods are called on an instance made with __new__.  Inputs: the exact inner-product k-NN lists of a clustered,
     # L2-normalised feature set (what knn.search returns for an IndexFlatIP), with a few negative similarities so that
-    # the clipping at :103 acts.  get_offline_result's `linalg.cg(tol=...)` (:18) is a TypeError on scipy 1.15: unpinned.
+    # the clipping at :103 acts.
     import src.utils.diffusion as rdf
     vd = synth_rows(61, 0, 300, 24).astype(np.float64)
     cd = synth_rows(62, 0, 12, 24).astype(np.float64)
@@ -247,6 +247,34 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "diffusion_graph.npz"), sims=sims_d, ids=ids_d,
                         aff_data=aff.data, aff_indices=aff.indices, aff_indptr=aff.indptr,
                         lap_data=lap.data, lap_indices=lap.indices, lap_indptr=lap.indptr)
+
+    # ---- a5, the per-node solve: get_offline_result (src/utils/diffusion.py:15-19) itself, on the module globals it reads
+    # (trunc_ids, trunc_init, lap_alpha -- what get_offline_results sets at :55,66-70) with the Laplacian the reference's
+    # own get_laplacian built.  The function calls `linalg.cg(trunc_lap, trunc_init, tol=1e-6, maxiter=20)`; scipy >= 1.14
+    # has renamed that keyword, so FOR THIS CALL ONLY the module's `linalg.cg` forwards `tol` as `rtol` with atol = 0 to
+    # the real scipy solver.  Same stopping rule: the legacy rule (scipy 1.9 _get_atol, atol unset) stops at
+    # ||r|| <= tol * ||b||, the current one at ||r|| <= max(atol, rtol * ||b||), and ||b|| = ||e0|| = 1.
+    T_s, kd_s = 200, 40
+    ids_s = np.argsort(-sd, axis=1, kind="stable")[:, :T_s]
+    sims_s = np.take_along_axis(sd, ids_s, axis=1)
+    lap_s = rdf.Diffusion.get_laplacian(obj, sims_s[:, :kd_s].copy(), ids_s[:, :kd_s])
+    nodes_s = np.arange(0, len(vd), 6)
+    real_cg = rdf.linalg.cg
+
+    def cg_with_legacy_keyword(A, b, *a, tol=1e-5, **k):
+        return real_cg(A, b, *a, rtol=tol, atol=0.0, **k)
+
+    rdf.trunc_ids, rdf.lap_alpha = ids_s, lap_s
+    rdf.trunc_init = np.zeros(T_s)
+    rdf.trunc_init[0] = 1
+    rdf.linalg.cg = cg_with_legacy_keyword
+    try:
+        solve_scores = np.stack([rdf.get_offline_result(int(i)) for i in nodes_s])
+    finally:
+        rdf.linalg.cg = real_cg
+    assert solve_scores.shape == (len(nodes_s), T_s) and solve_scores.dtype == np.float64
+    np.savez_compressed(os.path.join(GOLD, "diffusion_solve.npz"), n_trunc=T_s, kd=kd_s, nodes=nodes_s,
+                        ids=ids_s[nodes_s], scores=solve_scores)
 
     # ---- f-2: descriptor tail (GeM -> L2N -> whiten Linear -> L2N), multi-scale average, SOA block -- the reference's
     # own layer functions / classes on seeded feature maps and weights

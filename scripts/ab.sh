@@ -4,7 +4,7 @@ dst=image-search-engine-for-historical-research_amd/libmi355_retrieval.so
 cp $dst /tmp/lib_keep.so
 for rep in 1 2 3; do for lib in $a $b; do
   cp $lib $dst
-  timeout -k 10 100 python bench.py --no-cpu-baseline "$@" | python -c "
+  timeout -k 10 100 python bench.py --scale-10m off --no-cpu-baseline "$@" | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,4 +1,4 @@
-for dbg in ${DBGS:-0 4}; do timeout -k 10 120 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --diagnostic --option debug=$dbg 2>&1 | python -c "
+for dbg in ${DBGS:-0 4}; do timeout -k 10 120 python bench.py --scale-10m off --steps 5 --warmup 1 --no-cpu-baseline --diagnostic --option debug=$dbg 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -6,7 +6,7 @@ cp $dst /tmp/lib_keep.so
 for lib in "$@"; do
   cp $lib $dst
   rm -rf gpurun_out/abtl
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abtl -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/abtl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abtl -- python3 bench.py --scale-10m off --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/abtl.log 2>&1
   python - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/abtl/*/*kernel_stats.csv")[0]

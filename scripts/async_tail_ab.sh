@@ -1,4 +1,4 @@
-for rep in 1 2; do for m in 0 2 1; do python bench.py --no-cpu-baseline --async-tail $m 2>/dev/null | python -c "
+for rep in 1 2; do for m in 0 2 1; do python bench.py --scale-10m off --no-cpu-baseline --async-tail $m 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('async_tail', $m, 'q/s %.0f' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'launch %.4f' % r['avg_launch_ms'], 'clock %.0f' % r['in_kernel_clock_mhz'])

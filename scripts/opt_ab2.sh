@@ -1,7 +1,7 @@
 # A/B of mi_set_option values with bench.py on ONE box, alternating: bash scripts/opt_ab2.sh name v1 v2 [rounds]
 name=$1; a=$2; b=$3; rounds=${4:-2}
 for r in $(seq $rounds); do for v in $a $b; do
-  timeout -k 10 200 python bench.py --no-cpu-baseline --option $name=$v | python -c "
+  timeout -k 10 200 python bench.py --scale-10m off --no-cpu-baseline --option $name=$v | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

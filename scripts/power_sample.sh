@@ -1,6 +1,6 @@
 # Board power and clocks while the scoring launch runs back to back (evidence for DESIGN 5.1 "power, not issue slots"):
 # bash scripts/power_sample.sh > gpurun_out/<tag>_power.txt
-python bench.py --steps 4000 --warmup 20 --no-cpu-baseline > /tmp/power_bench.json 2> /tmp/power_bench.err &
+python bench.py --scale-10m off --steps 4000 --warmup 20 --no-cpu-baseline > /tmp/power_bench.json 2> /tmp/power_bench.err &
 pid=$!
 sleep 4             # import + gallery build + warm-up take 5-8 s; the timed region is 4000 x 3.3 ms = 13 s
 for i in $(seq 1 20); do

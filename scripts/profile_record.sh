@@ -7,17 +7,17 @@ o=gpurun_out
 # 1. headline bench + its rocprofv3 kernel trace + PMC passes (separate runs, as the microarchitecture guide prescribes)
 python bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err            # the driver's default invocation: 200 steps
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -- python3 bench.py --no-cpu-baseline > $o/${tag}_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $o/${tag}_pmc_l2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_l2.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_sq.log 2>&1 || true
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_pmc_grbm -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_grbm.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -- python3 bench.py --scale-10m off --no-cpu-baseline > $o/${tag}_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $o/${tag}_pmc_l2 -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_l2.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_sq.log 2>&1 || true
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_pmc_grbm -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_grbm.log 2>&1 || true
 echo "pmc done"
 # 2. the other configurations, each as bench line + rocprofv3 kernel stats of the same command
 for v in "q1:--queries 1" "q70:--queries 70" "bf16:--image-dtype bf16" "aqe:--with-aqe" "aqe_rparis:--workload rparis6k+1m --with-aqe" "10m:--workload 10m --steps 10 --warmup 2"; do
   name=${v%%:*}; args=${v#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_${name}_trace -- python3 bench.py --no-cpu-baseline $args > $o/${tag}_${name}_bench.json 2> $o/${tag}_${name}.err || echo "$name failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_${name}_trace -- python3 bench.py --scale-10m off --no-cpu-baseline $args > $o/${tag}_${name}_bench.json 2> $o/${tag}_${name}.err || echo "$name failed"
   echo "$name done"
 done
 # 3. timelines (per-dispatch) of the full gallery and of a 1/8 shard; scripts
@@ -30,7 +30,7 @@ python scripts/xcc_report.py > $o/${tag}_xcc_report.txt 2>&1 || true
 python -m pytest tests/test_gpu_diffusion.py -q -s -k reference_size > $o/${tag}_diffusion_refsize.txt 2>&1 || true
 python scripts/ladder_probe.py > $o/${tag}_ladder_probe.txt 2> /dev/null || true
 (for g in 2 4 8; do python scripts/shard_step_model.py $g 1005994 rescore_grid_x=$((96 / g)) 2> /dev/null | tail -2; done) > $o/${tag}_shard_model.txt || true
-(for f in "" "--force-protocol"; do python bench.py --no-cpu-baseline --rows 125750 $f 2> /dev/null | tail -1 | cut -c1-700; done) > $o/${tag}_protocol_rccl1.txt || true
+(for f in "" "--force-protocol"; do python bench.py --scale-10m off --no-cpu-baseline --rows 125750 $f 2> /dev/null | tail -1 | cut -c1-700; done) > $o/${tag}_protocol_rccl1.txt || true
 bash scripts/layout_model.sh > $o/${tag}_layout_model.txt 2> /dev/null || true
 echo "scripts done"
 # 4. kernel A/B driver and MFMA probe (C++, no torch)

@@ -1,4 +1,4 @@
-for rows in 1005994 502997 251499 125750; do timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --rows $rows 2>&1 | python -c "
+for rows in 1005994 502997 251499 125750; do timeout -k 10 200 python bench.py --scale-10m off --steps 10 --warmup 2 --no-cpu-baseline --rows $rows 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,5 +1,5 @@
 # per-step time and scoring-launch time for small query batches (online: Q=1, rOxford test set: Q=70)
-for q in ${QS:-1 16 70 128}; do timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --queries $q 2>&1 | python -c "
+for q in ${QS:-1 16 70 128}; do timeout -k 10 200 python bench.py --scale-10m off --steps 20 --warmup 3 --no-cpu-baseline --queries $q 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -86,9 +86,18 @@ def main():
     stream_ok = int(len(pipe) == 5 and all(torch.equal(p_[0], r_[0]) and torch.equal(p_[1], r_[1])
                                            for p_, r_ in zip(pipe, seq)))
     flagged = sg.any_flag()
+    agreed_dtype = int(shard.get_option("image_dtype"))
+    # what THIS shard's rows measure under the agreed image type (a shard that chose fp16 on its own was re-imaged as bf16
+    # by the agreement, with larger rounding norms than `own_bounds`): a fresh handle of the same rows, never raised
+    probe = _lib.Gallery.from_device_ptr(raw[lo:hi].data_ptr(), hi - lo, d, norm_mode=norm, row_offset=lo)
+    if int(probe.get_option("image_dtype")) != agreed_dtype:
+        probe.set_image_dtype(agreed_dtype)
+    reimaged_bounds = probe.norm_bounds()
+    probe.close()
     out = dict(idx=idx.cpu().numpy(), sc=sc.cpu().numpy(), aidx=aidx.cpu().numpy(), asc=asc.cpu().numpy(),
-               qx=qx.cpu().numpy(), own_dtype=own_dtype, agreed_dtype=int(shard.get_option("image_dtype")),
-               own_bounds=np.array(own_bounds), agreed_bounds=np.array(shard.norm_bounds()), flagged=int(flagged),
+               qx=qx.cpu().numpy(), own_dtype=own_dtype, agreed_dtype=agreed_dtype,
+               own_bounds=np.array(own_bounds), reimaged_bounds=np.array(reimaged_bounds),
+               agreed_bounds=np.array(shard.norm_bounds()), flagged=int(flagged),
                lo=lo, hi=hi, stream_ok=stream_ok)
     if rank == 0:
         single = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d, norm_mode=norm)

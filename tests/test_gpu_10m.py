@@ -1,0 +1,100 @@
+"""GPU: BASELINE.json configs[3]'s gallery on ONE GPU -- 10,000,000 x 2048 rows with a bf16 image (the chunk schedule of
+the tile kernel over 39,063 gallery tiles; 82 GB of stored f32 rows + 41 GB of image) -- through size-independent
+properties: equality with the f32-scored path, float64 re-computation of returned scores, planted neighbours at both
+ends and on both sides of every chunk seam.  Rows are generated on the device."""
+import numpy as np
+import pytest
+
+from isehr_amd.synth import synth_rows
+
+pytestmark = pytest.mark.gpu
+N, D, K = 10_000_000, 2048, 100
+# chunk schedule at this size (csrc/api.hip phase1_batch): tiles [0, 32), [32, 256), [256, 39063) -> seams at rows 8192, 65536
+PLANTS = {0: 11, 1: 8191, 2: 8192, 3: 65535, 4: 65536, 5: 5_000_000, 6: N - 1}
+
+
+@pytest.fixture(scope="module")
+def huge():
+    import torch
+    from isehr_amd import _lib
+    dev = torch.device("cuda", 0)
+    free, total = torch.cuda.mem_get_info()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 215 << 30:
+        pytest.fail("10 M x 2048 needs ~205 GB of HBM at ingest; %.0f GB free" % (free / 2 ** 30))
+    s = torch.cuda.current_stream().cuda_stream
+    raw = torch.empty((N, D), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), 1234, 0, N, D, s)
+    q = torch.from_numpy(synth_rows(4321, 0, 1024, D)).to(dev)
+    for qi, row in PLANTS.items():
+        raw[row] = q[qi] * (0.25 + qi)
+    torch.cuda.synchronize()
+    _lib.set_global_option("image_dtype", 0)                      # bf16 image, as configs[3] names it
+    try:
+        g = _lib.Gallery.from_device_ptr(raw.data_ptr(), N, D)
+    finally:
+        _lib.set_global_option("image_dtype", 1)
+    del raw
+    torch.cuda.empty_cache()
+    assert int(g.get_option("image_dtype")) == 0
+    yield g, q
+    g.close()
+    torch.cuda.empty_cache()
+
+
+def _search(g, q, nq):
+    import torch
+    idx = torch.empty((nq, K), dtype=torch.int64, device=q.device)
+    sc = torch.empty((nq, K), dtype=torch.float32, device=q.device)
+    g.search_device(q.data_ptr(), nq, K, idx.data_ptr(), sc.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), sc.cpu().numpy()
+
+
+def _check_scores_f64(g, q, idx, sc, queries):
+    qn = q.cpu().numpy().astype(np.float64)
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    for qi in queries:
+        rows = np.stack([g.get_rows(int(r), 1)[0] for r in idx[qi]]).astype(np.float64)
+        assert np.abs(rows @ qn[qi] - sc[qi]).max() < 3e-7
+
+
+def test_10m_64_queries_equal_the_f32_scored_path(huge):
+    g, q = huge
+    g.status(reset=True)
+    idx, sc = _search(g, q, 64)
+    assert g.flags() == 0 and g.status()["overflow_batches"] == 0
+    assert (np.diff(sc, axis=1) <= 0).all() and all(len(set(r)) == K for r in idx)
+    assert idx.min() >= 0 and idx.max() < N
+    for qi, row in PLANTS.items():
+        assert idx[qi, 0] == row and abs(sc[qi, 0] - 1.0) < 1e-6
+    g.set_option("force_exact", 1)
+    try:
+        idx_e, sc_e = _search(g, q, 64)
+    finally:
+        g.set_option("force_exact", 0)
+    assert np.array_equal(idx, idx_e) and np.array_equal(sc, sc_e)
+    _check_scores_f64(g, q, idx, sc, range(0, 64, 4))
+    # random 2048-d unit vectors: the 100th best cosine of 10 M rows sits near 4.27 sigma = 0.094
+    assert 0.085 < sc[8:, K - 1].mean() < 0.105
+
+
+def test_10m_full_batch_tile_kernel_equals_the_f32_scored_path(huge):
+    """The benchmarked batch shape: 1024 queries on the tile kernel's chunk schedule."""
+    g, q = huge
+    g.status(reset=True)
+    idx, sc = _search(g, q, 1024)
+    st = g.status()
+    assert g.flags() == 0 and st["overflow_batches"] == 0 and st["gemm_launches"] >= 1
+    for qi, row in PLANTS.items():
+        assert idx[qi, 0] == row
+    g.set_option("force_exact", 1)
+    try:
+        idx_e, sc_e = _search(g, q, 1024)
+    finally:
+        g.set_option("force_exact", 0)
+    assert np.array_equal(idx, idx_e) and np.array_equal(sc, sc_e)
+    _check_scores_f64(g, q, idx, sc, range(0, 1024, 128))
+    idx2, sc2 = _search(g, q, 1024)                                   # idempotent
+    assert np.array_equal(idx, idx2) and np.array_equal(sc, sc2)

@@ -1,0 +1,60 @@
+"""GPU: bench.py as the driver starts it.  `python bench.py --gpus 2` WITHOUT a launcher must itself start two rank
+processes (here they share the test box's one GPU and talk over gloo, because RCCL refuses two ranks on one device) and
+print one JSON line whose n_gpus and communicator size are 2."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                           "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                     # stdout carries the one JSON line only
+    return json.loads(lines[0])
+
+
+def test_bare_gpus_2_runs_two_ranks():
+    out = _bench(["--gpus", "2", "--rows", "200000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                 {"ISEHR_DIST_BACKEND": "gloo", "ISEHR_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["comm_backend"] == "gloo"
+    assert out["config"]["gallery_rows"] == 200000 and out["steps"] == 4 and out["value"] > 0
+    assert "scale_10m" not in out                                     # --rows override: the secondary block is off
+
+
+def test_bare_gpus_2_row_shards_with_secondary_block():
+    """Row shards (1 x 2: the protocol with both all-gathers) and the secondary block at a reduced size (2 x 300 k rows of
+    the bf16 image on the shared GPU)."""
+    out = _bench(["--gpus", "2", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--layout", "1x2",
+                  "--scale-10m", "on", "--scale-10m-rows", "600000", "--scale-10m-steps", "3"],
+                 {"ISEHR_DIST_BACKEND": "gloo", "ISEHR_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2
+    assert out["config"]["collectives"] == "synchronous per batch"
+    s = out["scale_10m"]
+    assert s["gallery_rows"] == 600000 and s["rows_per_rank"] == 300000 and s["image"] == "bf16" and s["n_gpus"] == 2
+    assert s["value"] > 0 and s["parallelism"] == "row-shard x2"
+
+
+def test_one_gpu_line_has_the_contract_fields():
+    out = _bench(["--rows", "150000", "--steps", "5", "--warmup", "2", "--cpu-sample-rows", "8192"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["config"]["rccl_ranks"] == 1
+    assert out["config"]["ingest_s"] <= out["config"]["ingest_first_s"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["cpu_model"]
+    pts = {(p["queries"], p["threads"] == 1) for p in cb["blas"]["points"]}
+    assert {(1024, True), (70, True), (1, True)} <= pts and any(q == 70 and not one for q, one in pts)
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["launches"] == 5

@@ -1,6 +1,7 @@
 """GPU: dense exact kNN and the truncated graph diffusion against the oracle's restatement of
-src/utils/diffusion.py / src/utils/Reranking.py:230-253 (parity unpinned there: faiss is absent; the oracle
-uses exact numpy inner-product top-k and scipy's cg(rtol=1e-6), see oracle/__init__.py)."""
+src/utils/diffusion.py / src/utils/Reranking.py:230-253 and against the solutions of the reference's own
+get_offline_result (tests/golden/diffusion_solve.npz).  Unpinned there: only the faiss search (absent); the oracle uses
+exact numpy inner-product top-k in its place, see oracle/__init__.py."""
 import numpy as np
 import pytest
 
@@ -152,3 +153,38 @@ def test_offline_diffusion_by_node_ranges():
             G.diffusion_offline_nodes(T, kd, 5, n + 1)
     finally:
         G.close()
+
+
+def test_diffusion_offline_vs_reference_solve_golden(golden_dir):
+    """The truncated CG solutions the reference's own get_offline_result (src/utils/diffusion.py:15-19) produced for 50
+    nodes of a 300-row clustered feature set (oracle/make_golden.py; n_trunc = 200, kd = 40, Laplacian from the reference's
+    get_laplacian) against mi_diffusion_offline: same truncation supports, values within float32 rounding of the f64
+    solution (the reference stores float32 too, :80-84)."""
+    import os
+    from isehr_amd.diffusion import Diffusion
+    z = np.load(os.path.join(golden_dir, "diffusion_solve.npz"))
+    T, kd, nodes = int(z["n_trunc"]), int(z["kd"]), z["nodes"]
+    vd = synth_rows(61, 0, 300, 24).astype(np.float64)
+    cd = synth_rows(62, 0, 12, 24).astype(np.float64)
+    vd = 0.8 * vd + 1.1 * cd[np.arange(300) % 12]
+    vd /= np.linalg.norm(vd, axis=1, keepdims=True)
+    f = vd.astype(np.float32)
+    d = Diffusion(f)
+    try:
+        ids, vals = d.gallery.diffusion_offline(T, kd)
+    finally:
+        d.close()
+    same = (ids[nodes] == z["ids"]).all(axis=1)
+    assert same.mean() >= 0.9, same.mean()        # a float32 near-tie between two neighbours may swap two columns of a row
+    ref = z["scores"].astype(np.float32)
+    err = np.abs(vals[nodes][same].astype(np.float64) - z["scores"][same])
+    assert err.max() < 2e-6, err.max()
+    assert np.abs(ref).max() > 1.0
+    # rows with a swapped near-tie: equal as sparse rows (values matched by neighbour id)
+    for r in np.flatnonzero(~same):
+        i = nodes[r]
+        got = dict(zip(ids[i].tolist(), vals[i].tolist()))
+        want = dict(zip(z["ids"][r].tolist(), z["scores"][r].tolist()))
+        common = set(got) & set(want)
+        assert len(common) >= T - 2
+        assert max(abs(got[c] - want[c]) for c in common) < 5e-5

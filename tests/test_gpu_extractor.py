@@ -114,3 +114,38 @@ def test_extract_to_gallery_pipeline():
     assert idx[0, 0] == 8 and idx[1, 0] == 9                                    # each image retrieves itself
     s = oracle.exact_scores_f64(ref_rows, qd)
     assert oracle.check_topk_parity(idx, s, 5, 2e-5) == []
+
+
+def test_full_depth_resnet101_soa_to_gallery():
+    """BASELINE configs[1] at its real width and depth: the full ResNet101 (3, 4, 23, 3) x 64 trunk with both SOA blocks
+    (src/networks/networks.py:149-211; 2048 output channels) under PyTorch-ROCm on the GPU -> HIP descriptor tail with a
+    2048 x 2048 whitening layer -> appended 2048-d device gallery -> search.  Random weights (no checkpoint ships): what is
+    checked is the pipeline at full size against the same trunk output pushed through plain torch ops."""
+    import torch
+    from isehr_amd._lib import Gallery
+    from isehr_amd.extractor import ResNet101SOA, DescriptorTail, extract_to_gallery
+    torch.manual_seed(1)
+    trunk = ResNet101SOA().cuda().eval()
+    assert trunk.outputdim == 2048 and sum(p.numel() for p in trunk.parameters()) > 42_000_000
+    D = 2048
+    W = (torch.randn(D, D) / D ** 0.5).cuda()
+    b = (torch.randn(D) * 0.01).cuda()
+    tail = DescriptorTail(3.0, 1e-6, W, b)
+    imgs = torch.randn(3, 3, 224, 224, device="cuda")
+    G = Gallery.empty(8, D)
+    try:
+        assert extract_to_gallery(trunk, tail, [imgs[:2], imgs[2:]], G) == 3
+        with torch.no_grad():
+            f = trunk(imgs)
+            assert f.shape[1] == 2048 and torch.isfinite(f).all()
+            o = f.clamp(min=1e-6).pow(3.0).mean(dim=(2, 3)).pow(1 / 3.0)
+            o = o / (o.norm(dim=1, keepdim=True) + 1e-6)
+            o = torch.nn.functional.linear(o, W, b)
+            o = (o / (o.norm(dim=1, keepdim=True) + 1e-6)).cpu().numpy()
+        ref = o / np.linalg.norm(o, axis=1, keepdims=True)
+        got = G.get_rows(0, 3)
+        assert np.abs(got - ref).max() < 5e-6
+        idx, sc, _ = G.search(ref, 3)
+        assert list(idx[:, 0]) == [0, 1, 2] and np.abs(sc[:, 0] - 1.0).max() < 1e-5
+    finally:
+        G.close()

@@ -66,9 +66,11 @@ def test_full_size_properties(big):
         assert np.abs(rows @ qn[qi] - sc[qi, :10]).max() < 3e-7
 
 
-def test_full_size_bf16_path_equals_exact_path(big):
-    """The MFMA bf16 filter + certificate must reproduce the f32-scored path bit for bit."""
+def test_full_size_filter_path_equals_exact_path(big):
+    """The 16-bit MFMA filter (default image: fp16; 16 queries -> the streaming kernel) + certificate must reproduce the
+    f32-scored path bit for bit."""
     g, _, _, q = big
+    assert int(g.get_option("image_dtype")) == 1
     idx, sc = _search(g, q, 16)
     g.set_option("force_exact", 1)
     try:
@@ -143,3 +145,29 @@ def test_full_size_tile_kernel_equals_exact_path_and_two_shards(big):
     torch.cuda.synchronize()
     assert g0.status()["overflow_batches"] == 0 and g1.status()["overflow_batches"] == 0
     assert np.array_equal(oi.cpu().numpy(), idx) and np.array_equal(osc.cpu().numpy(), sc)
+
+
+def test_full_size_bf16_image_equals_exact_path(big):
+    """The same gallery re-imaged as bf16 (`mi_gallery_set_image_dtype(0)`: 8-bit significand, ~3x the candidates) at
+    1,005,994 x 2048: tile kernel (1024 queries) and streaming kernel (70 queries) against the f32-scored path."""
+    g, _, _, q = big
+    g.set_image_dtype(0)
+    try:
+        assert int(g.get_option("image_dtype")) == 0
+        for nq in (1024, 70):
+            g.status(reset=True)
+            idx, sc = _search(g, q, nq)
+            st = g.status()
+            assert st["overflow_batches"] == 0 and g.flags() == 0
+            assert st["candidates"] / st["queries"] > 200            # bf16 margins: ~358 candidate rows per query, fp16 ~127
+            assert idx[0, 0] == 7 and idx[1, 0] == 500000 and idx[2, 0] == N - 1
+            g.set_option("force_exact", 1)
+            try:
+                idx_e, sc_e = _search(g, q, nq)
+            finally:
+                g.set_option("force_exact", 0)
+            assert np.array_equal(idx, idx_e) and np.array_equal(sc, sc_e)
+    finally:
+        g.set_image_dtype(1)
+    idx, sc = _search(g, q, 64)                                       # back on fp16: same answers as before
+    assert int(g.get_option("image_dtype")) == 1 and np.array_equal(idx, idx_e[:64]) and np.array_equal(sc, sc_e[:64])

@@ -188,3 +188,34 @@ def test_diffusion_graph_vs_reference_golden(golden_dir):
     lap.sort_indices()
     assert np.array_equal(lap.indptr, z["lap_indptr"]) and np.array_equal(lap.indices, z["lap_indices"])
     assert lap.data.dtype == z["lap_data"].dtype and np.array_equal(lap.data, z["lap_data"])
+
+
+def _diffusion_solve_features():
+    """The feature set of oracle/make_golden.py's diffusion fixtures (seeds 61 / 62: 300 clustered unit rows, 24-d)."""
+    vd = synth_rows(61, 0, 300, 24).astype(np.float64)
+    cd = synth_rows(62, 0, 12, 24).astype(np.float64)
+    vd = 0.8 * vd + 1.1 * cd[np.arange(300) % 12]
+    vd /= np.linalg.norm(vd, axis=1, keepdims=True)
+    return vd.astype(np.float32)
+
+
+def test_diffusion_solve_vs_reference_golden(golden_dir):
+    """a5, the per-node solve: the reference's own get_offline_result (src/utils/diffusion.py:15-19) was run by
+    oracle/make_golden.py on the Laplacian its own get_laplacian built (its `cg(tol=)` keyword forwarded as `rtol`, atol = 0:
+    the same stopping rule since ||e0|| = 1).  The oracle's diffusion_offline must reproduce the truncated CG solutions of
+    those 50 nodes bit for bit, on the k-NN lists it finds itself."""
+    z = np.load(os.path.join(golden_dir, "diffusion_solve.npz"))
+    T, kd, nodes = int(z["n_trunc"]), int(z["kd"]), z["nodes"]
+    f = _diffusion_solve_features()
+    off, sims, ids, lap, allsc = oracle.diffusion_offline(f, T, kd, return_parts=True)
+    assert len(nodes) == 50 and z["scores"].shape == (50, T) and z["scores"].dtype == np.float64
+    assert np.array_equal(ids[nodes], z["ids"])
+    assert np.array_equal(allsc[nodes], z["scores"])
+    # the solutions are not trivial: the node itself carries the largest weight, its neighbours positive mass, and 20
+    # iterations at tol 1e-6 leave the iteration truncated for some nodes and converged for others
+    assert (allsc[nodes].argmax(axis=1) == 0).all() and (allsc[nodes, 0] > 1.0).all()
+    assert (np.abs(allsc[nodes][:, 1:kd]).max(axis=1) > 1e-3).all()
+    # and they land in the float32 CSR matrix the way src/utils/diffusion.py:80-84 assembles it
+    dense = np.asarray(off[nodes].todense())
+    for r, i in enumerate(nodes):
+        assert np.array_equal(dense[r, ids[i]], allsc[i].astype(np.float32))
