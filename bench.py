@@ -78,6 +78,10 @@ def parse():
     ap.add_argument("--pipeline", action="store_true",
                     help="sharded runs (--gpus N > 1 or --force-protocol): ShardedGallery.search_stream -- asynchronous "
                          "all-gathers, three batches in flight -- instead of one synchronous search per step")
+    ap.add_argument("--graph", action="store_true",
+                    help="one GPU, diagnostic: capture the launch sequence of one search per query batch in a hipGraph "
+                         "(torch.cuda.CUDAGraph over the library's launches on the capture stream) and time graph replays "
+                         "instead of eager launches.  No per-launch events exist inside a graph: `roofline.achieved` is null")
     ap.add_argument("--scale-10m", default="auto", choices=["auto", "on", "off"],
                     help="secondary block `scale_10m` (BASELINE configs[3]: 10 M x 2048 rows, bf16 image, row-sharded 1 x N "
                          "over the job's ranks), measured after the headline.  auto: on for the default workload without "
@@ -215,7 +219,7 @@ class Job:
 
 
 def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_aqe=False, async_tail=0, pipeline=False,
-                 options=(), check=True, warm_ingest=False, keep=False):
+                 options=(), check=True, warm_ingest=False, keep=False, graph=False):
     """Ingests this rank's shard of an n_total-row synthetic gallery and times `steps` steps of nq_job queries.
     Returns a dict of measurements (+ the gallery and the last query batch when keep=True)."""
     import numpy as np
@@ -308,8 +312,35 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     if pipelined:
         gal.join(stream)
     job.barrier()
+    graphs = None
+    if graph:
+        # one hipGraph per pooled query batch: the whole launch sequence of a search (query ingest ... emit), captured on a
+        # side stream and replayed; outputs land in the ShardedGallery's (static) result buffers like the eager calls'
+        if world > 1 or with_aqe or pipelined or use_stream:
+            raise SystemExit("--graph: single-GPU plain search only")
+        graphs = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for qb in pool:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    out_g = sg.search(qb, k)
+                graphs.append((gr, out_g, qb))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        def run_steps(count):                      # noqa: F811  (graph replays instead of eager launches)
+            out_ = None
+            for i in range(count):
+                gr, out_, qb = graphs[i % len(graphs)]
+                gr.replay()
+                last["q"] = qb
+            return out_
+        run_steps(2)
+        torch.cuda.synchronize()
     gal.status(reset=True)
-    gal.profile(True)
+    gal.profile(not graph)
     job.barrier()
     t0 = time.perf_counter()
     idx, sc = run_steps(steps)
@@ -356,7 +387,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
                ingest_s=ingest_s, ingest_first_s=ingest_first_s, worst=worst, use_stream=use_stream,
-               protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype)
+               protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
     if keep:
         res["gal"], res["q_last_pool"] = gal, pool[(steps - 1) % len(pool)]
     else:
@@ -429,11 +460,11 @@ def main():
     default_shape = (args.workload == "roxford5k+1m" and not args.rows and args.queries == 1024 and d == 2048)
     scale_10m = args.scale_10m == "on" or (
         args.scale_10m == "auto" and default_shape and not (args.diagnostic or args.force_protocol or args.with_aqe
-                                                            or args.async_tail or args.option))
+                                                            or args.async_tail or args.option or args.graph))
 
     res = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, args.layout,
                        with_aqe=args.with_aqe, async_tail=args.async_tail, pipeline=args.pipeline, options=args.option,
-                       check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True)
+                       check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True, graph=args.graph)
     gal = res.pop("gal")
     q_last_pool = res.pop("q_last_pool")
     out = None
@@ -455,6 +486,7 @@ def main():
                                       (" (two-phase protocol over RCCL forced on one rank)"
                                        if args.force_protocol and world == 1 else ""),
                        "alpha_qe": bool(args.with_aqe),
+                       "launch": "hipGraph replay of the per-batch launch sequence" if res["graph"] else "eager",
                        "collectives": ("asynchronous, three batches in flight (search_stream)" if res["use_stream"] else
                                        "synchronous per batch") if res["protocol"] else None,
                        "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "

@@ -252,11 +252,14 @@ static void prof_begin(mi_gallery* g, hipStream_t s, size_t* slot) {
   }
   *slot = g->ev_used++;
   g->ev_stream = s;
-  (void)hipEventRecord(g->ev_pool[*slot].first, s);
+  // the pair rides in the dispatch packet of the scoring launch itself (hipExtLaunchKernelGGL): begin / end timestamps of
+  // that kernel, no barrier packets of their own on the stream
+  set_launch_events(g->ev_pool[*slot].first, g->ev_pool[*slot].second);
 }
 static void prof_end(mi_gallery* g, hipStream_t s, size_t slot) {
-  if (slot == (size_t)-1) return;
-  (void)hipEventRecord(g->ev_pool[slot].second, s);
+  (void)g; (void)s; (void)slot;
+  hipEvent_t a, b;
+  take_launch_events(&a, &b);      // a launcher that did not take them (f32 scorer) leaves nothing behind
 }
 static void prof_collect(mi_gallery* g) {
   for (size_t i = 0; i < g->ev_used; ++i) {
@@ -316,7 +319,6 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   uint32_t* fc_rows = fuse_cand ? ws.cand_rows : nullptr;
   uint32_t* fc_cnt = fuse_cand ? ws.cand_cnt : nullptr;
   const int32_t qpad = (int32_t)round_up(nq, TILE);
-  launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, qpad, s);
   QueryState st = make_state(ws);
   const int64_t ntiles = g->npad / TILE;
   // bootstrap chunk: stored completely (no threshold yet); must hold >= K rows and fit the survivor buffer
@@ -341,7 +343,12 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   }
   const uint32_t first_cnt = (uint32_t)(samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
   const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
-  launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
+  // query ingest (normalise, f32 rows, 16-bit image, rounding norms) and the per-query search state in one launch
+  if (!launch_ingest_queries(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp,
+                             qpad, g->gstat3, gamma, exact ? 0 : 1, first_cnt, st, s)) {
+    launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, qpad, s);
+    launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
+  }
   // chunk boundaries (cumulative tiles): t0, t0*g, then x max(2, g/2) per step (thresholds keep tightening as the
   // sample grows; a 10M-row shard needs more steps than a 1M-row one); a tail shorter than half a step is merged
   const int64_t gr = std::max(1, g->chunk_growth);
@@ -350,6 +357,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   int64_t t = 0, len = t0;
   bool first = true;
   bool ladder_on = false;           // set for the one filtered launch of the sample-based schedule
+  // sample-based schedule with the dedicated threshold kernel: the bootstrap launch (stream_select MODE 2) stores bare
+  // 4-byte scores, all that kernel reads (half the bytes written and read back; ScoreArgs::scores_only)
+  const bool sample_f32 = samp_r > 0 && sample_threshold_applies(first_cnt, k, samp_r) && g->small_batch_kernel &&
+                          g->debug == 0;
   auto score_launch = [&](int64_t tile_from, int64_t ntile, bool first_chunk, const uint32_t* cond, bool profile_it,
                           bool on_sample = false) {
     const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
@@ -385,6 +396,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.cond = cond;
     a.bal = g->xcc_balance ? ws.bal : nullptr;
     a.lad_k = ladder_on ? k : 0;
+    a.scores_only = (on_sample && first_chunk && sample_f32) ? 1 : 0;
     a.dbg = ws.dbg;
     a.st = st;
     profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
@@ -415,7 +427,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       lad_r = std::max<int32_t>(1, std::min<int32_t>(lad_r, samp_r - 1));
     }
     if (sample_threshold_applies(first_cnt, k, samp_r)) {
-      launch_sample_threshold(st, nq, k, samp_r, first_cnt, s, lad_r);
+      launch_sample_threshold(st, nq, k, samp_r, first_cnt, s, lad_r, sample_f32 ? 1 : 0);
       ladder_on = lad_r > 0;
     } else {
       launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);

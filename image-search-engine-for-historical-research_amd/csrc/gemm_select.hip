@@ -22,12 +22,25 @@
 //    32 MFMAs of a slice, the other reads its fragments (12 ds_read_b128) -- the matrix pipe of every SIMD
 //    alternates between its two waves and stays busy;
 //  * the rings keep running across tile boundaries (no prologue/epilogue bubble per tile).
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
 
 namespace mi {
+
+static thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};
+void set_launch_events(hipEvent_t start, hipEvent_t stop) {
+  g_launch_ev[0] = start;
+  g_launch_ev[1] = stop;
+}
+void take_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  *start = g_launch_ev[0];
+  *stop = g_launch_ev[1];
+  g_launch_ev[0] = g_launch_ev[1] = nullptr;
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -463,8 +476,13 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
 //   * slice 0 of a tile is peeled (group 0 runs its deferred filter there), the filter sits outside the inner loop.
 // ORDER 1 issues the MFMAs query-block-major (the B fragment stays on the operand bus for 8 MFMAs instead of the A
 // fragment for 4).
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER>
+// OPT (round 3): bit 0 = the first K-slice of a tile accumulates onto the inline constant 0 (no 128-register reset after the
+// filter); bit 1 = the filter's decide step (32-value maxima per lane and query block, ballots) is computed inside the MFMA
+// segment of the tile's LAST K-slice, in the issue gaps of the matrix instructions, instead of after it.
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
+  constexpr bool ZC = (OPT & 1) != 0;
+  constexpr bool INTER = (OPT & 2) != 0 && !FIRST && !(DBG & (4 | 4096 | 8192));
   using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // rings | per-wave scratch | per-wave thresholds  (ONE LDS object)
   if (REPAIR && *p.cond == 0) return;
@@ -583,6 +601,42 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
 
     // ---- per-tile filter of the accumulators (+ reset); same code as structure 1
     unsigned long long fdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG 2048: cycles in decide / write burst / read wait / emit
+    // decide step of the filter, in two pieces so that INTER builds can place them inside the last MFMA segment of a tile:
+    // decide_fetch = this wave's thresholds of its 4 query blocks (LDS words; ladder: packed pair + live counter),
+    // decide_block(nb) = maximum of the lane's 32 scores of query block nb against its threshold -> ballot hm[nb]
+    float thr4[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long hm[4] = {0ull, 0ull, 0ull, 0ull};
+    auto decide_fetch = [&]() {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        if (lad) {
+          // the tighter threshold t_c - margin once K rows with approx >= t_c have been counted (by any wave of the
+          // launch: the counter is a fact about rows already scored, so it is a rigorous bound whenever it is read)
+          const uint32_t pk = reinterpret_cast<const uint32_t*>(thr_w)[nb * 16 + l15];
+          // the counters are written by this wave's own DMA piece, issued a tile ago and long retired by the counted
+          // vmcnt waits of the slices in between; read through asm so that the compiler does not order the read behind
+          // ALL pending DMA with a vmcnt(0), which would drain the rings at every tile boundary
+          uint32_t cnt;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cnt) : "v"(lds_addr(thr_w + 64 + nb * 16 + l15)) : "memory");
+          thr4[nb] = __uint_as_float(cnt >= (uint32_t)p.lad_k ? (pk & 0xFFFF0000u) : (pk << 16));
+        } else {
+          thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
+        }
+      }
+    };
+    auto decide_block = [&](int nb) {
+      // gallery blocks in the order the snake issues their MFMAs (odd query blocks run 7 .. 0): inside the last MFMA segment
+      // the first values read are then the oldest results
+      const int first = (ORDER == 3 && (nb & 1)) ? 7 : 0;
+      float m = acc[first][nb][0];
+#pragma unroll
+      for (int m2 = 0; m2 < 8; ++m2) {
+        const int mb = (ORDER == 3 && (nb & 1)) ? 7 - m2 : m2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
+      }
+      hm[nb] = __ballot(m >= thr4[nb]);
+    };
     auto tile_epilogue = [&](uint32_t gt, uint32_t qt) {
       const uint32_t row_base = gt * TILE + GRP * 128 + lq * 4;          // + mb*16 + reg
       const uint32_t ql_base = qt * TILE + wc * 64 + l15;                // + nb*16
@@ -714,36 +768,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
         }
         if (DBG & 2048) { fdbg[0] += stamp() - fb0; fdbg[5] += 1; }
       } else {
-        if (qt != thr_qt) load_thresholds(qt);
         unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
         if (DBG & 2048) f0 = stamp();
-        float thr4[4];
-        unsigned long long hm[4];
+        if (!INTER) {
+          if (qt != thr_qt) load_thresholds(qt);
+          decide_fetch();
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) decide_block(nb);
+        }
         uint32_t base[5];
         base[0] = 0;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          if (lad) {
-            // the tighter threshold t_c - margin once K rows with approx >= t_c have been counted (by any wave of the
-            // launch: the counter is a fact about rows already scored, so it is a rigorous bound whenever it is read)
-            const uint32_t pk = reinterpret_cast<const uint32_t*>(thr_w)[nb * 16 + l15];
-            // the counters are written by this wave's own DMA piece, issued a tile ago and long retired by the counted
-            // vmcnt waits of the slices in between; read through asm so that the compiler does not order the read behind
-            // ALL pending DMA with a vmcnt(0), which would drain the rings at every tile boundary
-            uint32_t cnt;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cnt) : "v"(lds_addr(thr_w + 64 + nb * 16 + l15)) : "memory");
-            thr4[nb] = __uint_as_float(cnt >= (uint32_t)p.lad_k ? (pk & 0xFFFF0000u) : (pk << 16));
-          } else {
-            thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
-          }
-          float m = acc[0][nb][0];
-#pragma unroll
-          for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][nb][r]);
-          hm[nb] = __ballot(m >= thr4[nb]);
-          base[nb + 1] = base[nb] + (uint32_t)__popcll(hm[nb]);
-        }
+        for (int nb = 0; nb < 4; ++nb) base[nb + 1] = base[nb] + (uint32_t)__popcll(hm[nb]);
         const uint32_t total = (DBG & 512) ? 0u : base[4];            // DBG 512: decide only, no hit path (diagnostics)
         if (DBG & 512) asm volatile("" ::"s"(base[4]));
         if (DBG & 2048) { f1 = stamp(); fdbg[0] += f1 - f0; fdbg[4] += total; fdbg[5] += 1; }
@@ -812,10 +848,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): see structure 1
       }
+      if (!ZC) {                                // ZC: the next tile's first MFMAs take the constant 0 as their C operand
 #pragma unroll
-      for (int mb = 0; mb < 8; ++mb)
+        for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     };
 
     // ---- prologue: all but one slot of this group's ring in flight, slice 0 landed
@@ -859,46 +897,55 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired BEFORE the barrier: frees the slots (WAR)
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto mfma_segment = [&](frag_t (&af)[8], frag_t (&bfr)[4]) {
+    // POS: 0 = middle slice, 1 = first slice of a tile (ZC: accumulate onto the constant 0), 2 = last slice of a tile
+    // (INTER: the filter's decide step of query block nb follows the MFMAs of block nb + 1, i.e. it issues in their gaps)
+    auto one_mfma = [&](frag_t a, frag_t b, f32x4 c) -> f32x4 {
+      if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
+    auto mfma_segment = [&](frag_t (&af)[8], frag_t (&bfr)[4], auto pos_tag) {
+      constexpr int POS = decltype(pos_tag)::value;
+      constexpr bool zero_c = ZC && POS == 1;
+      constexpr bool inter = INTER && POS == 2;
+      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (!(DBG & 2)) {
         if (ORDER == 0) {
 #pragma unroll
           for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-              if constexpr (F16)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-              else
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = one_mfma(af[mb], bfr[nb], zero_c ? zero4 : acc[mb][nb]);
         } else if (ORDER == 1) {
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb)
-              if constexpr (F16)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-              else
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+            for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = one_mfma(af[mb], bfr[nb], zero_c ? zero4 : acc[mb][nb]);
         } else if (ORDER == 2) {        // diagnostics: operands swapped (C transposed: results invalid with the filter)
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb)
-              if constexpr (F16)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);
-              else
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);
-        } else {                        // diagnostics: snake order (every MFMA shares an operand with its predecessor)
+            for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = one_mfma(bfr[nb], af[mb], zero_c ? zero4 : acc[mb][nb]);
+        } else {                        // snake order (every MFMA shares an operand with its predecessor)
+          if (inter) decide_fetch();
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb)
+          for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
             for (int m2 = 0; m2 < 8; ++m2) {
               const int mb = (nb & 1) ? 7 - m2 : m2;
-              if constexpr (F16)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-              else
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = one_mfma(af[mb], bfr[nb], zero_c ? zero4 : acc[mb][nb]);
             }
+            if (inter && nb > 0) {
+              // the maxima of query block nb - 1 (its MFMAs were issued >= 8 instructions ago: no result-latency stall) ride
+              // in the issue gaps of block nb's MFMAs: one matrix instruction, then up to three vector instructions
+              decide_block(nb - 1);
+#pragma unroll
+              for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+              }
+            }
+            if (inter) __builtin_amdgcn_sched_barrier(0);
+          }
+          if (inter) decide_block(3);
         }
       } else {
 #pragma unroll
@@ -909,6 +956,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       if (GRP == 0) vm_wait<(A_SLOTS - 2) * 4>();        // A(S+1) landed, A(S+2..S+4) may be in flight
       __builtin_amdgcn_sched_barrier(0);
     };
+    using pos_mid = std::integral_constant<int, 0>;
+    using pos_first = std::integral_constant<int, 1>;
+    using pos_last = std::integral_constant<int, 2>;
 
     uint32_t gt, qt, prev_gt = 0, prev_qt = 0;
     for (uint32_t i = 0; i < my_tiles; ++i) {
@@ -939,18 +989,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
           __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
         }
-        mfma_segment(af, bfr);
+        mfma_segment(af, bfr, pos_first{});
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- slices 1 .. KSL-1: straight-line body
+      // ---- slices 1 .. KSL-1 (INTER: .. KSL-2): straight-line body
 #pragma unroll 1
-      for (uint32_t sl = 1; sl < KSL; ++sl) {
+      for (uint32_t sl = 1; sl < KSL - (INTER ? 1u : 0u); ++sl) {
         frag_t af[8], bfr[4];
         load_segment(af, bfr, false);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_segment(af, bfr);
+        mfma_segment(af, bfr, pos_mid{});
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (INTER) {
+        // ---- last slice of the tile (peeled): its MFMA segment also computes the filter's decide step (KSL >= 2: dp is a
+        // multiple of 64).  The thresholds of the tile's query block must be this wave's before the segment reads them.
+        frag_t af[8], bfr[4];
+        if (qt != thr_qt) load_thresholds(qt);
+        load_segment(af, bfr, false);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_segment(af, bfr, pos_last{});
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1101,13 +1163,25 @@ void init_xcc_balance_host(XccBalance* h) {
 template <bool FIRST, int DBG, bool F16, bool REPAIR = false>
 static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   ensure_dynamic_lds((const void*)gemm_select_kernel<FIRST, DBG, F16, REPAIR>);
-  hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+  hipEvent_t e0, e1;
+  take_launch_events(&e0, &e1);
+  if (e0 && e1)
+    hipExtLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, e0, e1,
+                          0, a);
+  else
+    hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER>
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0>
 static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
-  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>);
-  hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT>);
+  hipEvent_t e0, e1;
+  take_launch_events(&e0, &e1);
+  if (e0 && e1)
+    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT>), dim3(persistent_grid()), dim3(512), lds, stream,
+                          e0, e1, 0, a);
+  else
+    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
@@ -1130,7 +1204,9 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
       case 5: return launch_tile<false, 5, true, false, 3>(a, lds, stream);
       case 512: return launch_tile<false, 512, true, false, 3>(a, lds, stream);
       case 1024: return launch_tile<false, 1024, true, false, 3>(a, lds, stream);
-      case 2048: return launch_tile<false, 2048, true, false, 3>(a, lds, stream);
+      case 2048:
+        if (a.variant == 6) return launch_tile<false, 2048, true, false, 3, 3>(a, lds, stream);
+        return launch_tile<false, 2048, true, false, 3>(a, lds, stream);
       case 8192: return launch_tile<false, 8192, true, false, 3>(a, lds, stream);
       case 8192 + 2048: return launch_tile<false, 8192 + 2048, true, false, 3>(a, lds, stream);
       case 4096: return launch_tile<false, 4096, true, false, 3>(a, lds, stream);
@@ -1140,6 +1216,9 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
       default:
         if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream);
         if (a.variant == 4) return launch_tile<false, 0, true, false, 1>(a, lds, stream);
+        if (a.variant == 5) return launch_tile<false, 0, true, false, 3, 1>(a, lds, stream);   // zero-C first slice
+        if (a.variant == 6) return launch_tile<false, 0, true, false, 3, 3>(a, lds, stream);   // + decide inside the last slice
+        if (a.variant == 7) return launch_tile<false, 0, true, false, 3, 2>(a, lds, stream);   // decide inside the last slice only
         return launch_tile<false, 0, true, false, 3>(a, lds, stream);
     }
   }

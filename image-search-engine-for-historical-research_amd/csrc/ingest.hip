@@ -207,6 +207,150 @@ __global__ __launch_bounds__(256) void ingest_rowwise_kernel(const InT* __restri
   }
 }
 
+// Query-batch ingest of the search path: the row-wise kernel above with (i) ONE pass over the source -- thread t keeps its
+// columns t, t + 256, ... in registers between the norm and the write phase (same summation order, so the same bits as
+// ingest_rowwise_kernel) and the 8-column chunks of the blocked image are regrouped through LDS -- and (ii) the per-query
+// state of the search (init_query_state_kernel of select.hip: error margin from the row's rounding norms, thresholds,
+// counters, ladder words) written by the row's workgroup, which saves a dependent launch per batch.  dp <= 4096.
+struct QueryInit {
+  const float* gstat3;     // gallery maxima of (||g||, ||g_hat||, ||g_hat - g||)
+  float gamma;
+  int use_img_terms;
+  uint32_t first_cnt;
+  int32_t nq;
+  QueryState st;
+};
+constexpr int QI_MAX_PER_THREAD = 16;
+template <typename InT>
+__global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs,
+                                                           int64_t cs, int norm_mode, float* __restrict__ out_f32,
+                                                           uint16_t* __restrict__ out_img, int img_f16,
+                                                           RowStat* __restrict__ rowstat, int32_t dp, QueryInit qi) {
+  __shared__ double red[3][4];
+  __shared__ __attribute__((aligned(16))) float rowbuf[256 * QI_MAX_PER_THREAD];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t row = blockIdx.x;
+  const bool valid = row < n;
+  auto block_sum3 = [&](double& a, double& b, double& c) {
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    __syncthreads();
+    if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  };
+  double v[QI_MAX_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < QI_MAX_PER_THREAD; ++j) {
+    const int c = t + 256 * j;
+    v[j] = (valid && c < d) ? (double)src[row * rs + (int64_t)c * cs] : 0.0;
+  }
+  double scale = 1.0;
+  if (norm_mode != 0) {
+    double ss = 0.0, z0 = 0.0, z1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < QI_MAX_PER_THREAD; ++j)
+      if (t + 256 * j < d) ss += v[j] * v[j];
+    block_sum3(ss, z0, z1);
+    const double nrm = sqrt(ss);
+    scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);
+  }
+#pragma unroll
+  for (int j = 0; j < QI_MAX_PER_THREAD; ++j)
+    if (t + 256 * j < dp) rowbuf[t + 256 * j] = (valid && t + 256 * j < d) ? (float)(v[j] * scale) : 0.0f;
+  __syncthreads();
+  double s_g = 0.0, s_b = 0.0, s_d = 0.0;
+  const int nslices = dp / SLICE_K;
+  const int64_t tileidx = row / TILE;
+  const uint32_t r = (uint32_t)(row % TILE);
+  for (int c0 = t * 8; c0 < dp; c0 += 2048) {
+    float vf[8];
+    const float4 lo = *reinterpret_cast<const float4*>(rowbuf + c0), hi = *reinterpret_cast<const float4*>(rowbuf + c0 + 4);
+    vf[0] = lo.x; vf[1] = lo.y; vf[2] = lo.z; vf[3] = lo.w; vf[4] = hi.x; vf[5] = hi.y; vf[6] = hi.z; vf[7] = hi.w;
+    const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
+    uint16_t* blk = out_img + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+    union { uint16_t h[8]; uint4 u; } pk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      double vb;
+      pk.h[e] = cvt_img(vf[e], img_f16, vb);
+      s_b += vb * vb;
+      s_d += (vb - (double)vf[e]) * (vb - (double)vf[e]);
+      s_g += (double)vf[e] * (double)vf[e];
+    }
+    *reinterpret_cast<uint4*>(blk + (swz_chunk(r, ch) << 3)) = pk.u;
+    if (valid) {
+      float4* o = reinterpret_cast<float4*>(out_f32 + row * dp + c0);
+      o[0] = lo;
+      o[1] = hi;
+    }
+  }
+  block_sum3(s_g, s_b, s_d);
+  if (t == 0) {
+    RowStat rsd;
+    rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
+    rsd.norm_img = (float)(sqrt(s_b) * (1.0 + 1e-6));
+    rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
+    rowstat[row] = rsd;
+    // ---- per-query search state (select.hip init_query_state_kernel, same arithmetic)
+    const QueryState& st = qi.st;
+    const int q = (int)row;
+    if (q == 0) st.flags[1] = 0;          // flags[0] is sticky across batches (read and cleared by the host)
+    if (q < qi.nq) {
+      const float g_f32 = qi.gstat3[0], g_bf = qi.gstat3[1], g_diff = qi.gstat3[2];
+      float eps;
+      if (qi.use_img_terms) eps = qi.gamma * rsd.norm_img * g_bf + rsd.norm_img * g_diff + rsd.norm_diff * g_f32;
+      else eps = qi.gamma * rsd.norm_f32 * g_f32;
+      float margin = 2.0f * eps * 1.001f + 1e-30f;
+      float thr0 = -INFINITY;
+      if (!(margin == margin)) margin = 0.f;
+      if (qi.use_img_terms && !isfinite(rsd.norm_img) && isfinite(rsd.norm_f32)) {
+        atomicOr(st.flags, FLAG_RANGE);
+        margin = 0.f;
+        thr0 = INFINITY;
+      }
+      st.thr[q] = thr0;
+      st.thr2[q] = thr0;
+      st.qflag[q] = 0;
+      st.margin[q] = margin;
+      st.cnt[q * CNT_STRIDE] = qi.first_cnt;
+    } else {
+      st.thr[q] = INFINITY;
+      st.thr2[q] = INFINITY;
+      st.qflag[q] = 0;
+      st.margin[q] = 0.f;
+      st.cnt[q * CNT_STRIDE] = 0;
+    }
+    if (st.lad_tc) {
+      st.lad_tc[q] = INFINITY;
+      st.lad_pack[q] = 0x7F807F80u;
+      st.lad_cnt[q] = 0;
+    }
+  }
+}
+
+bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
+                           float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int32_t qpad,
+                           const float* gstat3, float gamma, int use_img_terms, uint32_t first_cnt, const QueryState& st,
+                           hipStream_t stream) {
+  if (dp > 256 * QI_MAX_PER_THREAD) return false;         // wider rows: the two-launch path
+  QueryInit qi;
+  qi.gstat3 = gstat3;
+  qi.gamma = gamma;
+  qi.use_img_terms = use_img_terms;
+  qi.first_cnt = first_cnt;
+  qi.nq = nq;
+  qi.st = st;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ingest_query_kernel<float>, dim3((unsigned)qpad), dim3(256), 0, stream, (const float*)src, (int64_t)nq,
+                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi);
+  else
+    hipLaunchKernelGGL(ingest_query_kernel<double>, dim3((unsigned)qpad), dim3(256), 0, stream, (const double*)src,
+                       (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi);
+  return true;
+}
+
 // max over valid rows of the three norms (non-finite rows -- zero-norm rows normalised to NaN -- skipped)
 __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restrict__ rowstat, int64_t n,
                                                           float* __restrict__ out3) {

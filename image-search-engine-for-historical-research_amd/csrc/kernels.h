@@ -8,6 +8,12 @@ namespace mi {
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                    float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream,
                    int64_t row_base = 0);
+// query batch of the search path: ingest + the per-query search state (launch_init_query_state) in ONE launch; returns false
+// (nothing launched) when the rows are too wide for it
+bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
+                           float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int32_t qpad,
+                           const float* gstat3, float gamma, int use_img_terms, uint32_t first_cnt, const struct QueryState& st,
+                           hipStream_t stream);
 // bootstrap sample image (n_s = multiple of TILE rows, one hashed draw per stratum of the shard)
 void launch_build_sample(const void* gal_img, void* samp_img, int64_t n, int64_t n_s, int32_t dp, hipStream_t stream);
 int64_t sample_source_row_host(int64_t i, int64_t n, int64_t n_s);   // row_base: output rows start here (gallery append); src row 0 <-> row_base
@@ -34,6 +40,9 @@ struct ScoreArgs {
   const uint32_t* cond;   // non-null: the whole launch is skipped when *cond == 0 (repair pass)
   const XccBalance* bal = nullptr;   // non-null: weighted split of the gallery tiles over the XCD labels (tile kernel)
   int32_t lad_k = 0;                 // > 0: in-launch threshold ladder on (K of the search); tile kernel, filtered launch only
+  int32_t scores_only = 0;           // bootstrap launch on the sample image (stream_select MODE 2): store the scores as 4-byte
+                                     // floats at ((float*)(surv + q * cap))[sample row] instead of 8-byte (score, row) entries --
+                                     // sample_threshold_kernel reads nothing but the scores, and the entries are dropped afterwards
   unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
@@ -44,6 +53,12 @@ bool stream_bootstrap_applies(const ScoreArgs& a);   // bootstrap launches of an
 void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream);
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
+// Timing of ONE scoring launch without extra packets on the stream: the next launch_gemm_select / launch_stream_select of
+// this thread goes out through hipExtLaunchKernelGGL with these events, which receive the begin / end timestamps of the
+// dispatch itself (events recorded around a launch with hipEventRecord are barrier packets of their own: ~5 us of gap
+// before and after a 3 ms kernel).  Consumed by that launch.
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+void take_launch_events(hipEvent_t* start, hipEvent_t* stop);
 // buckets the wave-private records of the last scoring launch into the per-query survivor buffers
 // bal / dbg / ntiles non-null / non-zero: block 0 also updates the XCD shares from the loop times of the launch that wrote dbg
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
@@ -73,7 +88,7 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // thresholds from the 2048 / 4096 / 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r = 0);
+                             int32_t lad_r = 0, int32_t f32_scores = 0);   // f32_scores: see ScoreArgs::scores_only
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows = nullptr, uint32_t* cand_cnt = nullptr,

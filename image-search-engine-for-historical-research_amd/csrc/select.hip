@@ -49,9 +49,30 @@ __device__ uint32_t block_kth_largest(const uint32_t* keys, uint32_t n, uint32_t
     const int shift = pass * 8;
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint32_t k = keys[i];
-      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    // Scores of one query share sign and exponent, so in the leading passes nearly all keys of a wave fall into ONE bin and
+    // a per-lane LDS atomic would serialise 64 adds on one address (the first pass of a 900-key select took ~10 k cycles
+    // that way).  The wave first peels off up to four digit values held by many lanes -- one add of the lane count each --
+    // and only the remaining lanes add for themselves.
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {       // i0 is block-uniform: every wave runs the same trip count
+      const uint32_t i = i0 + threadIdx.x;
+      bool live = false;
+      uint32_t digit = 0;
+      if (i < n) {
+        const uint32_t k = keys[i];
+        live = (k & mask) == prefix;
+        digit = (k >> shift) & 255u;
+      }
+      unsigned long long todo = __ballot(live);
+#pragma unroll 1
+      for (int peel = 0; peel < 4 && todo; ++peel) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t dl = (uint32_t)__shfl((int)digit, leader);
+        const unsigned long long same = __ballot(live && digit == dl);
+        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+        if (digit == dl) live = false;
+        todo &= ~same;
+      }
+      if (live) atomicAdd(&hist[digit], 1u);
     }
     __syncthreads();
     // suffix sums over bins 255..0 by the first wave: lane l owns bins 4l..4l+3
@@ -332,7 +353,7 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
-                                                                        int32_t lad_r) {
+                                                                        int32_t lad_r, int32_t f32_scores) {
   __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sh[8];
@@ -344,7 +365,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
 #pragma unroll
   for (int j = 0; j < SAMP_PER_THREAD; ++j) {
     const uint32_t i = threadIdx.x + j * SAMP_THREADS;
-    kv[j] = (i < n) ? f2key(entry_score(gsurv[i])) : 0u;
+    // f32_scores: the bootstrap launch stored bare 4-byte scores (ScoreArgs::scores_only), half the bytes of the entries
+    kv[j] = (i < n) ? f2key(f32_scores ? reinterpret_cast<const float*>(gsurv)[i] : entry_score(gsurv[i])) : 0u;
     kmax = max(kmax, kv[j]);
   }
   const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);   // wanted ranks, w1 <= w2 <= 256
@@ -413,15 +435,15 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
 }
 
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r) {
+                             int32_t lad_r, int32_t f32_scores) {
   if (first_cnt == SAMP_THREADS * 2u)
-    hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+    hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
   else if (first_cnt == SAMP_THREADS * 4u)
-    hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+    hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
   else if (first_cnt == SAMP_THREADS * 8u)
-    hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+    hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
   else
-    hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r);
+    hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,71 +644,71 @@ void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int3
 }
 
 // ------------------------------------------------------------------------------------------------
-// bitonic sort of (score64 desc, id asc) pairs in LDS; n2 = power of two >= count
-template <typename IdT>
-__device__ void bitonic_sort_desc(double* s, IdT* id, uint32_t n2) {
-  for (uint32_t size = 2; size <= n2; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (uint32_t t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
-        const uint32_t lo = 2 * t - (t & (stride - 1));
-        const uint32_t hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const double a = s[lo], b = s[hi];
-        const IdT ia = id[lo], ib = id[hi];
-        // "a before b" in the final order: higher score first, NaN last, ties to the lower id
-        const bool a_nan = (a != a), b_nan = (b != b);
-        bool a_first;
-        if (a_nan || b_nan) a_first = (!a_nan) || (b_nan && ia < ib);
-        else a_first = (a > b) || (a == b && ia < ib);
-        if (a_first != desc) {
-          s[lo] = b; s[hi] = a;
-          id[lo] = ib; id[hi] = ia;
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
+// Final order of one query's candidates: (exact f64 score desc, NaN last, ties to the lower row id) -- a strict total
+// order, since the row ids of a list are distinct -- and the first k of it.  The place of a candidate is the number of
+// candidates that come before it, so every thread COUNTS the place of its candidates against the list staged in LDS
+// (tiles of EMIT_TILE entries; ~127 candidates per query at K = 100: one tile, ~127 broadcast reads per thread) and
+// writes them straight to their output slots.  No sorting network, no barriers beyond the staging, 6 KiB of LDS per
+// workgroup whatever rescore_cap is (the bitonic sort it replaces staged rcap * 12 bytes -- 24 KiB -- per workgroup and
+// took 20 us per 1024-query batch; same order, bit for bit: bitonic_sort_desc used the same comparison).
+constexpr uint32_t EMIT_TILE = 512;
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ cand_rows,
                                                    const uint32_t* __restrict__ cand_cnt,
                                                    const double* __restrict__ cand_score, uint32_t rcap, int32_t k,
                                                    int64_t row_offset, int64_t* __restrict__ out_idx,
                                                    float* __restrict__ out_score, double* __restrict__ out_score64) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double ts[EMIT_TILE];
+  __shared__ uint32_t ti[EMIT_TILE];
   const uint32_t q = blockIdx.x;
   const uint32_t nc = min(cand_cnt[q], rcap);
-  uint32_t n2 = 1;
-  while (n2 < nc) n2 <<= 1;
-  if (n2 < 2) n2 = 2;
-  double* s = reinterpret_cast<double*>(smem);
-  uint32_t* id = reinterpret_cast<uint32_t*>(smem + (size_t)rcap * 8);
-  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
-    if (i < nc) {
-      s[i] = cand_score[(uint64_t)q * rcap + i];
-      id[i] = cand_rows[(uint64_t)q * rcap + i];
-    } else {
-      s[i] = -INFINITY;
-      id[i] = 0xFFFFFFFFu;
-    }
+  const double* qs = cand_score + (uint64_t)q * rcap;
+  const uint32_t* qi = cand_rows + (uint64_t)q * rcap;
+  // slots no candidate claims (fewer than k candidates): padding
+  for (uint32_t i = nc + threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
+    out_idx[(uint64_t)q * k + i] = -1;
+    if (out_score) out_score[(uint64_t)q * k + i] = -INFINITY;
+    if (out_score64) out_score64[(uint64_t)q * k + i] = -INFINITY;
   }
-  bitonic_sort_desc<uint32_t>(s, id, n2);
-  for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
-    const bool ok = (i < nc);
-    out_idx[(uint64_t)q * k + i] = ok ? row_offset + (int64_t)id[i] : -1;
-    if (out_score) out_score[(uint64_t)q * k + i] = ok ? (float)s[i] : -INFINITY;
-    if (out_score64) out_score64[(uint64_t)q * k + i] = ok ? s[i] : -INFINITY;
+  for (uint32_t i0 = 0; i0 < nc; i0 += blockDim.x) {          // my candidate of this sweep (one sweep when nc <= 256)
+    const uint32_t i = i0 + threadIdx.x;
+    const bool mine = i < nc;
+    const double a = mine ? qs[i] : 0.0;
+    const uint32_t ia = mine ? qi[i] : 0u;
+    const bool a_nan = (a != a);
+    uint32_t place = 0;
+    for (uint32_t t0 = 0; t0 < nc; t0 += EMIT_TILE) {
+      const uint32_t tn = min(EMIT_TILE, nc - t0);
+      __syncthreads();                                        // the previous tile has been read by everybody
+      for (uint32_t e = threadIdx.x; e < tn; e += blockDim.x) {
+        ts[e] = qs[t0 + e];
+        ti[e] = qi[t0 + e];
+      }
+      __syncthreads();
+      if (mine)
+        for (uint32_t e = 0; e < tn; ++e) {
+          const double b = ts[e];
+          const uint32_t ib = ti[e];
+          // "b comes before a": higher score first, NaN last, ties to the lower id (b == a itself never counts: ib == ia)
+          const bool b_nan = (b != b);
+          bool b_first;
+          if (a_nan || b_nan) b_first = (!b_nan && a_nan) || (a_nan && b_nan && ib < ia);
+          else b_first = (b > a) || (b == a && ib < ia);
+          place += b_first ? 1u : 0u;
+        }
+    }
+    if (mine && place < (uint32_t)k) {
+      out_idx[(uint64_t)q * k + place] = row_offset + (int64_t)ia;
+      if (out_score) out_score[(uint64_t)q * k + place] = (float)a;
+      if (out_score64) out_score64[(uint64_t)q * k + place] = a;
+    }
   }
 }
 
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
                  int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64,
                  hipStream_t stream) {
-  // rcap is a power of two (enforced by the host), LDS = rcap * 12 (96 KiB at rescore_cap = 8192)
-  ensure_dynamic_lds((const void*)emit_kernel);
-  hipLaunchKernelGGL(emit_kernel, dim3(nq), dim3(256), (size_t)rcap * 12, stream, cand_rows, cand_cnt, cand_score,
-                     rcap, k, row_offset, out_idx, out_score, out_score64);
+  hipLaunchKernelGGL(emit_kernel, dim3(nq), dim3(256), 0, stream, cand_rows, cand_cnt, cand_score, rcap, k, row_offset,
+                     out_idx, out_score, out_score64);
 }
 
 // ------------------------------------------------------------------------------------------------

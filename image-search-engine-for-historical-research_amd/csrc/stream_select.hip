@@ -15,6 +15,8 @@
 //  * the filter is the one of the big kernel without its LDS scratch (the matrix pipe is idle most of the time
 //    here): ballot/popcount positions into wave-private record segments, no returning atomics.
 // Records, thresholds and flags are shared with gemm_select.hip (scatter_records_kernel runs afterwards).
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -165,10 +167,14 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
           const uint32_t q = q0 + qi;
           if (q >= (uint32_t)p.nq) break;
           uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap + row0;
+          float* dstf = reinterpret_cast<float*>(p.st.surv + (uint64_t)q * p.st.cap) + row0;
 #pragma unroll
           for (int it = 0; it < TILE / 64; ++it) {
             const uint32_t rl = it * 64 + lane;
-            if (row0 + rl < (uint64_t)p.n) dst[rl] = pack_entry(T[qi * TSTR + rl], row0 + rl);
+            if (row0 + rl < (uint64_t)p.n) {
+              if (p.scores_only) dstf[rl] = T[qi * TSTR + rl];
+              else dst[rl] = pack_entry(T[qi * TSTR + rl], row0 + rl);
+            }
           }
         }
       }
@@ -228,7 +234,10 @@ static void launch_stream_variant(const ScoreArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)SS_DEPTH * SLICE_BYTES + (size_t)SS_DEPTH * NQB * 1024 + NQB * 16 * 4;
   ensure_dynamic_lds((const void*)stream_select_kernel<NQB, F16, MODE>);
   const unsigned grid = MODE == 2 ? (unsigned)a.ntiles * (unsigned)((a.nq + NQB * 16 - 1) / (NQB * 16)) : gemm_select_grid();
-  hipLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(grid), dim3(512), lds, stream, a);
+  hipEvent_t e0, e1;
+  take_launch_events(&e0, &e1);
+  if (e0 && e1) hipExtLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(grid), dim3(512), lds, stream, e0, e1, 0, a);
+  else hipLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(grid), dim3(512), lds, stream, a);
 }
 
 bool stream_select_applies(const ScoreArgs& a) {
