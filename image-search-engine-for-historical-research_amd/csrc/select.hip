@@ -486,6 +486,11 @@ void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_
 // exact re-score: s = sum_k g[k] * q[k] with f32 inputs, exact f64 products and f64 accumulation
 // (HBM-bound gather of 4*dp bytes per candidate row).  One wave per row, two rows per wave pass.
 
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {          // global_load_dwordx4 ... nt
+  const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 constexpr int RESCORE_MAX_THREADS = 256;
 template <int UNROLL, int ROWS_PER_WG>
 __global__ __launch_bounds__(RESCORE_MAX_THREADS) void rescore_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
@@ -520,8 +525,9 @@ __global__ __launch_bounds__(RESCORE_MAX_THREADS) void rescore_kernel(const floa
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         x[u] = qv[v + 64 * u];
-        y0[u] = g0[v + 64 * u];
-        y1[u] = g1[v + 64 * u];
+        // candidate rows are read once per batch (the query row is shared by all its candidates: default policy)
+        y0[u] = nt_load4(g0 + v + 64 * u);
+        y1[u] = nt_load4(g1 + v + 64 * u);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -657,8 +663,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
                                                    const double* __restrict__ cand_score, uint32_t rcap, int32_t k,
                                                    int64_t row_offset, int64_t* __restrict__ out_idx,
                                                    float* __restrict__ out_score, double* __restrict__ out_score64) {
-  __shared__ double ts[EMIT_TILE];
-  __shared__ uint32_t ti[EMIT_TILE];
+  __shared__ __attribute__((aligned(16))) double ts[EMIT_TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t ti[EMIT_TILE];
   const uint32_t q = blockIdx.x;
   const uint32_t nc = min(cand_cnt[q], rcap);
   const double* qs = cand_score + (uint64_t)q * rcap;
@@ -677,24 +683,37 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
     const bool a_nan = (a != a);
     uint32_t place = 0;
     for (uint32_t t0 = 0; t0 < nc; t0 += EMIT_TILE) {
-      const uint32_t tn = min(EMIT_TILE, nc - t0);
+      const uint32_t tn = min(EMIT_TILE, nc - t0), tn4 = (tn + 3u) & ~3u;
       __syncthreads();                                        // the previous tile has been read by everybody
-      for (uint32_t e = threadIdx.x; e < tn; e += blockDim.x) {
-        ts[e] = qs[t0 + e];
-        ti[e] = qi[t0 + e];
+      for (uint32_t e = threadIdx.x; e < tn4; e += blockDim.x) {
+        // padding to a multiple of four: (NaN, largest id) comes before nothing -- not before a number, and not before
+        // another NaN either (its id is the largest)
+        ts[e] = e < tn ? qs[t0 + e] : __longlong_as_double(0x7FF8000000000000ll);
+        ti[e] = e < tn ? qi[t0 + e] : 0xFFFFFFFFu;
       }
       __syncthreads();
-      if (mine)
-        for (uint32_t e = 0; e < tn; ++e) {
-          const double b = ts[e];
-          const uint32_t ib = ti[e];
-          // "b comes before a": higher score first, NaN last, ties to the lower id (b == a itself never counts: ib == ia)
-          const bool b_nan = (b != b);
-          bool b_first;
-          if (a_nan || b_nan) b_first = (!b_nan && a_nan) || (a_nan && b_nan && ib < ia);
-          else b_first = (b > a) || (b == a && ib < ia);
-          place += b_first ? 1u : 0u;
+      if (mine) {
+        // four entries per step as three 16-byte LDS reads (every lane reads the same address: a broadcast), two steps
+        // in flight: the loop is a chain of LDS round trips otherwise
+#pragma unroll 2
+        for (uint32_t e = 0; e < tn4; e += 4) {
+          const double2 b01 = *reinterpret_cast<const double2*>(ts + e), b23 = *reinterpret_cast<const double2*>(ts + e + 2);
+          const uint4 id4 = *reinterpret_cast<const uint4*>(ti + e);
+          const double bs[4] = {b01.x, b01.y, b23.x, b23.y};
+          const uint32_t is[4] = {id4.x, id4.y, id4.z, id4.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double b = bs[u];
+            const uint32_t ib = is[u];
+            // "b comes before a": higher score first, NaN last, ties to the lower id (a itself never counts: ib == ia)
+            const bool b_nan = (b != b);
+            bool b_first;
+            if (a_nan || b_nan) b_first = (!b_nan && a_nan) || (a_nan && b_nan && ib < ia);
+            else b_first = (b > a) || (b == a && ib < ia);
+            place += b_first ? 1u : 0u;
+          }
         }
+      }
     }
     if (mine && place < (uint32_t)k) {
       out_idx[(uint64_t)q * k + place] = row_offset + (int64_t)ia;

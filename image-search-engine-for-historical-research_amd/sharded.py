@@ -259,8 +259,8 @@ class ShardedGallery:
 
     def aqe_search(self, ranks, k_qe, w, k, eps=1e-6, join=True):
         """alpha-QE across shards (src/utils/Reranking.py:195-208): every rank adds the rows it owns into a
-        float64 partial sum [Q, D] (`mi_aqe_partial_device`), the partials are all-reduced (8 MiB at Q = 1024,
-        D = 2048, f64: the rows of one query may live on any shard), every rank normalises redundantly
+        float64 partial sum [Q, D] (`mi_aqe_partial_device`), the partials are all-gathered and added in rank order
+        on every rank (a fixed summation order, unlike an all-reduce; the rows of one query may live on any shard), every rank normalises redundantly
         (`mi_aqe_finish_device`) and the expanded queries go through the sharded search as they are (no second
         normalisation).  ranks: int64 cuda tensor [K_in, Q] of GLOBAL row ids (any strides).
         Returns (idx [Q,k], score [Q,k], q_exp float32 [Q,D])."""
@@ -273,7 +273,17 @@ class ShardedGallery:
         self.g.aqe_partial_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, w, part.data_ptr(),
                                   stream)
         if self._protocol:
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+            # The partial sums are float64 and their total must not depend on the collective's algorithm: an all-reduce adds
+            # in ring / tree order, which differs between world sizes and libraries, so two runs of one job could disagree in
+            # the last bit of an expanded query (and with it in near-ties of the re-search).  The partials are therefore
+            # all-gathered (world x Q x D x 8 bytes: 128 MiB at 8 ranks, Q = 1024, D = 2048) and every rank adds them in rank
+            # order: one fixed order, bit-identical on every rank.  Against the single-shard sum (rows added in the order
+            # j = 0 .. k_qe-1) the order of the f64 additions can still differ when a query's rows sit on several shards:
+            # |difference| <= a few ulp of f64 (1e-16 relative), nine orders below the f32 rounding of the expanded query.
+            parts = all_gather_stacked(part, self.group)                  # [world, Q, D]
+            part = parts[0].clone()
+            for r in range(1, parts.shape[0]):
+                part += parts[r]
         qx = torch.empty((nq, d), dtype=torch.float32, device=ranks.device)
         _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)
         idx, sc = self.search(qx, k, query_norm_none=True, join=join)
