@@ -191,7 +191,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cand_rows, (size_t)QB * ws.rcap);
   A(cand_cnt, QB);
   A(cand_score, (size_t)QB * ws.rcap);
-  A(stats2, 4);
+  A(stats2, 2 * (size_t)QB);     // per query: (survivors, candidates) accumulators -- one writer each, no atomics
   ws.rec_cap = 4096;          // records per wave segment and launch (K = 1000 at 1M rows needs ~1800)
   ws.nseg = gemm_select_grid() * 8;
   A(rec, (size_t)ws.nseg * ws.rec_cap);
@@ -208,7 +208,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cand_score_set[1], (size_t)QB * ws.rcap);
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
-  HIPC(hipMemset(ws.stats2, 0, 32));
+  HIPC(hipMemset(ws.stats2, 0, 2 * (size_t)QB * 8));
   HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
   HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
   HIPC(hipMemset(ws.cand_cnt_set[1], 0, (size_t)QB * 4));
@@ -1781,13 +1781,17 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
   HIPC(hipStreamSynchronize(g->stream));
   HIPC(hipDeviceSynchronize());
   prof_collect(g);
-  Workspace& sw = sw.qcap ? g->ws : g->ws_alt;          // flags / statistics / clocks are ONE set for both slots
+  Workspace& sw = g->ws.qcap ? g->ws : g->ws_alt;       // flags / statistics / clocks are ONE set for both slots
   if (sw.qcap) {
-    uint64_t s2[2] = {0, 0};
-    HIPC(hipMemcpy(s2, sw.stats2, 16, hipMemcpyDeviceToHost));
-    g->stats.survivors += (int64_t)s2[0];
-    g->stats.candidates += (int64_t)s2[1];
-    HIPC(hipMemset(sw.stats2, 0, 16));
+    // per-query accumulators (the kernels add to the words of their own query: no atomics on one address from 1024
+    // workgroups, which cost the final maintain launch 15 us per batch); summed here
+    std::vector<uint64_t> s2(2 * (size_t)QB);
+    HIPC(hipMemcpy(s2.data(), sw.stats2, s2.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < (size_t)QB; ++i) {
+      g->stats.survivors += (int64_t)s2[2 * i];
+      g->stats.candidates += (int64_t)s2[2 * i + 1];
+    }
+    HIPC(hipMemset(sw.stats2, 0, s2.size() * 8));
     uint32_t flags = 0;
     HIPC(hipMemcpy(&flags, sw.flags, 4, hipMemcpyDeviceToHost));
     if (flags) {

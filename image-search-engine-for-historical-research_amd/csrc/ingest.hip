@@ -221,11 +221,12 @@ struct QueryInit {
   QueryState st;
 };
 constexpr int QI_MAX_PER_THREAD = 16;
-template <typename InT>
+template <typename InT, bool INIT>
 __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs,
                                                            int64_t cs, int norm_mode, float* __restrict__ out_f32,
                                                            uint16_t* __restrict__ out_img, int img_f16,
-                                                           RowStat* __restrict__ rowstat, int32_t dp, QueryInit qi) {
+                                                           RowStat* __restrict__ rowstat, int32_t dp, QueryInit qi,
+                                                           int64_t row_base) {
   __shared__ double red[3][4];
   __shared__ __attribute__((aligned(16))) float rowbuf[256 * QI_MAX_PER_THREAD];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -262,8 +263,9 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
   __syncthreads();
   double s_g = 0.0, s_b = 0.0, s_d = 0.0;
   const int nslices = dp / SLICE_K;
-  const int64_t tileidx = row / TILE;
-  const uint32_t r = (uint32_t)(row % TILE);
+  const int64_t orow = row_base + row;          // output row (gallery append: source row 0 <-> row_base)
+  const int64_t tileidx = orow / TILE;
+  const uint32_t r = (uint32_t)(orow % TILE);
   for (int c0 = t * 8; c0 < dp; c0 += 2048) {
     float vf[8];
     const float4 lo = *reinterpret_cast<const float4*>(rowbuf + c0), hi = *reinterpret_cast<const float4*>(rowbuf + c0 + 4);
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     }
     *reinterpret_cast<uint4*>(blk + (swz_chunk(r, ch) << 3)) = pk.u;
     if (valid) {
-      float4* o = reinterpret_cast<float4*>(out_f32 + row * dp + c0);
+      float4* o = reinterpret_cast<float4*>(out_f32 + orow * dp + c0);
       o[0] = lo;
       o[1] = hi;
     }
@@ -292,7 +294,8 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
     rsd.norm_img = (float)(sqrt(s_b) * (1.0 + 1e-6));
     rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
-    rowstat[row] = rsd;
+    rowstat[orow] = rsd;
+    if (!INIT) return;
     // ---- per-query search state (select.hip init_query_state_kernel, same arithmetic)
     const QueryState& st = qi.st;
     const int q = (int)row;
@@ -343,11 +346,11 @@ bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, in
   qi.nq = nq;
   qi.st = st;
   if (dtype == 0)
-    hipLaunchKernelGGL(ingest_query_kernel<float>, dim3((unsigned)qpad), dim3(256), 0, stream, (const float*)src, (int64_t)nq,
-                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi);
+    hipLaunchKernelGGL((ingest_query_kernel<float, true>), dim3((unsigned)qpad), dim3(256), 0, stream, (const float*)src,
+                       (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi, (int64_t)0);
   else
-    hipLaunchKernelGGL(ingest_query_kernel<double>, dim3((unsigned)qpad), dim3(256), 0, stream, (const double*)src,
-                       (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi);
+    hipLaunchKernelGGL((ingest_query_kernel<double, true>), dim3((unsigned)qpad), dim3(256), 0, stream, (const double*)src,
+                       (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi, (int64_t)0);
   return true;
 }
 
@@ -374,6 +377,20 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                    float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad,
                    hipStream_t stream, int64_t row_base) {
+  if (cs == 1 && dp <= 256 * QI_MAX_PER_THREAD && npad < (int64_t)1 << 31) {
+    // rows contiguous in memory (row-major source: device-generated galleries, appended descriptor batches, re-imaging of
+    // the stored rows): one workgroup per row, ONE pass over the source with the row held in registers -- a gallery is
+    // read once (8 KiB per row) and written once (8 + 4 KiB) instead of being read twice through the 64 x 64 LDS tiles of
+    // ingest_kernel, which exists for the reference's strided `vecs.T` views ([D, N] arrays: rs == 1)
+    QueryInit none{};
+    if (dtype == 0)
+      hipLaunchKernelGGL((ingest_query_kernel<float, false>), dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
+                         d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base);
+    else
+      hipLaunchKernelGGL((ingest_query_kernel<double, false>), dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
+                         n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base);
+    return;
+  }
   if (npad <= 4096 || row_base != 0) {   // small batches (queries): one workgroup per row
     if (dtype == 0)
       hipLaunchKernelGGL(ingest_rowwise_kernel<float>, dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,

@@ -86,6 +86,7 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // mode 0: maintain (threshold <- K-th largest - margin, compact survivors)
 // mode 1: maintain + write the K largest approximate values to topvals[q][K] and L_local[q]
 // thresholds from the 2048 / 4096 / 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
+void set_tail_debug_phase(int phase);   // diagnostics only (scripts/tailbench.hip): selection kernels return after phase N; 0 = product
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
                              int32_t lad_r = 0, int32_t f32_scores = 0);   // f32_scores: see ScoreArgs::scores_only

@@ -13,6 +13,10 @@
 
 namespace mi {
 
+// diagnostics (scripts/tailbench.hip): the selection kernels return after phase N of their work; 0 = run to the end (product)
+static int g_tail_debug_phase = 0;
+void set_tail_debug_phase(int phase) { g_tail_debug_phase = phase; }
+
 int ensure_dynamic_lds(const void* kernel, int bytes) {
   static std::mutex mu;
   static std::set<std::pair<const void*, int>> done;
@@ -40,71 +44,93 @@ int current_device_cus() {
 
 
 // ------------------------------------------------------------------------------------------------
-// block-wide K-th largest key among keys[0..n) held in LDS (MSB-first 8-bit radix select).
-// hist: 256 uint32 of LDS scratch; sh: 2 uint32 of LDS scratch.  All threads must call; returns the key.
-// Requires 1 <= K <= n and blockDim.x >= 256.
-__device__ uint32_t block_kth_largest(const uint32_t* keys, uint32_t n, uint32_t K, uint32_t* hist, uint32_t* sh) {
+// inclusive prefix sum over the 64 lanes of a wave by DPP moves (row_shr 1, 2, 4, 8, then row_bcast 15 / 31): six VALU
+// steps instead of six ds_bpermute round trips (~100 cycles each) of a __shfl-based scan
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// block-wide K-th largest of n keys (MSB-first 8-bit radix select): keys[0 .. min(n, lds_n)) in LDS, the rest -- degenerate
+// data only -- through rest_at(i) (global memory).  lds_n must be a multiple of blockDim.x.
+// hist: 1024 uint32 of LDS scratch = one 256-bin histogram PER PASS, all cleared up front, and EVERY wave scans the
+// histogram of a pass for itself (same bins, same answer): a pass costs ONE barrier, between its adds and its scan.  The
+// cross-lane steps are v_readlane / DPP, not LDS permutes: these kernels are chains of latencies, not throughput
+// (scripts/tailbench.hip: the select of 900 keys went 12 -> 4 us).  All threads must call; returns the key.  Requires
+// 1 <= K <= n and blockDim.x a multiple of 64.
+template <typename RestAt>
+__device__ uint32_t block_kth_largest_f(const uint32_t* keys, uint32_t lds_n, RestAt rest_at, uint32_t n, uint32_t K,
+                                        uint32_t* hist) {
   uint32_t prefix = 0, mask = 0, remaining = K;
+  for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const int l = threadIdx.x & 63;
   for (int pass = 3; pass >= 0; --pass) {
     const int shift = pass * 8;
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
+    uint32_t* h = hist + pass * 256;
     // Scores of one query share sign and exponent, so in the leading passes nearly all keys of a wave fall into ONE bin and
-    // a per-lane LDS atomic would serialise 64 adds on one address (the first pass of a 900-key select took ~10 k cycles
-    // that way).  The wave first peels off up to four digit values held by many lanes -- one add of the lane count each --
-    // and only the remaining lanes add for themselves.
-    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {       // i0 is block-uniform: every wave runs the same trip count
-      const uint32_t i = i0 + threadIdx.x;
-      bool live = false;
-      uint32_t digit = 0;
-      if (i < n) {
-        const uint32_t k = keys[i];
-        live = (k & mask) == prefix;
-        digit = (k >> shift) & 255u;
-      }
+    // a per-lane LDS atomic would serialise 64 adds on one address.  The wave first peels off up to four digit values held
+    // by many lanes -- one add of the lane count each -- and only the remaining lanes add for themselves.
+    auto add_key = [&](bool have, uint32_t k) {
+      bool live = have && (k & mask) == prefix;
+      const uint32_t digit = (k >> shift) & 255u;
       unsigned long long todo = __ballot(live);
 #pragma unroll 1
       for (int peel = 0; peel < 4 && todo; ++peel) {
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t dl = (uint32_t)__shfl((int)digit, leader);
+        const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);
         const unsigned long long same = __ballot(live && digit == dl);
-        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+        if (l == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
         if (digit == dl) live = false;
         todo &= ~same;
       }
-      if (live) atomicAdd(&hist[digit], 1u);
+      if (live) atomicAdd(&h[digit], 1u);
+    };
+    const uint32_t n_lds = min(n, lds_n);
+    for (uint32_t i0 = 0; i0 < n_lds; i0 += blockDim.x) {   // i0 is block-uniform: every wave runs the same trip count
+      const uint32_t i = i0 + threadIdx.x;
+      add_key(i < n_lds, i < n_lds ? keys[i] : 0u);
+    }
+    for (uint32_t i0 = lds_n; i0 < n; i0 += blockDim.x) {
+      const uint32_t i = i0 + threadIdx.x;
+      add_key(i < n, i < n ? rest_at(i) : 0u);
     }
     __syncthreads();
-    // suffix sums over bins 255..0 by the first wave: lane l owns bins 4l..4l+3
-    if (threadIdx.x < 64) {
-      const int l = threadIdx.x;
-      const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
-      const uint32_t tot = h0 + h1 + h2 + h3;
-      uint32_t suf = tot;   // inclusive suffix over lanes >= l
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_down(suf, o);
-        if (l + o < 64) suf += v;
-      }
-      const uint32_t above = suf - tot;   // keys in bins of higher lanes
-      // bins 4l+3 .. 4l in descending order
-      uint32_t c = above;
-      const uint32_t hs[4] = {h3, h2, h1, h0};
+    // suffix sums over bins 255..0, by every wave for itself: lane l owns bins 4l..4l+3
+    const uint4 hv = *reinterpret_cast<const uint4*>(h + 4 * l);
+    const uint32_t tot = hv.x + hv.y + hv.z + hv.w;
+    const uint32_t inc = wave_prefix_sum(tot);                                     // bins 0 .. 4l+3
+    const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    // bins 4l+3 .. 4l in descending order; exactly one (lane, bin) holds the key of rank `remaining`
+    uint32_t c = all - inc;   // keys in bins of higher lanes
+    const uint32_t hs[4] = {hv.w, hv.z, hv.y, hv.x};
+    uint32_t my_bin = 0, my_rem = 0;
+    bool found = false;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (c < remaining && c + hs[e] >= remaining) {
-          sh[0] = (uint32_t)(4 * l + 3 - e);
-          sh[1] = remaining - c;
-        }
-        c += hs[e];
+    for (int e = 0; e < 4; ++e) {
+      if (c < remaining && c + hs[e] >= remaining) {
+        my_bin = (uint32_t)(4 * l + 3 - e);
+        my_rem = remaining - c;
+        found = true;
       }
+      c += hs[e];
     }
-    __syncthreads();
-    prefix |= sh[0] << shift;
+    const int owner = __ffsll((long long)__ballot(found)) - 1;
+    prefix |= (uint32_t)__builtin_amdgcn_readlane((int)my_bin, owner) << shift;
     mask |= 255u << shift;
-    remaining = sh[1];
-    __syncthreads();
+    remaining = (uint32_t)__builtin_amdgcn_readlane((int)my_rem, owner);
   }
+  __syncthreads();                      // callers reuse hist right away
   return prefix;
+}
+// keys[0..n) held in LDS
+__device__ uint32_t block_kth_largest(const uint32_t* keys, uint32_t n, uint32_t K, uint32_t* hist) {
+  return block_kth_largest_f(keys, 0xFFFFFC00u, [](uint32_t) { return 0u; }, n, K, hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,9 +186,13 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // ------------------------------------------------------------------------------------------------
 // maintain: L = K-th largest approximate score among the survivors so far (a lower bound of the final
 // K-th largest); threshold <- L - margin; survivors below the new threshold are dropped.
-// Only the 4-byte keys live in LDS (cap * 4 + 1 KiB -> 3 workgroups per CU); the 8-byte entries stay in
-// registers between the read and the in-place compaction (all reads complete before the first write).
+// Only the 4-byte keys live in LDS, and only the first MAINT_LDS_KEYS of them: 32 KiB + 2 KiB per workgroup lets FOUR
+// 512-thread workgroups share a CU, i.e. the 1024 queries of a batch run in one round (the keys of all survivor_cap
+// entries took 50 KiB: three per CU, two rounds; a descriptor batch has ~900 survivors per query).  Keys beyond that
+// (degenerate data only) are recomputed from the entries in global memory by the select passes.  The 8-byte entries stay
+// in registers between the read and the in-place compaction (all reads complete before the first write).
 constexpr int MAINT_THREADS = 512;
+constexpr uint32_t MAINT_LDS_KEYS = 8192;
 constexpr int MAINT_PER_THREAD_MAX = 32;        // 512 * 32 = 16384 = largest survivor_cap
 
 // MODE 0 (after the bootstrap chunk).  spec_r > 0: SPECULATIVE threshold for the single remaining scoring launch =
@@ -184,35 +214,48 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
                                                                         int32_t spec, int32_t repair,
                                                                         const uint32_t* __restrict__ cond,
                                                                         uint32_t* __restrict__ cand_rows,
-                                                                        uint32_t* __restrict__ cand_cnt, uint32_t rcap) {
+                                                                        uint32_t* __restrict__ cand_cnt, uint32_t rcap,
+                                                                        int dbg_phase) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (cond && *cond == 0) return;
   const uint32_t q = blockIdx.x;
   if (MODE == 1 && repair && st.qflag[q] == 0) return;
   const uint32_t cap = st.cap;
+  const uint32_t lds_keys = min(cap, MAINT_LDS_KEYS);
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* hist = keys + cap;
-  uint32_t* sh = hist + 256;
-  const uint32_t n = min(st.cnt[q * CNT_STRIDE], cap);
-  if (MODE == 1 && st.cnt[q * CNT_STRIDE] > cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+  uint32_t* hist = keys + ((lds_keys + 3u) & ~3u);    // 1024 words, 16-byte aligned: one histogram per pass (block_kth_largest_f)
+  uint32_t* sh = hist + 1024;
+  // the per-query words this workgroup needs later are requested up front: each is a global round trip of its own
+  // otherwise, in the middle of the barrier chain
+  const uint32_t cnt_q = st.cnt[q * CNT_STRIDE];
+  const float margin_q = st.margin[q];
+  const float used_thr = st.thr[q];
+  const float thr2_q = st.thr2[q];
+  const uint32_t lad_cnt_q = st.lad_cnt ? st.lad_cnt[q] : 0u;
+  const uint32_t n = min(cnt_q, cap);
+  if (MODE == 1 && cnt_q > cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
   uint64_t* gsurv = st.surv + (uint64_t)q * cap;
   uint64_t ent[PT];
 #pragma unroll
   for (int j = 0; j < PT; ++j) {
     const uint32_t i = threadIdx.x + j * MAINT_THREADS;
     ent[j] = (i < n) ? gsurv[i] : 0ull;
-    if (i < n) keys[i] = f2key(entry_score(ent[j]));
+    if (i < n && i < lds_keys) keys[i] = f2key(entry_score(ent[j]));
   }
+  auto rest_at = [&](uint32_t i) -> uint32_t { return f2key(entry_score(gsurv[i])); };       // keys beyond the LDS part
+  auto key_at = [&](uint32_t i) -> uint32_t { return i < lds_keys ? keys[i] : rest_at(i); };
+  if (dbg_phase == 1) { if (ent[0] == 1ull && n == 0xFFFFFFFFu) st.flags[3] = 1; return; }
   if (threadIdx.x == 0) { sh[2] = 0; sh[3] = 0; }
   __syncthreads();                                  // all entries are in registers from here on
   float L = -INFINITY;
   uint32_t keyL = 0;
   if (n >= (uint32_t)k) {
-    keyL = block_kth_largest(keys, n, (uint32_t)k, hist, sh);
+    keyL = block_kth_largest_f(keys, lds_keys, rest_at, n, (uint32_t)k, hist);
     L = key2f(keyL);
   }
-  float thr_new = L - st.margin[q];
+  float thr_new = L - margin_q;
   float thr2 = thr_new;
+  if (dbg_phase == 2) { if (threadIdx.x == 0) l_local[q] = L; return; }
   if (MODE == 0 && spec_r > 0 && n >= (uint32_t)k) {
     // the spec_r-th and (4 spec_r)-th largest lie among the keys >= keyL (spec_r, 4 spec_r < k): gather those (k plus
     // ties, normally ~k) into the histogram scratch and rank them by counting instead of two more full radix selects
@@ -220,9 +263,9 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     if (threadIdx.x == 0) sh[3] = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-      if (keys[i] >= keyL) {
+      if (key_at(i) >= keyL) {
         const uint32_t pos = atomicAdd(&sh[3], 1u);
-        if (pos < 256) hist[pos] = keys[i];
+        if (pos < 256) hist[pos] = key_at(i);
       }
     __syncthreads();
     const uint32_t m = sh[3];
@@ -238,24 +281,24 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
           if (want[t] < (uint32_t)k && gt < want[t] && want[t] <= ge) sh[4 + t] = me;
       }
       __syncthreads();
-      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(sh[4]) - st.margin[q]);
-      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(sh[5]) - st.margin[q]);
+      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(sh[4]) - margin_q);
+      if (4 * spec_r < k) thr2 = fmaxf(thr2, key2f(sh[5]) - margin_q);
     } else {                                        // a crowd of ties at the K-th score: plain selects
-      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest(keys, n, (uint32_t)spec_r, hist, sh)) - st.margin[q]);
+      if (spec_r < k) thr_new = fmaxf(thr_new, key2f(block_kth_largest_f(keys, lds_keys, rest_at, n, (uint32_t)spec_r, hist)) - margin_q);
       if (4 * spec_r < k)
-        thr2 = fmaxf(thr2, key2f(block_kth_largest(keys, n, (uint32_t)(4 * spec_r), hist, sh)) - st.margin[q]);
+        thr2 = fmaxf(thr2, key2f(block_kth_largest_f(keys, lds_keys, rest_at, n, (uint32_t)(4 * spec_r), hist)) - margin_q);
     }
     if (threadIdx.x == 0) sh[3] = 0;
     __syncthreads();
   }
   bool failed = false;
   if (MODE == 1 && spec) {
-    const float used = st.thr[q];
+    const float used = used_thr;
     // ladder validated: >= K rows with approx >= t_c were emitted, so L >= t_c and every row with approx >= t_c - margin
     // (the tightest threshold any wave applied) is among the survivors: nothing speculative is left to verify
-    const bool lad_ok = st.lad_cnt && !repair && st.lad_cnt[q] >= (uint32_t)k && n >= (uint32_t)k;
-    failed = !lad_ok && (used > -INFINITY) && !(n >= (uint32_t)k && L - st.margin[q] >= used);
-    if (failed) thr_new = st.thr2[q];
+    const bool lad_ok = st.lad_cnt && !repair && lad_cnt_q >= (uint32_t)k && n >= (uint32_t)k;
+    failed = !lad_ok && (used > -INFINITY) && !(n >= (uint32_t)k && L - margin_q >= used);
+    if (failed) thr_new = thr2_q;
   }
   float* tv = topvals + (uint64_t)q * k;
 #pragma unroll
@@ -281,6 +324,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     }
   }
   __syncthreads();
+  if (dbg_phase == 3) return;
   if (MODE == 1) {
     const uint32_t have = (n >= (uint32_t)k) ? sh[3] : n;
     const float fill = (n >= (uint32_t)k) ? L : -INFINITY;
@@ -308,15 +352,17 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
       st.thr[q] = thr_new;
       st.cnt[q * CNT_STRIDE] = sh[2];
     }
+    // statistics: per-query accumulators, written by this workgroup only (an atomic on ONE word from every workgroup of
+    // the launch serialises at the memory side: 2 x 1024 x ~12 ns was 15 us of this kernel's 30)
     if (MODE == 1 && stats2 && !failed)        // survivors = entries the filter kept (before the cut at L - margin)
-      atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[0]), (unsigned long long)n);
+      stats2[2 * q] += (uint64_t)n;
     if (MODE == 1 && cand_rows) {
       // a query whose speculative threshold failed has no candidate list yet (the repair launch writes it; if that fails
       // too the batch is flagged and answered again): its count must still be defined, the re-score reads it
       const uint32_t nc = failed ? 0u : min(sh[2], rcap);
       if (!failed && sh[2] > rcap) atomicOr(st.flags, FLAG_CAND_OVERFLOW);
       cand_cnt[q] = nc;
-      if (stats2 && nc) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[1]), (unsigned long long)nc);
+      if (stats2 && nc) stats2[2 * q + 1] += (uint64_t)nc;
     }
   }
 }
@@ -324,11 +370,11 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows, uint32_t* cand_cnt, uint32_t rcap) {
-  const size_t lds = (size_t)st.cap * 4 + 256 * 4 + 32;      // keys | hist[256] | sh[8]
+  const size_t lds = (size_t)std::min<uint32_t>(st.cap, MAINT_LDS_KEYS) * 4 + 16 + 1024 * 4 + 32;     // keys | hist[1024] | sh[8]
   auto go = [&](auto kern) {
     ensure_dynamic_lds((const void*)kern);                     // survivor_cap = 16384 needs 66.6 KB
     hipLaunchKernelGGL(kern, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local, stats2, spec_r, spec,
-                       repair, cond, cand_rows, cand_cnt, rcap);
+                       repair, cond, cand_rows, cand_cnt, rcap, g_tail_debug_phase);
   };
   const uint32_t per_thread = (st.cap + MAINT_THREADS - 1) / MAINT_THREADS;
   if (mode == 0) {
@@ -353,11 +399,12 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
-                                                                        int32_t lad_r, int32_t f32_scores) {
+                                                                        int32_t lad_r, int32_t f32_scores, int dbg_phase) {
   __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
-  __shared__ uint32_t hist[256];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[1024];   // the select's histograms; first 256 words: gather buffer
   __shared__ uint32_t sh[8];
   const uint32_t q = blockIdx.x;
+  const float margin_q = st.margin[q], thr_in = st.thr[q];    // requested up front (thread 0 needs them at the very end)
   const uint32_t n = min(st.cnt[q * CNT_STRIDE], (uint32_t)(SAMP_THREADS * SAMP_PER_THREAD));
   const uint64_t* gsurv = st.surv + (uint64_t)q * st.cap;
   uint32_t kv[SAMP_PER_THREAD];
@@ -369,13 +416,15 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     kv[j] = (i < n) ? f2key(f32_scores ? reinterpret_cast<const float*>(gsurv)[i] : entry_score(gsurv[i])) : 0u;
     kmax = max(kmax, kv[j]);
   }
+  if (dbg_phase == 1) { if (kmax == 1u && n == 0xFFFFFFFFu) st.flags[3] = 1; return; }
   const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);   // wanted ranks, w1 <= w2 <= 256
   uint32_t* maxima = keys;                                  // 512 keys
   maxima[threadIdx.x] = kmax;
   if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
   __syncthreads();
-  const uint32_t t0 = block_kth_largest(maxima, SAMP_THREADS, w2, hist, sh);
+  const uint32_t t0 = block_kth_largest(maxima, SAMP_THREADS, w2, hist);
   __syncthreads();
+  if (dbg_phase == 2) { if (threadIdx.x == 0 && t0 == 1u) st.flags[3] = 1; return; }
 #pragma unroll
   for (int j = 0; j < SAMP_PER_THREAD; ++j)
     if (kv[j] >= t0 && kv[j] != 0u) {
@@ -403,16 +452,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
 #pragma unroll
     for (int j = 0; j < SAMP_PER_THREAD; ++j) keys[threadIdx.x + j * SAMP_THREADS] = kv[j];
     __syncthreads();
-    key1 = block_kth_largest(keys, n, w1, hist, sh);
-    key2 = block_kth_largest(keys, n, w2, hist, sh);
-    if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist, sh);
+    key1 = block_kth_largest(keys, n, w1, hist);
+    key2 = block_kth_largest(keys, n, w2, hist);
+    if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist);
   }
   if (threadIdx.x == 0) {
-    const float margin = st.margin[q];
+    const float margin = margin_q;
     // thr = score(r) - margin (>= the rigorous L_sample - margin since r < K); thr2 = score(min(4r, K)) - margin
     // minus the margin: the verification asks for L - margin >= thr, and L >= score(r) is what the rank guarantees
     const float thr = key2f(key1) - margin, thr2 = key2f(key2) - margin;
-    const bool excluded = st.thr[q] == INFINITY;                       // query excluded at init (range overflow)
+    const bool excluded = thr_in == INFINITY;                          // query excluded at init (range overflow)
     st.thr[q] = excluded ? INFINITY : thr;
     st.thr2[q] = excluded ? INFINITY : thr2;
     st.cnt[q * CNT_STRIDE] = 0;
@@ -437,13 +486,17 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
                              int32_t lad_r, int32_t f32_scores) {
   if (first_cnt == SAMP_THREADS * 2u)
-    hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
+    hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
+                       g_tail_debug_phase);
   else if (first_cnt == SAMP_THREADS * 4u)
-    hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
+    hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
+                       g_tail_debug_phase);
   else if (first_cnt == SAMP_THREADS * 8u)
-    hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
+    hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
+                       g_tail_debug_phase);
   else
-    hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores);
+    hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
+                       g_tail_debug_phase);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,7 +526,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(QueryState st, c
   if (threadIdx.x == 0) {
     if (counter > rcap) atomicOr(st.flags, FLAG_CAND_OVERFLOW);
     cand_cnt[q] = min(counter, rcap);
-    if (stats2) atomicAdd(reinterpret_cast<unsigned long long*>(&stats2[1]), (unsigned long long)min(counter, rcap));
+    if (stats2) stats2[2 * q + 1] += (uint64_t)min(counter, rcap);      // per-query accumulator (one writer)
   }
 }
 
@@ -652,70 +705,94 @@ void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int3
 // ------------------------------------------------------------------------------------------------
 // Final order of one query's candidates: (exact f64 score desc, NaN last, ties to the lower row id) -- a strict total
 // order, since the row ids of a list are distinct -- and the first k of it.  The place of a candidate is the number of
-// candidates that come before it, so every thread COUNTS the place of its candidates against the list staged in LDS
-// (tiles of EMIT_TILE entries; ~127 candidates per query at K = 100: one tile, ~127 broadcast reads per thread) and
-// writes them straight to their output slots.  No sorting network, no barriers beyond the staging, 6 KiB of LDS per
-// workgroup whatever rescore_cap is (the bitonic sort it replaces staged rcap * 12 bytes -- 24 KiB -- per workgroup and
-// took 20 us per 1024-query batch; same order, bit for bit: bitonic_sort_desc used the same comparison).
+// candidates that come before it, so the threads COUNT places against the list staged in LDS (tiles of EMIT_TILE
+// entries) and write every candidate straight to its output slot: no sorting network, two barriers, 6 KiB of LDS per
+// workgroup whatever rescore_cap is.  Scores are staged as order-preserving 64-bit integer keys (NaN -> 0, i.e. last;
+// -0.0 counted as +0.0), so one comparison is two integer compares, and with <= 128 candidates (~127 at K = 100) two
+// threads share a candidate, each counting against half of the list.  Same order, bit for bit, as the bitonic sort this
+// replaces (which staged rcap * 12 bytes -- 24 KiB -- per workgroup); 17 -> 8 us per 1024-query batch in isolation
+// (scripts/tailbench.hip).
 constexpr uint32_t EMIT_TILE = 512;
+__device__ __forceinline__ uint64_t emit_key(double s) {
+  if (s != s) return 0ull;                                    // NaN: after everything
+  if (s == 0.0) return 0x8000000000000000ull;                 // +0.0 and -0.0 compare equal
+  const uint64_t b = (uint64_t)__double_as_longlong(s);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ cand_rows,
                                                    const uint32_t* __restrict__ cand_cnt,
                                                    const double* __restrict__ cand_score, uint32_t rcap, int32_t k,
                                                    int64_t row_offset, int64_t* __restrict__ out_idx,
                                                    float* __restrict__ out_score, double* __restrict__ out_score64) {
-  __shared__ __attribute__((aligned(16))) double ts[EMIT_TILE];
+  __shared__ __attribute__((aligned(16))) uint64_t tk[EMIT_TILE];
   __shared__ __attribute__((aligned(16))) uint32_t ti[EMIT_TILE];
+  __shared__ uint32_t partial[256];
   const uint32_t q = blockIdx.x;
-  const uint32_t nc = min(cand_cnt[q], rcap);
   const double* qs = cand_score + (uint64_t)q * rcap;
   const uint32_t* qi = cand_rows + (uint64_t)q * rcap;
+  // the count and this thread's first list entry are requested together (the list has rcap >= 64 slots whatever the count:
+  // reading slot threadIdx.x is in bounds; what it holds is ignored when the slot is beyond the count) -- one global round
+  // trip instead of two in a kernel that is nothing but a chain of them
+  const uint32_t nc_raw = cand_cnt[q];
+  const bool pre_ok = threadIdx.x < rcap;
+  const double s_pre = pre_ok ? qs[threadIdx.x] : 0.0;
+  const uint32_t i_pre = pre_ok ? qi[threadIdx.x] : 0u;
+  const uint32_t nc = min(nc_raw, rcap);
   // slots no candidate claims (fewer than k candidates): padding
   for (uint32_t i = nc + threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
     out_idx[(uint64_t)q * k + i] = -1;
     if (out_score) out_score[(uint64_t)q * k + i] = -INFINITY;
     if (out_score64) out_score64[(uint64_t)q * k + i] = -INFINITY;
   }
-  for (uint32_t i0 = 0; i0 < nc; i0 += blockDim.x) {          // my candidate of this sweep (one sweep when nc <= 256)
-    const uint32_t i = i0 + threadIdx.x;
+  const uint32_t parts = (nc <= 128u) ? 2u : 1u;              // threads per candidate
+  const uint32_t per = 256u / parts;                          // candidates per sweep
+  const uint32_t local = threadIdx.x & (per - 1u), part = threadIdx.x / per;
+  for (uint32_t i0 = 0; i0 < nc; i0 += per) {                 // one sweep unless there are more than 256 candidates
+    const uint32_t i = i0 + local;
     const bool mine = i < nc;
-    const double a = mine ? qs[i] : 0.0;
-    const uint32_t ia = mine ? qi[i] : 0u;
-    const bool a_nan = (a != a);
+    double a = 0.0;
+    uint32_t ia = 0u;
+    uint64_t ka = 0ull;
+    bool have_a = false;
     uint32_t place = 0;
     for (uint32_t t0 = 0; t0 < nc; t0 += EMIT_TILE) {
       const uint32_t tn = min(EMIT_TILE, nc - t0), tn4 = (tn + 3u) & ~3u;
-      __syncthreads();                                        // the previous tile has been read by everybody
+      __syncthreads();                                        // the previous tile (and `partial`) has been read by everybody
       for (uint32_t e = threadIdx.x; e < tn4; e += blockDim.x) {
-        // padding to a multiple of four: (NaN, largest id) comes before nothing -- not before a number, and not before
-        // another NaN either (its id is the largest)
-        ts[e] = e < tn ? qs[t0 + e] : __longlong_as_double(0x7FF8000000000000ll);
-        ti[e] = e < tn ? qi[t0 + e] : 0xFFFFFFFFu;
+        // padding to a multiple of four never counts: key 0 with the largest id comes before nothing
+        const bool reg = (t0 == 0 && e == threadIdx.x);       // the first 256 entries of the list are in registers
+        tk[e] = e < tn ? emit_key(reg ? s_pre : qs[t0 + e]) : 0ull;
+        ti[e] = e < tn ? (reg ? i_pre : qi[t0 + e]) : 0xFFFFFFFFu;
       }
+      partial[threadIdx.x] = 0;
       __syncthreads();
+      if (mine && !have_a) {                                  // my candidate: from the staged tile when it lies in it
+        if (i >= t0 && i < t0 + tn) { ka = tk[i - t0]; ia = ti[i - t0]; }
+        else { ka = emit_key(qs[i]); ia = qi[i]; }
+        have_a = true;
+      }
       if (mine) {
-        // four entries per step as three 16-byte LDS reads (every lane reads the same address: a broadcast), two steps
-        // in flight: the loop is a chain of LDS round trips otherwise
+        // this thread's share of the tile: `parts` contiguous chunks of whole 4-entry groups; four entries per step as three
+        // 16-byte LDS reads (broadcasts), two steps in flight
+        const uint32_t groups = tn4 >> 2, g0 = groups * part / parts, g1 = groups * (part + 1u) / parts;
 #pragma unroll 2
-        for (uint32_t e = 0; e < tn4; e += 4) {
-          const double2 b01 = *reinterpret_cast<const double2*>(ts + e), b23 = *reinterpret_cast<const double2*>(ts + e + 2);
+        for (uint32_t e = g0 * 4u; e < g1 * 4u; e += 4) {
+          const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(tk + e), k23 = *reinterpret_cast<const ulonglong2*>(tk + e + 2);
           const uint4 id4 = *reinterpret_cast<const uint4*>(ti + e);
-          const double bs[4] = {b01.x, b01.y, b23.x, b23.y};
-          const uint32_t is[4] = {id4.x, id4.y, id4.z, id4.w};
+          const uint64_t kb[4] = {k01.x, k01.y, k23.x, k23.y};
+          const uint32_t ib[4] = {id4.x, id4.y, id4.z, id4.w};
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double b = bs[u];
-            const uint32_t ib = is[u];
-            // "b comes before a": higher score first, NaN last, ties to the lower id (a itself never counts: ib == ia)
-            const bool b_nan = (b != b);
-            bool b_first;
-            if (a_nan || b_nan) b_first = (!b_nan && a_nan) || (a_nan && b_nan && ib < ia);
-            else b_first = (b > a) || (b == a && ib < ia);
-            place += b_first ? 1u : 0u;
-          }
+          for (int u = 0; u < 4; ++u) place += ((kb[u] > ka) || (kb[u] == ka && ib[u] < ia)) ? 1u : 0u;   // "b comes before a"
         }
       }
     }
-    if (mine && place < (uint32_t)k) {
+    if (parts == 2u) {                                        // (block-uniform) combine the two halves of a candidate
+      if (mine && part == 1u) partial[local] = place;
+      __syncthreads();
+      if (mine && part == 0u) place += partial[local];
+    }
+    if (mine && part == 0u && place < (uint32_t)k) {
+      a = (i < 256u && i == threadIdx.x) ? s_pre : qs[i];
       out_idx[(uint64_t)q * k + place] = row_offset + (int64_t)ia;
       if (out_score) out_score[(uint64_t)q * k + place] = (float)a;
       if (out_score64) out_score64[(uint64_t)q * k + place] = a;
@@ -739,20 +816,19 @@ __global__ __launch_bounds__(256) void kth_of_gathered_kernel(const float* __res
   const uint32_t q = blockIdx.x;
   const uint32_t n = (uint32_t)nshards * (uint32_t)k;
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* hist = keys + n;
-  uint32_t* sh = hist + 256;
+  uint32_t* hist = keys + ((n + 3u) & ~3u);               // 16-byte aligned (the select reads its bins as uint4)
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t s = i / k, e = i % k;
     keys[i] = f2key(gathered[((uint64_t)s * nq + q) * k + e]);
   }
   __syncthreads();
-  const uint32_t key = block_kth_largest(keys, n, (uint32_t)k, hist, sh);
+  const uint32_t key = block_kth_largest(keys, n, (uint32_t)k, hist);
   if (threadIdx.x == 0) out_L[q] = key2f(key);
 }
 
 void launch_kth_of_gathered(const float* gathered, int32_t nshards, int64_t nq, int32_t k, float* out_L,
                             hipStream_t stream) {
-  const size_t lds = (size_t)nshards * k * 4 + 256 * 4 + 16;
+  const size_t lds = (size_t)nshards * k * 4 + 16 + 1024 * 4 + 16;
   ensure_dynamic_lds((const void*)kth_of_gathered_kernel);
   hipLaunchKernelGGL(kth_of_gathered_kernel, dim3((unsigned)nq), dim3(256), lds, stream, gathered, nshards, nq, k,
                      out_L);

@@ -15,7 +15,8 @@ for name in ("q1", "q70", "bf16", "aqe", "aqe_rparis", "10m"):
         shutil.copy(max(st, key=os.path.getmtime), os.path.join(pr, f"{tag}_{name}_kernel_stats.csv"))
 for f in ("timeline_full.txt", "timeline_s8.txt", "rank_all.txt", "host_api.txt", "gallery_io.json", "xcc_report.txt",
           "diffusion_refsize.txt", "mfma_probe.txt", "kbench.txt", "rehearse2.txt", "rehearse4.txt", "ladder_probe.txt",
-          "shard_model.txt", "protocol_rccl1.txt", "layout_model.txt", "rehearse4_rows_pipelined.txt"):
+          "shard_model.txt", "protocol_rccl1.txt", "layout_model.txt", "rehearse4_rows_pipelined.txt", "tile4_probe.txt",
+          "kbench_thr.txt", "bare_gpus2.txt", "graph_replay.txt", "timeline_q1.txt", "timeline_q70.txt"):
     src = os.path.join(go, f"{tag}_{f}")
     if os.path.exists(src) and os.path.getsize(src) < 200000:
         text = open(src, errors="replace").read()

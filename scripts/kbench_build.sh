@@ -8,4 +8,6 @@ python -c "import sys; sys.path.insert(0, '.'); import __graft_entry__ as g; g.b
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 scripts/mfma_probe.hip -o $pkg/build/mfma_probe
 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -std=c++17 scripts/denorm_probe.hip -o $pkg/build/denorm_probe 2> /dev/null
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 scripts/tile4_probe.hip -o $pkg/build/tile4_probe
-echo built $pkg/build/kbench $pkg/build/mfma_probe $pkg/build/denorm_probe $pkg/build/tile4_probe
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 scripts/tailbench.hip -L$pkg -lmi355_retrieval \
+  -Wl,-rpath,'$ORIGIN/..' -o $pkg/build/tailbench
+echo built $pkg/build/tailbench $pkg/build/kbench $pkg/build/mfma_probe $pkg/build/denorm_probe $pkg/build/tile4_probe

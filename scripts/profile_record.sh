@@ -7,7 +7,9 @@ o=gpurun_out
 # 1. headline bench + its rocprofv3 kernel trace + PMC passes (separate runs, as the microarchitecture guide prescribes)
 python bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err            # the driver's default invocation: 200 steps
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -- python3 bench.py --scale-10m off --no-cpu-baseline > $o/${tag}_trace.log 2>&1
+# the SAME command under the profiler (minus the host-side CPU baseline): headline + the 10 M-row secondary block, whose bf16 launches
+# are other template instantiations of the kernels and get rows of their own in the statistics
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -- python3 bench.py --no-cpu-baseline > $o/${tag}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $o/${tag}_pmc_l2 -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_l2.log 2>&1
@@ -23,6 +25,8 @@ done
 # 3. timelines (per-dispatch) of the full gallery and of a 1/8 shard; scripts
 bash scripts/timeline.sh ${tag}_full > $o/${tag}_timeline_full.txt 2>&1 || true
 bash scripts/timeline.sh ${tag}_s8 --rows 125750 > $o/${tag}_timeline_s8.txt 2>&1 || true
+bash scripts/timeline.sh ${tag}_q1 --queries 1 > $o/${tag}_timeline_q1.txt 2>&1 || true
+bash scripts/timeline.sh ${tag}_q70 --queries 70 > $o/${tag}_timeline_q70.txt 2>&1 || true
 python scripts/rank_all_timing.py > $o/${tag}_rank_all.txt 2>&1 || true
 python scripts/host_api_rate.py > $o/${tag}_host_api.txt 2>&1 || true
 python scripts/gallery_io_rate.py > $o/${tag}_gallery_io.json 2> /dev/null || true
@@ -36,9 +40,14 @@ echo "scripts done"
 # 4. kernel A/B driver and MFMA probe (C++, no torch)
 bash scripts/kbench_build.sh > /dev/null 2>&1 || true    # the driver shares struct layouts with the library: never run a stale one
 (cd image-search-engine-for-historical-research_amd && ./build/mfma_probe > ../$o/${tag}_mfma_probe.txt 2>&1 || true)
-(cd image-search-engine-for-historical-research_amd && ./build/kbench --rounds 4 --reps 5 default:0 structure1:0:1 nofilter:4 nofilter_s1:4:1 nodma:5 nodma_nofrag:133 filter_stamps:2048 > ../$o/${tag}_kbench.txt 2>&1 || true)
+(cd image-search-engine-for-historical-research_amd && timeout -k 10 300 ./build/kbench --rounds 4 --reps 5 default:0 structure1:0:1 zc:0:5 zc_inter:0:6 inter:0:7 nofilter:4 nofilter_s1:4:1 nodma:5 nodma_nofrag:133 filter_stamps:2048 stamps_inter:2048:6 > ../$o/${tag}_kbench.txt 2>&1 || true)
+(cd image-search-engine-for-historical-research_amd && timeout -k 10 200 ./build/tile4_probe --rounds 3 --reps 5 > ../$o/${tag}_tile4_probe.txt 2>&1 || true)
+(cd image-search-engine-for-historical-research_amd && for t in 0.0663 0.0700 0.0760; do timeout -k 10 100 ./build/kbench --rounds 2 --reps 5 --thr $t default:0 | tail -1; done > ../$o/${tag}_kbench_thr.txt 2>&1 || true)
 # 5. multi-rank rehearsal of bench.py (ranks share the GPU, gloo)
 bash scripts/rehearse_sharded.sh 2 > $o/${tag}_rehearse2.txt 2>&1 || true
 bash scripts/rehearse_sharded.sh 4 > $o/${tag}_rehearse4.txt 2>&1 || true
 bash scripts/rehearse_sharded.sh 4 --layout 1x4 --pipeline > $o/${tag}_rehearse4_rows_pipelined.txt 2>&1 || true
+# bench.py --gpus 2 started BARE (it starts its two ranks itself); ranks share the GPU over gloo; secondary block at 600 k rows
+(ISEHR_DIST_BACKEND=gloo ISEHR_SHARE_GPU=1 timeout -k 10 300 python bench.py --gpus 2 --rows 200000 --steps 6 --warmup 2 --no-cpu-baseline --scale-10m on --scale-10m-rows 600000 --scale-10m-steps 4 2> /dev/null | tail -1 | cut -c1-2500) > $o/${tag}_bare_gpus2.txt || true
+(timeout -k 10 300 python bench.py --graph --no-cpu-baseline 2> /dev/null | tail -1 | cut -c1-900) > $o/${tag}_graph_replay.txt || true
 echo "all done"
