@@ -16,7 +16,7 @@ for name in ("q1", "q70", "bf16", "aqe", "aqe_rparis", "10m"):
 for f in ("timeline_full.txt", "timeline_s8.txt", "rank_all.txt", "host_api.txt", "gallery_io.json", "xcc_report.txt",
           "diffusion_refsize.txt", "mfma_probe.txt", "kbench.txt", "rehearse2.txt", "rehearse4.txt", "ladder_probe.txt",
           "shard_model.txt", "protocol_rccl1.txt", "layout_model.txt", "rehearse4_rows_pipelined.txt", "tile4_probe.txt",
-          "kbench_thr.txt", "bare_gpus2.txt", "graph_replay.txt", "timeline_q1.txt", "timeline_q70.txt"):
+          "kbench_thr.txt", "bare_gpus2.txt", "tailbench.txt", "ab_r02.txt", "sweep_seeds.txt", "graph_replay.txt", "timeline_q1.txt", "timeline_q70.txt"):
     src = os.path.join(go, f"{tag}_{f}")
     if os.path.exists(src) and os.path.getsize(src) < 200000:
         text = open(src, errors="replace").read()

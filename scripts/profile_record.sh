@@ -42,6 +42,7 @@ bash scripts/kbench_build.sh > /dev/null 2>&1 || true    # the driver shares str
 (cd image-search-engine-for-historical-research_amd && ./build/mfma_probe > ../$o/${tag}_mfma_probe.txt 2>&1 || true)
 (cd image-search-engine-for-historical-research_amd && timeout -k 10 300 ./build/kbench --rounds 4 --reps 5 default:0 structure1:0:1 zc:0:5 zc_inter:0:6 inter:0:7 nofilter:4 nofilter_s1:4:1 nodma:5 nodma_nofrag:133 filter_stamps:2048 stamps_inter:2048:6 > ../$o/${tag}_kbench.txt 2>&1 || true)
 (cd image-search-engine-for-historical-research_amd && timeout -k 10 200 ./build/tile4_probe --rounds 3 --reps 5 > ../$o/${tag}_tile4_probe.txt 2>&1 || true)
+(cd image-search-engine-for-historical-research_amd && timeout -k 10 200 ./build/tailbench --reps 50 > ../$o/${tag}_tailbench.txt 2>&1 || true)
 (cd image-search-engine-for-historical-research_amd && for t in 0.0663 0.0700 0.0760; do timeout -k 10 100 ./build/kbench --rounds 2 --reps 5 --thr $t default:0 | tail -1; done > ../$o/${tag}_kbench_thr.txt 2>&1 || true)
 # 5. multi-rank rehearsal of bench.py (ranks share the GPU, gloo)
 bash scripts/rehearse_sharded.sh 2 > $o/${tag}_rehearse2.txt 2>&1 || true
@@ -50,4 +51,11 @@ bash scripts/rehearse_sharded.sh 4 --layout 1x4 --pipeline > $o/${tag}_rehearse4
 # bench.py --gpus 2 started BARE (it starts its two ranks itself); ranks share the GPU over gloo; secondary block at 600 k rows
 (ISEHR_DIST_BACKEND=gloo ISEHR_SHARE_GPU=1 timeout -k 10 300 python bench.py --gpus 2 --rows 200000 --steps 6 --warmup 2 --no-cpu-baseline --scale-10m on --scale-10m-rows 600000 --scale-10m-steps 4 2> /dev/null | tail -1 | cut -c1-2500) > $o/${tag}_bare_gpus2.txt || true
 (timeout -k 10 300 python bench.py --graph --no-cpu-baseline 2> /dev/null | tail -1 | cut -c1-900) > $o/${tag}_graph_replay.txt || true
+# 6. same-box A/B against the library of the previous round, when a build of it was left under ab/ (git-ignored)
+if [ -f ab/lib_r02.so ]; then
+  cp image-search-engine-for-historical-research_amd/libmi355_retrieval.so ab/lib_now.so
+  (for a in "" "--queries 70" "--queries 1"; do echo "# bench.py $a"; bash scripts/ab.sh ab/lib_r02.so ab/lib_now.so $a 2> /dev/null; done) > $o/${tag}_ab_r02.txt || true
+fi
+# 7. fuzzing: the shape sweep with four other seeds
+(for sd in 101 102 103 104; do ISEHR_SWEEP_SEED=$sd timeout -k 10 600 python -m pytest tests/test_gpu_shape_sweep.py -q 2>&1 | tail -1; done) > $o/${tag}_sweep_seeds.txt || true
 echo "all done"
