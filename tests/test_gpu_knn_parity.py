@@ -325,3 +325,38 @@ def test_raised_caps_answer_massive_ties_without_the_dense_path(lib):
     assert np.array_equal(idx[0], expect)
     s = oracle.exact_scores_f64(g, q)
     assert oracle.check_topk_parity(idx, s, k, TAU) == []
+
+
+def test_more_survivors_than_the_maintain_kernel_keeps_in_lds(lib):
+    """The final maintain launch keeps the first 8192 survivor keys of a query in LDS and reads the keys beyond from the
+    entries in global memory (csrc/select.hip MAINT_LDS_KEYS).  9000 gallery rows at graded similarity 0.5 .. 0.9 to the
+    query, none of them among the 8192 rows of the bootstrap sample (so the speculative threshold stays where random 64-d
+    rows put it, near 0.37), all pass the filter: the select runs over ~9500 keys with survivor_cap = 16384, while only
+    ~100 of them are candidates.  The answer must be the exact one and nothing may overflow."""
+    from isehr_amd._lib import Gallery
+    n, d, k = 60000, 64, 100
+    g = synth_rows(81, 0, n, d)
+    q = synth_rows(82, 0, 2, d)
+    qn = q[0] / np.linalg.norm(q[0])
+    rng = np.random.default_rng(9)
+    outside = np.setdiff1d(np.arange(n), lib.sample_source_rows(n))
+    rows = rng.choice(outside, size=9000, replace=False)
+    cosv = np.linspace(0.5, 0.9, 9000)
+    noise = synth_rows(83, 0, 9000, d).astype(np.float64)
+    noise -= (noise @ qn)[:, None] * qn[None, :]
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    g[rows] = (cosv[:, None] * qn[None, :] + np.sqrt(1 - cosv ** 2)[:, None] * noise).astype(np.float32) * 1.7
+    G = Gallery.from_host(g)
+    try:
+        G.set_option("survivor_cap", 16384)
+        G.set_option("exact_fallback", 0)                      # an overflow would be an error, not a silent fallback
+        G.status(reset=True)
+        idx, sc, _ = G.search(q, k)
+        st = G.status()
+        assert st["overflow_batches"] == 0
+        assert st["survivors"] / st["queries"] > 8192 / 2      # query 0 alone has > 9000 (query 1: the usual few hundred)
+    finally:
+        G.close()
+    assert set(idx[0]) == set(rows[-k:])                       # the hundred most similar planted rows
+    s = oracle.exact_scores_f64(g, q)
+    assert oracle.check_topk_parity(idx, s, k, TAU) == []
