@@ -256,8 +256,31 @@ bool stream_bootstrap_applies(const ScoreArgs& a) { return a.small_batch_kernel 
 void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream) {
   // bootstrap launches are one workgroup per (sample tile, group of NQB * 16 queries): with <= 512 queries the narrower
   // group fills the 256 CUs (32 tiles x 8 groups) where the wider one would leave half of them idle for a whole tile time
-  if (a.nq <= 64 || (first && a.nq <= 512)) a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
-  else a.img_f16 ? launch_stream_mode<8, true>(a, first, stream) : launch_stream_mode<8, false>(a, first, stream);
+  if (first) {
+    if (a.nq <= 512) a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
+    else a.img_f16 ? launch_stream_mode<8, true>(a, first, stream) : launch_stream_mode<8, false>(a, first, stream);
+    return;
+  }
+  // filtered launches: as many blocks of 16 query slots as the batch needs, at least four (the reference's online stage has 1
+  // query, its test sets 70: src/online.py:132-147, src/test_rOP1m.py:144-149) -- fewer MFMAs, fragment reads and query
+  // DMA per gallery slice in a kernel that should wait for HBM only.  Same box, alternating builds
+  // (profiles/r03b_qsweep_ab.txt): 70 queries 0.675 -> 0.637 ms with 5 blocks instead of 8, 100 queries 0.691 -> 0.669 with
+  // 7; fewer than four blocks buy nothing (16 queries: 0.611 ms with one block, 0.602 with four)
+  switch ((a.nq + 15) / 16) {
+#define MI_STREAM_CASE(N)                                                                                              \
+  case N:                                                                                                              \
+    a.img_f16 ? launch_stream_mode<N, true>(a, first, stream) : launch_stream_mode<N, false>(a, first, stream);       \
+    break;
+    MI_STREAM_CASE(5)
+    MI_STREAM_CASE(6)
+    MI_STREAM_CASE(7)
+    case 8:
+      a.img_f16 ? launch_stream_mode<8, true>(a, first, stream) : launch_stream_mode<8, false>(a, first, stream);
+      break;
+    default:
+      a.img_f16 ? launch_stream_mode<4, true>(a, first, stream) : launch_stream_mode<4, false>(a, first, stream);
+#undef MI_STREAM_CASE
+  }
 }
 
 }  // namespace mi

@@ -217,7 +217,7 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
     assert (st["overflow_batches"] >= 1) == expect_fallback
 
 
-@pytest.mark.parametrize("nq", [1, 16, 17, 64, 65, 70, 128, 129])
+@pytest.mark.parametrize("nq", [1, 16, 17, 64, 65, 70, 80, 81, 96, 97, 112, 113, 128, 129])
 def test_small_batch_kernel_equals_tile_kernel(lib, nq):
     """Batches of <= 128 queries are scored by the HBM-bound kernel of stream_select.hip (4 or 8 blocks of 16
     queries); it must produce the answers of the 256 x 256-tile kernel bit for bit, and the exact top-K."""
