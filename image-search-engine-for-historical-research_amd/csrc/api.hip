@@ -412,7 +412,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     if (!first_chunk)
       launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s,
                              (g->xcc_balance && !on_sample && !stream_select_applies(a)) ? ws.bal : nullptr, ws.dbg,
-                             (uint32_t)ntile);
+                             (uint32_t)ntile, nq);
   };
   if (samp_r > 0) {
     score_launch(0, t0, true, nullptr, false, true);                           // bootstrap on the sample image

@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void scatter_records_kernel(const 
                                                                           const uint32_t* __restrict__ cond,
                                                                           XccBalance* __restrict__ bal,
                                                                           const unsigned long long* __restrict__ dbg,
-                                                                          uint32_t nseg) {
+                                                                          uint32_t nseg, uint32_t group) {
   __shared__ uint32_t hist[1024];                          // per query of the batch (QB = 1024): count, then base
   if (cond && *cond == 0) return;
   if (bal && blockIdx.x == 0) {
@@ -1109,46 +1109,68 @@ __global__ __launch_bounds__(SCATTER_THREADS) void scatter_records_kernel(const 
     for (uint32_t i = threadIdx.x; i < 16; i += SCATTER_THREADS) hist[i] = 0;
     __syncthreads();
   }
-  const uint32_t seg = blockIdx.x;
-  const uint32_t n = min(rec_cnt[seg], (uint32_t)(SCATTER_THREADS * SCATTER_PER_THREAD));
-  if (n == 0) return;
-  const SurvRec* r = rec + (uint64_t)seg * rec_cap;
-  for (uint32_t i = threadIdx.x; i < 1024; i += SCATTER_THREADS) hist[i] = 0;
-  __syncthreads();
-  SurvRec e[SCATTER_PER_THREAD];
-  uint32_t rank[SCATTER_PER_THREAD];
-#pragma unroll
-  for (int j = 0; j < SCATTER_PER_THREAD; ++j) {
-    const uint32_t i = threadIdx.x + j * SCATTER_THREADS;
-    if (i < n) {
-      e[j] = r[i];
-      rank[j] = atomicAdd(&hist[e[j].q & 1023u], 1u);
+  // `group` consecutive segments (the 8 waves of one scoring workgroup when the batch is small) form ONE list for this
+  // workgroup: with few queries every segment holds records of the SAME queries, and one global atomic per (segment, query)
+  // would put 2048 adds on each query's counter -- 15-25 us of same-address atomics at 1..128 queries (scripts/timeline.sh)
+  __shared__ uint32_t pre[9];                              // prefix of the group's segment counts
+  const uint32_t seg0 = blockIdx.x * group;
+  const uint32_t CAP = (uint32_t)(SCATTER_THREADS * SCATTER_PER_THREAD);
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t g = 0; g < group; ++g) {
+      pre[g] = acc;
+      acc += (seg0 + g < nseg) ? min(rec_cnt[seg0 + g], CAP) : 0u;
     }
+    pre[group] = acc;
   }
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < 1024; q += SCATTER_THREADS) {
-    const uint32_t c = hist[q];
-    if (c) hist[q] = atomicAdd(&st.cnt[q * CNT_STRIDE], c);
-  }
-  __syncthreads();
+  const uint32_t total = pre[group];
+  if (total == 0) return;
+  for (uint32_t base = 0; base < total; base += CAP) {     // one round unless the group holds more than 4096 records
+    const uint32_t n = min(total - base, CAP);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 1024; i += SCATTER_THREADS) hist[i] = 0;
+    __syncthreads();
+    SurvRec e[SCATTER_PER_THREAD];
+    uint32_t rank[SCATTER_PER_THREAD];
 #pragma unroll
-  for (int j = 0; j < SCATTER_PER_THREAD; ++j) {
-    const uint32_t i = threadIdx.x + j * SCATTER_THREADS;
-    if (i < n) {
-      const uint32_t pos = hist[e[j].q & 1023u] + rank[j];
-      if (pos < st.cap) st.surv[(uint64_t)e[j].q * st.cap + pos] = pack_entry(e[j].score, e[j].row);
-      else atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+    for (int j = 0; j < SCATTER_PER_THREAD; ++j) {
+      const uint32_t i = threadIdx.x + j * SCATTER_THREADS;
+      if (i < n) {
+        const uint32_t v = base + i;
+        uint32_t g = 0;
+        while (g + 1 < group && v >= pre[g + 1]) ++g;
+        e[j] = rec[(uint64_t)(seg0 + g) * rec_cap + (v - pre[g])];
+        rank[j] = atomicAdd(&hist[e[j].q & 1023u], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < 1024; q += SCATTER_THREADS) {
+      const uint32_t c = hist[q];
+      if (c) hist[q] = atomicAdd(&st.cnt[q * CNT_STRIDE], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SCATTER_PER_THREAD; ++j) {
+      const uint32_t i = threadIdx.x + j * SCATTER_THREADS;
+      if (i < n) {
+        const uint32_t pos = hist[e[j].q & 1023u] + rank[j];
+        if (pos < st.cap) st.surv[(uint64_t)e[j].q * st.cap + pos] = pack_entry(e[j].score, e[j].row);
+        else atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+      }
     }
   }
 }
 
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
                             QueryState st, const uint32_t* cond, hipStream_t stream, XccBalance* bal,
-                            const unsigned long long* dbg, uint32_t ntiles) {
+                            const unsigned long long* dbg, uint32_t ntiles, int32_t nq) {
   // shares are only re-measured on launches with enough tiles per XCD for the loop time to be a speed
   if (cond || !dbg || ntiles < 8u * 64u) bal = nullptr;
-  hipLaunchKernelGGL(scatter_records_kernel, dim3(nseg), dim3(SCATTER_THREADS), 0, stream, rec, rec_cnt, rec_cap, st, cond,
-                     bal, dbg, nseg);
+  // batches of <= 128 queries: one workgroup per scoring workgroup (its 8 wave segments as one list), see the kernel
+  const uint32_t group = (nq > 0 && nq <= STREAM_MAX_QUERIES) ? 8u : 1u;
+  hipLaunchKernelGGL(scatter_records_kernel, dim3((nseg + group - 1) / group), dim3(SCATTER_THREADS), 0, stream, rec, rec_cnt,
+                     rec_cap, st, cond, bal, dbg, nseg, group);
 }
 
 void init_xcc_balance_host(XccBalance* h) {

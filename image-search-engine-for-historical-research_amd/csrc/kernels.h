@@ -63,7 +63,7 @@ void take_launch_events(hipEvent_t* start, hipEvent_t* stop);
 // bal / dbg / ntiles non-null / non-zero: block 0 also updates the XCD shares from the loop times of the launch that wrote dbg
 void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_t rec_cap, uint32_t nseg,
                             QueryState st, const uint32_t* cond, hipStream_t stream, XccBalance* bal = nullptr,
-                            const unsigned long long* dbg = nullptr, uint32_t ntiles = 0);
+                            const unsigned long long* dbg = nullptr, uint32_t ntiles = 0, int32_t nq = 0);   // nq: queries of the batch
 void init_xcc_balance_host(XccBalance* host);
 
 // exact_score.hip -- f32 FMA scoring with the same filter (fallback / force_exact)
