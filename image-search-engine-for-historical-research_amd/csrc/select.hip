@@ -203,7 +203,8 @@ constexpr int MAINT_PER_THREAD_MAX = 32;        // 512 * 32 = 16384 = largest su
 //   approximate score >= thr, so if there are >= K of them L is the true K-th largest approximate score, and if also
 //   L - margin >= thr every candidate row is among them.  Otherwise the query is flagged for the repair pass
 //   (device-side, conditional launches, no host round trip); a query failing again raises FLAG_SPEC_FAIL.
-//   repair != 0: only flagged queries are processed.  cond: skip the launch when *cond == 0.
+//   repair == 1: the repair pass itself, only flagged queries are processed; repair == 2: no repair pass will follow (small
+//   batches, api.hip), a failed query raises FLAG_SPEC_FAIL at once.  cond: skip the launch when *cond == 0.
 // PT = entries per thread kept in registers (PT * 512 >= survivor_cap): 24 instead of 32 at the default cap frees the
 // registers for a second workgroup per CU in MODE 1
 template <int MODE, int PT>
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (cond && *cond == 0) return;
   const uint32_t q = blockIdx.x;
-  if (MODE == 1 && repair && st.qflag[q] == 0) return;
+  if (MODE == 1 && repair == 1 && st.qflag[q] == 0) return;      // repair pass: flagged queries only
   const uint32_t cap = st.cap;
   const uint32_t lds_keys = min(cap, MAINT_LDS_KEYS);
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     const float used = used_thr;
     // ladder validated: >= K rows with approx >= t_c were emitted, so L >= t_c and every row with approx >= t_c - margin
     // (the tightest threshold any wave applied) is among the survivors: nothing speculative is left to verify
-    const bool lad_ok = st.lad_cnt && !repair && lad_cnt_q >= (uint32_t)k && n >= (uint32_t)k;
+    const bool lad_ok = st.lad_cnt && repair != 1 && lad_cnt_q >= (uint32_t)k && n >= (uint32_t)k;
     failed = !lad_ok && (used > -INFINITY) && !(n >= (uint32_t)k && L - margin_q >= used);
     if (failed) thr_new = thr2_q;
   }
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
       st.thr2[q] = thr2;
       st.cnt[q * CNT_STRIDE] = spec ? 0u : sh[2];   // spec (MODE 0): entries came from the sample image, drop them
     } else if (spec) {
-      if (failed && !repair) {
+      if (failed && repair == 0) {                // repair == 2: no repair pass follows, the failure is final
         st.thr[q] = thr_new;                       // = thr2: the repair pass re-scans every tile for this query
         st.cnt[q * CNT_STRIDE] = 0;
         st.qflag[q] = 1;

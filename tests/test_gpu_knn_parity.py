@@ -189,12 +189,15 @@ def test_unnormalised_gallery_with_large_values_uses_bf16_image(lib):
     assert oracle.check_topk_parity(ranks.T, s64, 30, 1e-6 * float(np.abs(s64).max())) == []
 
 
-@pytest.mark.parametrize("ndup,expect_fallback", [(0, False), (30, False), (90, True)])
-def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallback):
+@pytest.mark.parametrize("ndup,device_repair,expect_fallback",
+                         [(0, 1, False), (30, 1, False), (90, 1, True), (0, -1, False), (30, -1, True), (30, 0, True)])
+def test_speculative_threshold_verification_and_repair(lib, ndup, device_repair, expect_fallback):
     """The single-launch schedule uses a speculative threshold taken from the bootstrap sample (32 tiles of 256 rows
     worth of rows drawn evenly from the gallery) and verifies it afterwards.  Near-duplicates of the query planted INSIDE the sample make that threshold too high:
     30 of them -> the device-side repair pass (looser threshold) must fix the query; 90 of them -> the repair fails
-    too and the host API falls back to the rigorous schedule.  Results must be exact in every case."""
+    too and the host API falls back to the rigorous schedule.  Batches of <= 128 queries (this one has 6) launch no repair
+    pass by default (option "device_repair" = -1): there a failed verification goes straight to the fallback.  Results
+    must be exact in every case."""
     from isehr_amd._lib import Gallery
     n, d, nq, k = 200000, 64, 6, 100
     g = synth_rows(71, 0, n, d)
@@ -207,7 +210,8 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, expect_fallbac
         g[r] = q[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
     G = Gallery.from_host(g)
     G.set_option("chunk0_tiles", 32)                        # the 8192-row sample the planted rows were drawn from
-    assert G.get_option("sample_rows") == 8192
+    G.set_option("device_repair", device_repair)
+    assert G.get_option("sample_rows") == 8192 and G.get_option("device_repair") == device_repair
     idx, sc, _ = G.search(q, k)
     st = G.status()
     G.close()
