@@ -104,6 +104,8 @@ struct mi_gallery {
   // options
   int chunk0_tiles = 0 /* 0 = default, bootstrap_tiles() */, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0,
       speculative = 1, rescore_grid_x = 0, spec_max_ratio = 160;
+  int small_tail = 0;           // 1: batches of <= 128 queries re-score and order in ONE launch (select.hip rescore_emit_kernel;
+                                // built, measured slower -- 39 vs 19.5 + 9 us at 70 queries -- and left off)
   int device_repair = -1;       // -1 = by batch size (off for <= 128 queries), 0 / 1 = never / always launch the conditional repair pass
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
@@ -508,6 +510,12 @@ static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev
   QueryState st = make_state(ws);
   if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
   const uint32_t last_row = (uint32_t)std::max<int64_t>(0, g->n - 1);
+  if (!resident && nq <= STREAM_MAX_QUERIES && g->small_tail) {      // option, off: re-score and final order in one launch
+    launch_rescore_emit(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, last_row, k,
+                        g->row_offset, out_idx, out_score, out_score64, s);
+    HIPC(hipGetLastError());
+    return MI_OK;
+  }
   if (resident) launch_rescore_resident(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
                                         last_row);
   else launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
@@ -1900,6 +1908,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "debug") *out_value = g->debug;
   else if (n == "speculative") *out_value = g->speculative;
   else if (n == "device_repair") *out_value = g->device_repair;
+  else if (n == "small_tail") *out_value = g->small_tail;
   else if (n == "small_batch_kernel") *out_value = g->small_batch_kernel;
   else if (n == "kernel_variant") *out_value = g->kernel_variant;
   else if (n == "xcc_balance") *out_value = g->xcc_balance;
@@ -1938,6 +1947,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "debug") g->debug = (int)value;
   else if (n == "speculative") g->speculative = value != 0;
   else if (n == "device_repair") g->device_repair = value < 0 ? -1 : (value != 0);
+  else if (n == "small_tail") g->small_tail = value != 0;
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;

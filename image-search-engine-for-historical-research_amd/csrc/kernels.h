@@ -102,6 +102,10 @@ void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int3
 void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                              const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
                              uint32_t last_row);
+// batches of <= STREAM_MAX_QUERIES queries: launch_rescore + launch_emit in one launch (one workgroup per query)
+void launch_rescore_emit(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
+                         const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, uint32_t last_row, int32_t k,
+                         int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64, hipStream_t stream);
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
                  int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score,
                  double* out_score64, hipStream_t stream);

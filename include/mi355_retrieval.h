@@ -262,7 +262,8 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
  * "device_repair" (-1 = default: batches of > 128 queries follow the scoring launch with a device-conditional repair pass
  * for queries whose speculative threshold failed verification, smaller batches raise the sticky flag at once and are
- * answered again; 0 / 1 = never / always launch the repair pass),
+ * answered again; 0 / 1 = never / always launch the repair pass), "small_tail" (1 = batches of <= 128 queries re-score and
+ * order in one launch; measured slower, default 0),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
  * already normalised expanded queries of alpha-QE), "kernel_variant" (structure of the tile kernel, A/B only).

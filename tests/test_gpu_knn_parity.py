@@ -364,3 +364,24 @@ def test_more_survivors_than_the_maintain_kernel_keeps_in_lds(lib):
     assert set(idx[0]) == set(rows[-k:])                       # the hundred most similar planted rows
     s = oracle.exact_scores_f64(g, q)
     assert oracle.check_topk_parity(idx, s, k, TAU) == []
+
+
+@pytest.mark.parametrize("nq", [1, 70])
+def test_one_launch_tail_option_gives_the_same_answers(lib, nq):
+    """Option "small_tail": exact re-score and final order of a small batch in ONE launch (one workgroup per query; measured
+    slower than the two launches and off by default) -- same candidates, same arithmetic, so the same bits."""
+    from isehr_amd._lib import Gallery
+    n, d, k = 50000, 256, 100
+    g = synth_rows(93, 0, n, d)
+    g[1000:1300] = g[7]                                     # 300 exact ties: more candidates than k, several per wave
+    q = np.concatenate([g[7:8], synth_rows(94, 0, max(1, nq - 1), d)])[:nq]
+    G = Gallery.from_host(g)
+    try:
+        idx0, sc0, _ = G.search(q, k)
+        G.set_option("small_tail", 1)
+        idx1, sc1, _ = G.search(q, k)
+        assert G.status()["overflow_batches"] == 0
+    finally:
+        G.close()
+    assert np.array_equal(idx0, idx1) and np.array_equal(sc0, sc1)
+    assert list(idx1[0][:3]) == [7, 1000, 1001]             # ties in index order
