@@ -100,3 +100,75 @@ def test_job_layout_covers_every_query_and_row_once():
     import pytest
     with pytest.raises(ValueError):
         job_layout(4, 0, 1024, "3x1")
+
+
+def _worker_layout(rank, world, port, layout, n, d, nq, k, ret):
+    """One rank of a gq x gs job: the rank's query group answers ITS slice of the batch against the gallery sharded over
+    the group's ranks, with the collectives of ShardedGallery (all_gather_stacked on the group) and the oracle standing in
+    for the per-shard GPU phases; plus the fixed-order sum of the sharded alpha-QE."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from isehr_amd.sharded import job_layout, layout_groups
+        gq, gs, qgroup, shard = job_layout(world, rank, nq, layout)
+        groups = layout_groups(gq, gs)                       # collective: every rank creates every group
+        group = groups[qgroup]
+        assert dist.get_world_size(group) == gs and dist.get_rank(group) == shard
+        g = synth_rows(5, 0, n, d)
+        q_all = synth_rows(6, 0, nq, d)
+        per = nq // gq
+        q = q_all[qgroup * per:(qgroup + 1) * per]
+        lo, hi = shard_bounds(n, gs, shard)
+        li, ls = oracle.exact_topk_f64(g[lo:hi], q, min(k, hi - lo))
+        idx = np.full((per, k), -1, dtype=np.int64)
+        sc = np.full((per, k), -np.inf)
+        idx[:, :li.shape[1]] = li + lo
+        sc[:, :ls.shape[1]] = ls
+        g_sc = all_gather_stacked(torch.from_numpy(sc), group).numpy()
+        g_idx = all_gather_stacked(torch.from_numpy(idx), group).numpy()
+        assert g_sc.shape == (gs, per, k)
+        ms, mi = oracle.merge_topk(list(g_sc), list(g_idx), k)
+        ref_i, ref_s = oracle.exact_topk_f64(g, q, k)
+        ok = np.array_equal(mi, ref_i) and np.allclose(ms, ref_s)
+        # sharded alpha-QE: float64 partial sums of the rows each shard owns, all-gathered and added in rank order
+        w = (np.arange(3, 0, -1) / 3.0) ** 4.0
+        part = np.zeros((per, d))
+        for j in range(3):
+            rows = ref_i[:, j]
+            mine = (rows >= lo) & (rows < hi)
+            part[mine] += g[rows[mine]].astype(np.float64) * w[j]
+        parts = all_gather_stacked(torch.from_numpy(part), group).numpy()
+        total = parts[0].copy()
+        for r in range(1, gs):
+            total += parts[r]
+        full = sum(g[ref_i[:, j]].astype(np.float64) * w[j] for j in range(3))
+        ok = ok and np.abs(total - full).max() < 1e-12
+        # every rank of the group holds the same bits (the point of the fixed order)
+        chk = all_gather_stacked(torch.from_numpy(total), group).numpy()
+        ok = ok and all(np.array_equal(chk[0], chk[r]) for r in range(gs))
+        ret[rank] = (bool(ok), gq, gs, qgroup, shard)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,layout", [(8, "2x4"), (8, "1x8"), (4, "2x2")])
+def test_query_groups_times_row_shards_over_gloo(world, layout):
+    """The rank count of the target node (8 processes) in the layouts bench.py --gpus 8 uses: 2 query groups x 4 row shards
+    for the headline, 1 x 8 for the 10 M-row block -- group creation, collectives inside a group, completeness."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    procs = [ctx.Process(target=_worker_layout, args=(r, world, port, layout, 803, 24, 16, 10, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(250)
+        assert p.exitcode == 0
+    gq, gs = (int(v) for v in layout.split("x"))
+    assert sorted((ret[r][3], ret[r][4]) for r in range(world)) == [(a, b) for a in range(gq) for b in range(gs)]
+    assert all(ret[r][0] is True and ret[r][1:3] == (gq, gs) for r in range(world))
