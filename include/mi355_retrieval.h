@@ -248,7 +248,7 @@ typedef struct mi_search_stats {
                                * main loop, median over waves); 0 if that kernel has not run.  The chip lowers its clock under
                                * MFMA load, so this is what the dense peak scales with */
 } mi_search_stats;
-int mi_profile_enable(mi_gallery* g, int on);      /* brackets scoring launches with hipEvents */
+int mi_profile_enable(mi_gallery* g, int on);      /* times the scoring launches with HIP events (dispatch timestamps) */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
 /* Tunables: "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
  * "workspace_slot" (0 | 1: which of the handle's two per-batch workspaces the phase API uses -- phase 1 of batch i + 1 may

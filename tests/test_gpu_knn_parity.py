@@ -307,9 +307,10 @@ def test_matching_fractional_dis_vs_reference_golden(lib, golden_dir, tag, dt):
 
 
 def test_raised_caps_answer_massive_ties_without_the_dense_path(lib):
-    """MI_ERR_OVERFLOW tells the user to raise survivor_cap / rescore_cap: at their maxima (16384 / 8192: 66.6 KB and
-    96 KiB of dynamic LDS in the maintain and emit kernels) 3000 exact duplicates of the best match fit the candidate
-    buffers, so the filter path itself answers -- with the ties in index order -- and nothing overflows."""
+    """MI_ERR_OVERFLOW tells the user to raise survivor_cap / rescore_cap: at their maxima (16384 / 8192; the maintain
+    kernel keeps 8192 keys in LDS and reads the rest from global memory, the emit kernel ranks in tiles of 512) 3000
+    exact duplicates of the best match fit the candidate buffers, so the filter path itself answers -- with the ties in
+    index order -- and nothing overflows."""
     from isehr_amd._lib import Gallery
     n, d, k = 20000, 128, 100
     g = synth_rows(61, 0, n, d)
