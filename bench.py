@@ -519,7 +519,7 @@ def main():
         try:
             r10 = run_workload(job, args.scale_10m_rows, 1024, "bf16", args.scale_10m_steps, 2, "1x%d" % world,
                                check=True, keep=False)
-        except (RuntimeError, AssertionError, MemoryError) as e:
+        except (RuntimeError, AssertionError, MemoryError, SystemExit) as e:
             # the secondary block must never cost the headline line (one rank: report and go on; several ranks: a rank that
             # fails alone would leave the others in a collective, so there the error ends the job)
             if world > 1:
