@@ -102,7 +102,9 @@ def QGE_hip(ranks, qvecs, vecs, dataset, gnd, cache_dir=None, gnd_path2=None, AQ
     from . import diffusion
     if blocks:
         vecs = np.concatenate([np.asarray(b) for b in vecs.blocks], axis=1)
-    return diffusion.qge_small_hip(ranks, qvecs, vecs, dataset, gnd, AQE=AQE, K=K, device=device, quiet=quiet)
+    # cache_dir: the reference's Diffusion(vecs.T, cache_dir) keeps offline.jbl there (src/utils/Reranking.py:234-235)
+    return diffusion.qge_small_hip(ranks, qvecs, vecs, dataset, gnd, AQE=AQE, K=K, cache_dir=cache_dir, device=device,
+                                   quiet=quiet)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -72,3 +72,44 @@ def test_test_rop1m_driver(feature_store, capsys, mode):
     line = [ln for ln in out.splitlines() if "mAP E:" in ln][0]
     for v in (e, m, h):
         assert str(np.around(v * 100, decimals=2)) in line, (line, e, m, h)
+
+
+@pytest.mark.parametrize("rerank", ["qge", "aqe", "dba", "kr"])
+def test_test_reranking_driver(tmp_path, monkeypatch, capsys, rerank):
+    """src/test_reranking.py's flow on numpy feature files (outputs/<dataset>_vecs.npy, [D, N]): matcher at K = 4000 ->
+    mAP -> one re-ranker.  The printed mAPs equal the oracle's for the same steps; QGE below 120 000 images writes and then
+    re-uses the diffusion cache the reference keeps under its cache_dir."""
+    from isehr_amd import evaluate
+    from isehr_amd.entry import test_reranking
+    monkeypatch.chdir(tmp_path)
+    vecs, qvecs, gnd = planted_dataset(78, 6000, 64, 12)
+    os.makedirs("outputs", exist_ok=True)
+    os.makedirs("data/test/roxford5k", exist_ok=True)
+    np.save("outputs/roxford5k_vecs.npy", vecs)
+    np.save("outputs/roxford5k_qvecs.npy", qvecs)
+    with open("data/test/roxford5k/gnd_roxford5k.pkl", "wb") as f:
+        pickle.dump({"gnd": gnd}, f)
+    assert test_reranking.main(["--datasets", "roxford5k", "--rerank", rerank]) == 0
+    out = capsys.readouterr().out
+    assert "matching time per query" in out
+    lines = [ln for ln in out.splitlines() if "mAP E:" in ln]
+    base = oracle.matching_l2(4000, vecs.T, qvecs.T).T
+    e, m, h = evaluate.compute_map_revisited(base, gnd)
+    for v in (e, m, h):
+        assert str(np.around(v * 100, decimals=2)) in lines[0], (lines[0], e, m, h)
+    assert len(lines) == 2                                        # initial ranking + the re-ranker's
+    if rerank == "qge":
+        assert os.path.exists("diffusion/tmp/roxford5k/offline.jbl") and "Obtaining cache" in out
+        # the oracle's small-database QGE (alpha-QE k = 10, w = 4, then diffusion from the expanded queries)
+        _, _, ranks_dfs = oracle.qge_small(base, qvecs, vecs, AQE=True, truncation_number=2000, k_gallery=200, k_query=3)
+        want = evaluate.compute_map_revisited(ranks_dfs, gnd)
+        got = [float(x) for x in lines[1].replace(",", " ").split() if x.replace(".", "", 1).isdigit()]
+        assert np.abs(np.array(got[-3:]) - np.around(np.array(want) * 100, 2)).max() <= 0.05, (lines[1], want)
+        assert test_reranking.main(["--datasets", "roxford5k", "--rerank", "qge"]) == 0    # second run: cache hit
+        assert "Loading cache" in capsys.readouterr().out
+    else:
+        ref = {"aqe": oracle.average_query_expansion, "dba": oracle.database_augmentation}.get(rerank)
+        if ref is not None:
+            want = evaluate.compute_map_revisited(ref(qvecs, vecs, 100), gnd)
+            got = [float(x) for x in lines[1].replace(",", " ").split() if x.replace(".", "", 1).isdigit()]
+            assert np.abs(np.array(got[-3:]) - np.around(np.array(want) * 100, 2)).max() <= 0.05, (lines[1], want)
