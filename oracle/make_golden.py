@@ -188,6 +188,26 @@ def main():
             res[f"{name}_aps_{'_'.join(okk)}"] = aps
         res[f"{name}_map_EMH"] = np.array(vals)
     np.savez_compressed(os.path.join(GOLD, "map.npz"), meta=np.array([41, 1200, 64, 12]), **res)
+    # ---- the first-generation evaluator (src/utils/evaluate.py:40-113: mAP + precision at kappas; what main_retrieve.py:176
+    # prints through) on the same planted ranking, and mAP_custom (:157-174, what test_custom.py:33 prints) on a directory-
+    # labelled toy database whose ranking is the planted one cut to K places
+    import src.utils.evaluate as ev1
+    res1 = {}
+    for okk, jk, tag in ((("easy",), ("junk", "hard"), "E"), (("easy", "hard"), ("junk",), "M"),
+                         (("hard",), ("junk", "easy"), "H")):
+        gt = [{"ok": np.concatenate([g_[k] for k in okk]), "junk": np.concatenate([g_[k] for k in jk])} for g_ in gnd]
+        mp, aps, pr, prs = ev1.compute_map(rk, gt, [1, 5, 10])
+        res1["map_" + tag], res1["aps_" + tag], res1["pr_" + tag], res1["prs_" + tag] = np.array(mp), aps, pr, prs
+    n_c, nq_c, K_c = 300, 9, 40
+    paths_d = ["custom/database/class%02d/img%04d.jpg" % ((i * 7) % 11, i) for i in range(n_c)]
+    paths_q = ["custom/query/class%02d/q%02d.jpg" % ((i * 3) % 13, i) for i in range(nq_c)]     # classes 11, 12: no positives
+    idx_c = np.stack([np.argsort(((np.arange(n_c) * (2 * i + 3)) % 101 + (np.arange(n_c) % 11 != (i * 3) % 13) * 37),
+                                 kind="stable")[:K_c] for i in range(nq_c)])
+    keep = [i for i in range(nq_c) if (i * 3) % 13 < 11]        # mAP_custom divides by the class size: 0 for an absent class
+    res1["custom_idx"], res1["custom_keep"] = idx_c, np.array(keep)
+    res1["custom_map"] = np.array(ev1.mAP_custom(K_c, idx_c[keep], [paths_q[i] for i in keep], paths_d))
+    res1["custom_paths_d"], res1["custom_paths_q"] = np.array(paths_d), np.array(paths_q)
+    np.savez_compressed(os.path.join(GOLD, "map_v1.npz"), meta=np.array([41, 1200, 64, 12]), **res1)
     # ---- f-4: average_query_expansion / database_augmentation.  They print and return None; the ranks are captured by
     # replacing the module-level compute_map_and_print2 they call last (src/utils/Reranking.py:361,428)
     captured = {}

@@ -9,7 +9,7 @@ import scipy.sparse.linalg as spla
 
 __all__ = [
     "matching_l2", "matching_fractional_dis", "fractional_distance", "ip_rank", "feature_enhancement", "qge1", "qe_weights", "l2n", "whitenapply",
-    "extract_ms_tail", "knn_flat_ip", "knn_flat_ip_blas", "compute_ap2", "compute_map2", "compute_map_revisited",
+    "extract_ms_tail", "knn_flat_ip", "knn_flat_ip_blas", "compute_ap2", "compute_map2", "compute_map_revisited", "compute_map_kappas", "map_custom",
     "get_affinity", "get_laplacian", "diffusion_offline", "diffusion_online", "qge_small",
     "average_query_expansion", "database_augmentation", "kr_reranking", "exact_scores_f64", "exact_topk_f64", "check_topk_parity", "merge_topk",
 ]
@@ -206,6 +206,60 @@ def compute_map_revisited(ranks, gnd):
               "junk": np.concatenate([gnd[i][k] for k in junk_keys])} for i in range(len(gnd))]
         out.append(compute_map2(ranks, g)[0])
     return tuple(out)
+
+
+def compute_map_kappas(ranks, gnd, kappas=(1, 5, 10)):
+    """src/utils/evaluate.py:40-113 (the first-generation evaluator that src/main_retrieve.py:176 and
+    src/main_train.py:705 print through): the same AP as compute_map2 plus precision at kappas -- with the junk-corrected
+    positions made 1-based (:103), kq = min(max(pos), kappa) (:105) and prs = #(pos <= kq) / kq (:106).  A query whose
+    positives are all missing from a truncated ranking raises in the reference (max of an empty array); here too.
+    Returns (map, aps, pr, prs)."""
+    nq = len(gnd)
+    aps = np.zeros(nq)
+    prs = np.zeros((nq, len(kappas)))
+    total, nempty = 0.0, 0
+    pr = np.zeros(len(kappas))
+    for i in range(nq):
+        ok = np.array(gnd[i]["ok"])
+        if ok.shape[0] == 0:
+            aps[i] = float("nan")
+            prs[i, :] = float("nan")
+            nempty += 1
+            continue
+        junk_ids = np.array(gnd[i]["junk"]) if "junk" in gnd[i] else np.empty(0)
+        col = ranks[:, i]
+        pos = np.flatnonzero(np.isin(col, ok))
+        junk = np.flatnonzero(np.isin(col, junk_ids))
+        if len(junk):
+            pos = pos - np.searchsorted(junk, pos)
+        ap = compute_ap2(pos, len(ok))
+        total += ap
+        aps[i] = ap
+        pos1 = pos + 1
+        for j, kappa in enumerate(kappas):
+            kq = min(max(pos1), kappa)
+            prs[i, j] = (pos1 <= kq).sum() / kq
+        pr = pr + prs[i, :]
+    return total / (nq - nempty), aps, pr / (nq - nempty), prs
+
+
+def map_custom(K, matching_idx, paths_q, paths_d):
+    """src/utils/evaluate.py:157-174 (`mAP_custom`, what src/test_custom.py:33 prints): the label of an image is the
+    name of its directory; AP of query i = sum over the places j < K that hold a same-label image of
+    (#same-label images up to j) / (j + 1), divided by min(#same-label images in the database, K)."""
+    label_d = [p.split("/")[-2] for p in paths_d]
+    total = 0.0
+    for i in range(len(paths_q)):
+        label_q = paths_q[i].split("/")[-2]
+        tp = {j for j, v in enumerate(label_d) if v == label_q}
+        count = 0
+        matched = np.zeros(K, dtype=np.int64)
+        for j in range(K):
+            if int(matching_idx[i, j]) in tp:
+                count += 1
+                matched[j] = count
+        total += sum(matched / (np.arange(K) + 1)) / min(len(tp), K)
+    return total / len(paths_q)
 
 
 # --------------------------------------------------------------------------- a5

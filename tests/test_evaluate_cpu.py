@@ -49,3 +49,37 @@ def test_map_from_positions_equals_map_of_the_full_ranking():
     assert np.allclose(full, got, rtol=0, atol=1e-15)
     cut = evaluate.compute_map_revisited(ranks[:1000], gnd)
     assert all(c < f for c, f in zip(cut, full))
+
+
+def test_first_generation_evaluator_and_custom_map_vs_reference_golden(golden_dir):
+    """src/utils/evaluate.py: compute_map with kappas (mAP + precision at 1 / 5 / 10, the evaluator behind
+    src/main_retrieve.py:176) and mAP_custom (src/test_custom.py:33), both captured from the reference's own functions
+    (oracle/make_golden.py -> map_v1.npz): the oracle restatement and the build's vectorised implementation reproduce them."""
+    z = np.load(os.path.join(golden_dir, "map_v1.npz"))
+    vecs, qv, gnd = planted_dataset(41, 1200, 64, 12)
+    rk = np.argsort(-(vecs.T @ qv), axis=0)
+    for (okk, jk), tag in zip(evaluate.EMH, "EMH"):
+        gt = [{"ok": np.concatenate([g[k] for k in okk]), "junk": np.concatenate([g[k] for k in jk])} for g in gnd]
+        mo, aps_o, pr_o, prs_o = oracle.compute_map_kappas(rk, gt, (1, 5, 10))
+        assert mo == float(z["map_" + tag]) and np.array_equal(aps_o, z["aps_" + tag], equal_nan=True)
+        assert np.array_equal(pr_o, z["pr_" + tag]) and np.array_equal(prs_o, z["prs_" + tag], equal_nan=True)
+        mp, aps = evaluate.compute_map(rk, gt)
+        pr, prs = evaluate.precision_at(rk, gt, (1, 5, 10))
+        assert abs(mp - float(z["map_" + tag])) <= 1e-12 and np.allclose(aps, z["aps_" + tag], rtol=0, atol=1e-12, equal_nan=True)
+        assert np.allclose(pr, z["pr_" + tag], rtol=0, atol=1e-12)
+        assert np.allclose(prs, z["prs_" + tag], rtol=0, atol=1e-12, equal_nan=True)
+    idx, keep = z["custom_idx"], z["custom_keep"]
+    pd_, pq_ = [str(p) for p in z["custom_paths_d"]], [str(p) for p in z["custom_paths_q"]]
+    K = idx.shape[1]
+    want = float(z["custom_map"])
+    assert oracle.map_custom(K, idx[keep], [pq_[i] for i in keep], pd_) == want
+    assert abs(evaluate.map_custom(K, idx[keep], [pq_[i] for i in keep], pd_) - want) <= 1e-12
+    assert 0.0 < want < 1.0
+
+
+def test_map_and_print_with_kappas_prints_the_precision_line(capsys):
+    vecs, qv, gnd = planted_dataset(41, 1200, 64, 12)
+    rk = np.argsort(-(vecs.T @ qv), axis=0)
+    evaluate.compute_map_and_print("roxford5k", rk, gnd, kappas=[1, 5, 10])
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith(">> roxford5k: mAP E: ") and out[1].startswith(">> roxford5k: mP@k[1, 5, 10] E: [")

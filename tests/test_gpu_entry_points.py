@@ -113,3 +113,123 @@ def test_test_reranking_driver(tmp_path, monkeypatch, capsys, rerank):
             want = evaluate.compute_map_revisited(ref(qvecs, vecs, 100), gnd)
             got = [float(x) for x in lines[1].replace(",", " ").split() if x.replace(".", "", 1).isdigit()]
             assert np.abs(np.array(got[-3:]) - np.around(np.array(want) * 100, 2)).max() <= 0.05, (lines[1], want)
+
+
+def test_main_retrieve_driver(tmp_path, monkeypatch, capsys):
+    """src/main_retrieve.py's evaluation flow on numpy feature files: feature store written, the FULL inner-product ranking
+    (:175-176) equal to the oracle's argsort wherever scores are not within 1e-6, mAP and mP@k lines equal to the
+    first-generation evaluator's (pinned by map_v1.npz), and the whitened second pass of src/main_train.py:709-716."""
+    from isehr_amd.entry import main_retrieve
+    from isehr_amd.entry.features import load_path_features
+    monkeypatch.chdir(tmp_path)
+    vecs, qvecs, gnd = planted_dataset(79, 3000, 64, 10)
+    os.makedirs("outputs", exist_ok=True)
+    os.makedirs("data/test/rparis6k", exist_ok=True)
+    np.save("outputs/rparis6k_vecs.npy", vecs)
+    np.save("outputs/rparis6k_qvecs.npy", qvecs)
+    with open("data/test/rparis6k/gnd_rparis6k.pkl", "wb") as f:
+        pickle.dump({"gnd": gnd, "imlist": ["im%d" % i for i in range(3000)], "qimlist": ["q%d" % i for i in range(10)]}, f)
+    rng = np.random.default_rng(5)
+    Lw = {"m": vecs.mean(axis=1, keepdims=True).astype(np.float64), "P": rng.standard_normal((64, 64)) / 8 + np.eye(64)}
+    with open("Lw.pkl", "wb") as f:
+        pickle.dump(Lw, f)
+    assert main_retrieve.main(["--datasets", "rparis6k", "--whitening", "Lw.pkl"]) == 0
+    out = capsys.readouterr().out.splitlines()
+    v2, paths = load_path_features("rparis6k_database")
+    assert np.array_equal(v2, vecs) and paths[5] == "im5"
+    want_ranks, scores = oracle.ip_rank(vecs.astype(np.float64), qvecs.astype(np.float64))
+    res = main_retrieve.evaluate_dataset("rparis6k", vecs, qvecs, gnd, Lw)
+    capsys.readouterr()
+    for got, sc, r in ((res["ranks"], scores, want_ranks),):
+        assert got.shape == r.shape
+        diff = np.argwhere(got != r)
+        for pos, qi in diff:
+            assert abs(sc[got[pos, qi], qi] - sc[r[pos, qi], qi]) <= 1e-6
+    vl, ql = oracle.whitenapply(vecs.astype(np.float64), Lw["m"], Lw["P"]), oracle.whitenapply(qvecs.astype(np.float64), Lw["m"], Lw["P"])
+    r_lw, s_lw = oracle.ip_rank(vl, ql)
+    for pos, qi in np.argwhere(res["ranks_lw"] != r_lw):
+        assert abs(s_lw[res["ranks_lw"][pos, qi], qi] - s_lw[r_lw[pos, qi], qi]) <= 1e-6
+    # printed lines: mAP + mP@k for the plain and the whitened descriptors, values of the oracle's evaluator
+    map_lines = [ln for ln in out if "mAP E:" in ln]
+    pr_lines = [ln for ln in out if "mP@k[1, 5, 10]" in ln]
+    assert len(map_lines) == 2 and len(pr_lines) == 2 and "rparis6k + whiten" in map_lines[1]
+    for ranks_, line, pline in ((want_ranks, map_lines[0], pr_lines[0]), (r_lw, map_lines[1], pr_lines[1])):
+        vals, prs = [], []
+        for okk, jk in evaluate_emh():
+            gt = [{"ok": np.concatenate([g[k] for k in okk]), "junk": np.concatenate([g[k] for k in jk])} for g in gnd]
+            mp, _, pr, _ = oracle.compute_map_kappas(ranks_, gt, (1, 5, 10))
+            vals.append(mp)
+            prs.append(pr)
+        for v in vals:
+            assert str(np.around(v * 100, decimals=2)) in line, (line, vals)
+        for p in prs:
+            assert str(np.around(p * 100, decimals=2)) in pline, (pline, prs)
+
+
+def evaluate_emh():
+    from isehr_amd import evaluate
+    return evaluate.EMH
+
+
+def test_main_retrieve_extract_flow(tmp_path, monkeypatch, capsys):
+    """--extract: image tensors -> ResNet-SOA trunk (reduced depth / width: the flow, not the weights) -> HIP descriptor
+    tail -> device gallery -> descriptors; the ranking of the driver equals the oracle's on the descriptors it stored."""
+    import torch
+    from isehr_amd.entry import main_retrieve
+    from isehr_amd.entry.features import load_path_features
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("outputs", exist_ok=True)
+    os.makedirs("data/test/roxford5k", exist_ok=True)
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn((21, 3, 64, 48), generator=g)
+    torch.save(imgs, "outputs/roxford5k_images.pt")
+    torch.save(imgs[[2, 7, 11]] + 0.05 * torch.randn((3, 3, 64, 48), generator=g), "outputs/roxford5k_qimages.pt")
+    gnd = [{"easy": np.array([i]), "hard": np.array([(i + 1) % 21]), "junk": np.array([], dtype=np.int64)} for i in (2, 7, 11)]
+    with open("data/test/roxford5k/gnd_roxford5k.pkl", "wb") as f:
+        pickle.dump({"gnd": gnd}, f)
+    torch.manual_seed(11)
+    assert main_retrieve.main(["--datasets", "roxford5k", "--extract", "--blocks", "1,1,1,1", "--width", "8",
+                               "--multiscale", "1,1.4142135,0.70710678", "--batch", "5"]) == 0
+    out = capsys.readouterr().out
+    vecs, _ = load_path_features("roxford5k_database")
+    qvecs, _ = load_path_features("roxford5k_query")
+    assert vecs.shape == (256, 21) and qvecs.shape == (256, 3)
+    assert np.allclose(np.linalg.norm(vecs, axis=0), 1.0, atol=1e-5)          # extract_ms ends with v / ||v||
+    want = oracle.compute_map_revisited(oracle.ip_rank(vecs.astype(np.float64), qvecs.astype(np.float64))[0], gnd)
+    line = [ln for ln in out.splitlines() if "mAP E:" in ln][0]
+    for v in want:
+        assert str(np.around(v * 100, decimals=2)) in line, (line, want)
+
+
+def test_test_custom_driver(tmp_path, monkeypatch, capsys):
+    """src/test_custom.py: full ranking of a directory-labelled collection (K = database size), mAP_custom, the pickle of
+    ranked database paths per query."""
+    from isehr_amd.entry import test_custom
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(8)
+    centres = rng.standard_normal((6, 48))
+    lab_d = np.arange(240) % 6
+    d = centres[lab_d] + 2.0 * rng.standard_normal((240, 48))
+    lab_q = np.arange(12) % 6
+    q = centres[lab_q] + 2.0 * rng.standard_normal((12, 48))
+    paths_d = ["data/test/custom/database/c%d/%03d.jpg" % (lab_d[i], i) for i in range(240)]
+    paths_q = ["data/test/custom/query/c%d/q%02d.jpg" % (lab_q[i], i) for i in range(12)]
+    os.makedirs("outputs/features", exist_ok=True)
+    for name, feat, paths in (("custom_query", q, paths_q), ("custom_database", d, paths_d)):
+        with open("outputs/features/%s_path_feature_2.pkl" % name, "wb") as f:
+            pickle.dump({"path": paths, "feature": feat.T.astype(np.float32)}, f)
+    assert test_custom.main([]) == 0
+    out = capsys.readouterr().out
+    want_idx = oracle.matching_l2(240, d.astype(np.float32), q.astype(np.float32))
+    want = oracle.map_custom(240, want_idx, paths_q, paths_d)
+    got = float([ln for ln in out.splitlines() if ln.startswith("mean average precision")][0].split(":")[1])
+    assert abs(got - want) <= 2e-3 and 0.3 < want < 1.0                      # near-ties may swap neighbours of one label
+    with open("outputs/ranks/custom_ranking_result.pkl", "rb") as f:
+        rank_res = pickle.load(f)
+    assert set(rank_res) == set(paths_q) and all(sorted(v) == sorted(paths_d) for v in rank_res.values())
+    gn = d / np.linalg.norm(d, axis=1, keepdims=True)
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    s = qn @ gn.T
+    for i, pq in enumerate(paths_q):
+        order = [paths_d.index(p) for p in rank_res[pq]]
+        assert (np.diff(s[i, order]) <= 1e-6).all()
