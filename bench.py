@@ -62,7 +62,7 @@ def parse():
                     help="element type of the streamed 16-bit operand image (MFMA input type)")
     ap.add_argument("--with-aqe", action="store_true",
                     help="BASELINE configs[4]: every step = search + alpha-QE (k=3, w=4) re-search of the expanded queries")
-    ap.add_argument("--async-tail", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+    ap.add_argument("--async-tail", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3],
                     help="single GPU: re-score + sort of batch i on the handle's second stream.  1: beside the scoring launch "
                          "of batch i+1 (measured: no gain -- the board is at its power cap and the scoring launch slows "
                          "down by what the overlap hides).  2: beside the query ingest + bootstrap of batch i+1 only; its "

@@ -120,6 +120,19 @@ struct mi_gallery {
   hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
   bool ev_tail_valid[2] = {false, false};
   hipEvent_t gate_before_scoring = nullptr;   // async_tail 2: the filtered scoring launch of a batch waits for this event
+  // async_tail 3 ("deferred"): the tail of batch i is ENQUEUED by the search call of batch i + 1, after that batch's query
+  // ingest / bootstrap / threshold launches and right before its scoring launch, so that the re-score gather shares the
+  // device with the power-bound scoring launch only -- not with the bootstrap, which wants the same memory system
+  // (mode 1 starts the tail as soon as phase 1 is done, i.e. beside the next batch's bootstrap: 63 -> 214 us).
+  struct PendingTail {
+    bool valid = false;
+    int32_t b = 0, k = 0;
+    int set = 0;
+    int64_t* out_idx = nullptr;
+    float* out_score = nullptr;
+    double* out_score64 = nullptr;
+  } pending;
+  hipEvent_t ev_pre = nullptr;                // recorded on the caller's stream right before the scoring launch
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -154,9 +167,16 @@ static int dev_alloc(Workspace& ws, T** p, size_t count) {
   return MI_OK;
 }
 
+static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring);
+
 static int ws_ensure(mi_gallery* g, int32_t k) {
   Workspace& ws = g->ws;
   if (ws.qcap >= QB && ws.kcap >= k && ws.cap == g->surv_cap && ws.rcap == g->rescore_cap) return MI_OK;
+  if (g->pending.valid) {          // a deferred tail (async_tail 3) still reads the buffers about to be rebuilt
+    const int rc = flush_pending_tail(g, nullptr, false);
+    if (rc != MI_OK) return rc;
+    HIPC(hipStreamSynchronize(g->tail_stream));
+  }
   const int32_t kcap = std::max<int32_t>(k, std::max(ws.kcap, g->ws_alt.kcap));
   // (re)allocation of the active workspace.  The parked one survives only if this is the active one's FIRST allocation
   // (then it owns the shared flags / statistics and the new one aliases them); any other re-allocation may free what
@@ -316,6 +336,8 @@ static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
 
 // ---- phase 1 for one batch (nq <= QB): query ingest, chunked scoring + threshold maintenance ----------
 // fuse_cand: the final maintain launch also writes the candidate lists (single-shard search: its L is the global one)
+static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring);
+
 static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                         int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false) {
   Workspace& ws = g->ws;
@@ -439,6 +461,10 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       HIPC(hipStreamWaitEvent(s, g->gate_before_scoring, 0));
       g->gate_before_scoring = nullptr;
     }
+    if (g->pending.valid) {                     // async_tail 3: the previous batch's tail starts beside THIS scoring launch
+      const int rc = flush_pending_tail(g, s, /*beside_scoring=*/true);
+      if (rc != MI_OK) return rc;
+    }
     score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
     ladder_on = false;
     // repair pass for queries whose speculative threshold failed verification (1e-7 per query): conditional on the device
@@ -526,6 +552,45 @@ static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev
   return MI_OK;
 }
 
+// async_tail 3: enqueue the deferred tail (exact re-score + emit of the batch recorded in g->pending) on the tail stream.
+// beside_scoring: called from phase1_batch right before the scoring launch of the NEXT batch on `s` -- the tail then also
+// waits for everything enqueued on `s` so far (that batch's query ingest, bootstrap, thresholds), so that it runs beside the
+// scoring launch and nothing else.  Otherwise (join, a call that cannot defer) it only waits for its own phase 1.
+static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring) {
+  if (!g->pending.valid) return MI_OK;
+  const mi_gallery::PendingTail p = g->pending;
+  g->pending.valid = false;
+  Workspace& ws = g->ws;
+  float* q_keep = ws.q_f32;
+  uint32_t* rows_keep = ws.cand_rows;
+  uint32_t* cnt_keep = ws.cand_cnt;
+  double* sc_keep = ws.cand_score;
+  ws.q_f32 = ws.q_f32_set[p.set];
+  ws.cand_rows = ws.cand_rows_set[p.set];
+  ws.cand_cnt = ws.cand_cnt_set[p.set];
+  ws.cand_score = ws.cand_score_set[p.set];
+  int rc = MI_OK;
+  hipError_t e = hipStreamWaitEvent(g->tail_stream, g->ev_p1[p.set], 0);
+  if (e == hipSuccess && beside_scoring) {
+    e = hipEventRecord(g->ev_pre, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g->tail_stream, g->ev_pre, 0);
+  }
+  if (e != hipSuccess) rc = fail(MI_ERR_HIP, hipGetErrorString(e));
+  if (rc == MI_OK)
+    rc = phase2_batch(g, p.b, p.k, ws.L, p.out_idx, p.out_score, p.out_score64, g->tail_stream, /*have_cand=*/true,
+                      /*resident=*/true);
+  if (rc == MI_OK) {
+    e = hipEventRecord(g->ev_tail[p.set], g->tail_stream);
+    if (e != hipSuccess) rc = fail(MI_ERR_HIP, hipGetErrorString(e));
+    else g->ev_tail_valid[p.set] = true;
+  }
+  ws.q_f32 = q_keep;
+  ws.cand_rows = rows_keep;
+  ws.cand_cnt = cnt_keep;
+  ws.cand_score = sc_keep;
+  return rc;
+}
+
 static int check_k(const mi_gallery* g, int32_t k) {
   REQUIRE(k >= 1, "k must be >= 1");
   if ((int64_t)k > g->n)
@@ -542,15 +607,23 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
                          hipStream_t s, bool allow_async = false) {
   int rc = check_k(g, k);
   if (rc != MI_OK) return rc;
+  const bool async = g->async_tail != 0 && allow_async;
+  if (g->pending.valid && !(async && g->async_tail == 3 && g->pending.k == k)) {
+    // a deferred tail is waiting and this call cannot carry it (another mode, another k: the workspace may be rebuilt):
+    // run it now and make this call's stream wait for it
+    const int set = g->pending.set;
+    if ((rc = flush_pending_tail(g, s, false)) != MI_OK) return rc;
+    HIPC(hipStreamWaitEvent(s, g->ev_tail[set], 0));
+  }
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
   const size_t esz = q_dtype == MI_F32 ? 4 : 8;
-  const bool async = g->async_tail != 0 && allow_async;
   if (async && !g->tail_stream) {
     HIPC(hipStreamCreateWithFlags(&g->tail_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
       HIPC(hipEventCreateWithFlags(&g->ev_p1[i], hipEventDisableTiming));
       HIPC(hipEventCreateWithFlags(&g->ev_tail[i], hipEventDisableTiming));
     }
+    HIPC(hipEventCreateWithFlags(&g->ev_pre, hipEventDisableTiming));
   }
   Workspace& ws = g->ws;
   for (int64_t q0 = 0; q0 < nq; q0 += QB) {
@@ -572,6 +645,23 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     ws.cand_cnt = ws.cand_cnt_set[set];
     ws.cand_score = ws.cand_score_set[set];
     if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true)) != MI_OK) return rc;
+    if (async && g->async_tail == 3) {
+      // deferred: a schedule without the single filtered launch (chunked, f32-scored) has not picked the previous tail up
+      if (g->pending.valid && (rc = flush_pending_tail(g, s, false)) != MI_OK) return rc;
+      HIPC(hipEventRecord(g->ev_p1[set], s));
+      if (b > STREAM_MAX_QUERIES) {
+        g->pending.valid = true;
+        g->pending.b = b;
+        g->pending.k = k;
+        g->pending.set = set;
+        g->pending.out_idx = out_idx + q0 * k;
+        g->pending.out_score = out_score ? out_score + q0 * k : nullptr;
+        g->pending.out_score64 = out_score64 ? out_score64 + q0 * k : nullptr;
+        g->stats.searches += 1;
+        g->stats.queries += b;
+        continue;
+      }
+    }
     if (async) {
       HIPC(hipEventRecord(g->ev_p1[set], s));
       HIPC(hipStreamWaitEvent(tail, g->ev_p1[set], 0));
@@ -592,6 +682,10 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
 
 // makes `s` wait for every tail enqueued so far (no-op in the synchronous mode)
 static int join_tails(mi_gallery* g, hipStream_t s) {
+  if (g->pending.valid) {
+    const int rc = flush_pending_tail(g, s, false);
+    if (rc != MI_OK) return rc;
+  }
   for (int i = 0; i < 2; ++i)
     if (g->ev_tail_valid[i]) HIPC(hipStreamWaitEvent(s, g->ev_tail[i], 0));
   return MI_OK;
@@ -624,6 +718,7 @@ int mi_gallery_destroy(mi_gallery* g) {
     if (g->ev_p1[i]) (void)hipEventDestroy(g->ev_p1[i]);
     if (g->ev_tail[i]) (void)hipEventDestroy(g->ev_tail[i]);
   }
+  if (g->ev_pre) (void)hipEventDestroy(g->ev_pre);
   if (g->tail_stream) (void)hipStreamDestroy(g->tail_stream);
   ws_free(g->ws);
   ws_free(g->ws_alt);
@@ -1952,7 +2047,15 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
   else if (n == "ladder") g->ladder = value != 0;
-  else if (n == "async_tail") { REQUIRE(value == 0 || value == 1 || value == 2, "async_tail: 0, 1 or 2"); g->async_tail = (int)value; }
+  else if (n == "async_tail") {
+    REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
+    if (g->pending.valid) {                    // leave no deferred tail behind a change of mode
+      HIPC(hipSetDevice(g->device));
+      const int rc = flush_pending_tail(g, nullptr, false);
+      if (rc != MI_OK) return rc;
+    }
+    g->async_tail = (int)value;
+  }
   else if (n == "query_norm_override") {
     REQUIRE(value >= -1 && value <= 2, "query_norm_override: -1 or an mi_norm value");
     g->qnorm_override = (int)value;

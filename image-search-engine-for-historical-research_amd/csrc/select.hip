@@ -625,7 +625,7 @@ constexpr uint32_t RESCORE_GRID_X = 64;     // 128 candidates per query and swee
 // launch finds room on every CU at once (a grid of 64 k one-wave workgroups fills the SIMDs with re-score waves first
 // and the persistent kernel then waits for them to drain).  Query q belongs to SUB consecutive waves, which take its
 // candidate pairs round-robin; same arithmetic as rescore_kernel.
-__global__ __launch_bounds__(256, 5) void rescore_resident_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
+__global__ __launch_bounds__(256, 6) void rescore_resident_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
                                                                int32_t dp, int32_t nq, const uint32_t* __restrict__ cand_rows,
                                                                const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
                                                                double* __restrict__ cand_score, uint32_t sub,
@@ -645,16 +645,18 @@ __global__ __launch_bounds__(256, 5) void rescore_resident_kernel(const float* _
       const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[two ? c + 1 : c], last_row) * dp);
       double a0 = 0.0, a1 = 0.0;
       int v = lane;
-      for (; v + 192 < nvec; v += 256) {
-        float4 x[4], y0[4], y1[4];
+      // two 16-byte loads per row in flight per lane (4 KiB per wave): the launch must stay within the 80 VGPRs the tile
+      // kernel leaves free on a SIMD (2 x 216 of 512), and it has a whole scoring launch to move its bytes in
+      for (; v + 64 < nvec; v += 128) {
+        float4 x[2], y0[2], y1[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
           x[u] = qv[v + 64 * u];
-          y0[u] = g0[v + 64 * u];
-          y1[u] = g1[v + 64 * u];
+          y0[u] = nt_load4(g0 + v + 64 * u);
+          y1[u] = nt_load4(g1 + v + 64 * u);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
           a0 += (double)x[u].x * (double)y0[u].x; a0 += (double)x[u].y * (double)y0[u].y;
           a0 += (double)x[u].z * (double)y0[u].z; a0 += (double)x[u].w * (double)y0[u].w;
           a1 += (double)x[u].x * (double)y1[u].x; a1 += (double)x[u].y * (double)y1[u].y;

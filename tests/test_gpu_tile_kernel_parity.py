@@ -123,10 +123,11 @@ def test_large_shard_chunk_schedule_equals_exact_path(lib, img):
         g.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_async_tail_gives_the_same_answers(lib, mode):
-    """mi_set_option("async_tail", 1 | 2): re-score + sort of batch i on the handle's own stream beside the scoring launch
-    (1) or only beside the query ingest + bootstrap (2) of batch i + 1.  Several different batches in flight, distinct
+    """mi_set_option("async_tail", 1 | 2 | 3): re-score + sort of batch i on the handle's own stream beside the scoring launch
+    (1), only beside the query ingest + bootstrap (2) of batch i + 1, or -- deferred (3) -- enqueued by the call of batch
+    i + 1 right before its scoring launch, so that it shares the device with that launch alone.  Several different batches in flight, distinct
     output buffers: after mi_search_join every batch equals the synchronous answer bit for bit; a synchronous host search
     on the same handle in between is unaffected."""
     import torch
