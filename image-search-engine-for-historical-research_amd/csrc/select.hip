@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256, 6) void rescore_resident_kernel(const float* _
                                                                int32_t dp, int32_t nq, const uint32_t* __restrict__ cand_rows,
                                                                const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
                                                                double* __restrict__ cand_score, uint32_t sub,
-                                                               uint32_t last_row) {
+                                                               uint32_t last_row, uint32_t dbg) {
   const int lane = threadIdx.x & 63;
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int nvec = dp >> 2;
@@ -641,10 +641,21 @@ __global__ __launch_bounds__(256, 6) void rescore_resident_kernel(const float* _
     double* outs = cand_score + (uint64_t)q * rcap;
     for (uint32_t c = part * 2; c < nc; c += 2 * sub) {
       const bool two = (c + 1 < nc);
-      const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[c], last_row) * dp);
-      const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)min(rows[two ? c + 1 : c], last_row) * dp);
+      uint32_t r0 = min(rows[c], last_row), r1 = min(rows[two ? c + 1 : c], last_row);
+      if (dbg & 2u) { r0 = c & 63u; r1 = (c + 1) & 63u; }                 // diagnostics: no gather (64 rows, cache-resident)
+      const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)r0 * dp);
+      const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)r1 * dp);
       double a0 = 0.0, a1 = 0.0;
       int v = lane;
+      if (dbg & 1u) {                                                       // diagnostics: the loads without the arithmetic
+        float f0 = 0.f, f1 = 0.f;
+        for (; v < nvec; v += 64) {
+          const float4 y0 = nt_load4(g0 + v), y1 = nt_load4(g1 + v);
+          f0 += y0.x + y0.w;
+          f1 += y1.x + y1.w;
+        }
+        a0 = f0; a1 = f1;
+      }
       // two 16-byte loads per row in flight per lane (4 KiB per wave): the launch must stay within the 80 VGPRs the tile
       // kernel leaves free on a SIMD (2 x 216 of 512), and it has a whole scoring launch to move its bytes in
       for (; v + 64 < nvec; v += 128) {
@@ -687,11 +698,13 @@ __global__ __launch_bounds__(256, 6) void rescore_resident_kernel(const float* _
 void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                              const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
                              uint32_t last_row) {
-  const unsigned grid = (unsigned)current_device_cus();
+  unsigned grid = (unsigned)current_device_cus();
+  static const uint32_t dbg = [] { const char* e = getenv("MI_RESIDENT_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+  if (dbg & 4u) grid /= 4;                                             // diagnostics: a quarter of the CUs host the tail
   uint32_t sub = 1;
   while ((uint64_t)nq * sub * 2 <= (uint64_t)grid * 4) sub *= 2;      // every wave of the grid gets a share
   hipLaunchKernelGGL(rescore_resident_kernel, dim3(grid), dim3(256), 0, stream, gal_f32, qry_f32, dp, nq, cand_rows,
-                     cand_cnt, rcap, cand_score, sub, last_row);
+                     cand_cnt, rcap, cand_score, sub, last_row, dbg);
 }
 
 // grid_x: workgroups (of 2 candidates) per query and sweep, 0 = default.  Workgroups beyond a query's count exit at once and
