@@ -496,6 +496,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # dmabuf IPC for RCCL / device-memory sharing between rank processes: the runtime reads this when it initialises, i.e.
+    # before anything below touches the GPU (a launcher's environment normally carries it already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # noqa: F401
     import torch.distributed as dist
     import isehr_amd  # noqa: F401
