@@ -219,19 +219,18 @@ struct QueryInit {
   uint32_t first_cnt;
   int32_t nq;
   QueryState st;
+  int64_t gallery_rows;    // INIT == false: rows the persistent grid produces (the shard's rows padded to whole tiles)
 };
 constexpr int QI_MAX_PER_THREAD = 16;
-template <typename InT, bool INIT>
+template <typename InT, bool INIT, int PT>
 __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs,
                                                            int64_t cs, int norm_mode, float* __restrict__ out_f32,
                                                            uint16_t* __restrict__ out_img, int img_f16,
                                                            RowStat* __restrict__ rowstat, int32_t dp, QueryInit qi,
                                                            int64_t row_base) {
   __shared__ double red[3][4];
-  __shared__ __attribute__((aligned(16))) float rowbuf[256 * QI_MAX_PER_THREAD];
+  __shared__ __attribute__((aligned(16))) float rowbuf[256 * PT];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int64_t row = blockIdx.x;
-  const bool valid = row < n;
   auto block_sum3 = [&](double& a, double& b, double& c) {
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
     __syncthreads();
@@ -241,24 +240,39 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
   };
-  double v[QI_MAX_PER_THREAD];
+  // Galleries (INIT == false) run a persistent grid: a workgroup takes rows blockIdx.x, + gridDim.x, ... and requests the
+  // NEXT row's elements before it reduces the current one.  A million one-row workgroups were paced by the dispatcher and by
+  // one memory latency per row and workgroup (3.1 TB/s of read + write traffic); the arithmetic and its order are untouched.
+  // nrows = rows to produce (padding rows of the last tile included: they are written as zeros); query batches (INIT) keep
+  // one workgroup per row, whose thread 0 also initialises the query's search state.
+  const int64_t nrows = INIT ? (int64_t)gridDim.x : qi.gallery_rows;
+  InT nxt[PT];     // PT = columns per thread: 8 for dp <= 2048 (half the registers), 16 up to 4096
+  auto request = [&](int64_t r) {
 #pragma unroll
-  for (int j = 0; j < QI_MAX_PER_THREAD; ++j) {
-    const int c = t + 256 * j;
-    v[j] = (valid && c < d) ? (double)src[row * rs + (int64_t)c * cs] : 0.0;
-  }
+    for (int j = 0; j < PT; ++j) {
+      const int c = t + 256 * j;
+      nxt[j] = (r < n && c < d) ? src[r * rs + (int64_t)c * cs] : (InT)0;
+    }
+  };
+  request(blockIdx.x);
+  for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+  const bool valid = row < n;
+  double v[PT];
+#pragma unroll
+  for (int j = 0; j < PT; ++j) v[j] = (double)nxt[j];
+  if (!INIT && row + gridDim.x < nrows) request(row + gridDim.x);
   double scale = 1.0;
   if (norm_mode != 0) {
     double ss = 0.0, z0 = 0.0, z1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < QI_MAX_PER_THREAD; ++j)
+    for (int j = 0; j < PT; ++j)
       if (t + 256 * j < d) ss += v[j] * v[j];
     block_sum3(ss, z0, z1);
     const double nrm = sqrt(ss);
     scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);
   }
 #pragma unroll
-  for (int j = 0; j < QI_MAX_PER_THREAD; ++j)
+  for (int j = 0; j < PT; ++j)
     if (t + 256 * j < dp) rowbuf[t + 256 * j] = (valid && t + 256 * j < d) ? (float)(v[j] * scale) : 0.0f;
   __syncthreads();
   double s_g = 0.0, s_b = 0.0, s_d = 0.0;
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     rsd.norm_img = (float)(sqrt(s_b) * (1.0 + 1e-6));
     rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
     rowstat[orow] = rsd;
-    if (!INIT) return;
+    if (!INIT) continue;
     // ---- per-query search state (select.hip init_query_state_kernel, same arithmetic)
     const QueryState& st = qi.st;
     const int q = (int)row;
@@ -331,6 +345,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
       st.lad_cnt[q] = 0;
     }
   }
+  }   // rows of this workgroup
 }
 
 bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
@@ -345,12 +360,13 @@ bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, in
   qi.first_cnt = first_cnt;
   qi.nq = nq;
   qi.st = st;
-  if (dtype == 0)
-    hipLaunchKernelGGL((ingest_query_kernel<float, true>), dim3((unsigned)qpad), dim3(256), 0, stream, (const float*)src,
-                       (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi, (int64_t)0);
-  else
-    hipLaunchKernelGGL((ingest_query_kernel<double, true>), dim3((unsigned)qpad), dim3(256), 0, stream, (const double*)src,
-                       (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi, (int64_t)0);
+  qi.gallery_rows = 0;
+#define MI_QI_LAUNCH(T, PT)                                                                                             \
+  hipLaunchKernelGGL((ingest_query_kernel<T, true, PT>), dim3((unsigned)qpad), dim3(256), 0, stream, (const T*)src,    \
+                     (int64_t)nq, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, qi, (int64_t)0)
+  if (dtype == 0) { if (dp <= 2048) MI_QI_LAUNCH(float, 8); else MI_QI_LAUNCH(float, 16); }
+  else { if (dp <= 2048) MI_QI_LAUNCH(double, 8); else MI_QI_LAUNCH(double, 16); }
+#undef MI_QI_LAUNCH
   return true;
 }
 
@@ -383,12 +399,15 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     // read once (8 KiB per row) and written once (8 + 4 KiB) instead of being read twice through the 64 x 64 LDS tiles of
     // ingest_kernel, which exists for the reference's strided `vecs.T` views ([D, N] arrays: rs == 1)
     QueryInit none{};
-    if (dtype == 0)
-      hipLaunchKernelGGL((ingest_query_kernel<float, false>), dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
-                         d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base);
-    else
-      hipLaunchKernelGGL((ingest_query_kernel<double, false>), dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
-                         n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base);
+    none.gallery_rows = npad;
+    // persistent grid: eight 256-thread workgroups per CU (the kernel's occupancy), each looping over its rows
+    const unsigned grid = (unsigned)std::min<int64_t>(npad, (int64_t)current_device_cus() * 8);
+#define MI_GI_LAUNCH(T, PT)                                                                                             \
+  hipLaunchKernelGGL((ingest_query_kernel<T, false, PT>), dim3(grid), dim3(256), 0, stream, (const T*)src, n, d, rs, cs, \
+                     norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base)
+    if (dtype == 0) { if (dp <= 2048) MI_GI_LAUNCH(float, 8); else MI_GI_LAUNCH(float, 16); }
+    else { if (dp <= 2048) MI_GI_LAUNCH(double, 8); else MI_GI_LAUNCH(double, 16); }
+#undef MI_GI_LAUNCH
     return;
   }
   if (npad <= 4096 || row_base != 0) {   // small batches (queries): one workgroup per row

@@ -102,7 +102,11 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
  * on `stream` and the exact re-score + sort on a stream of the handle, so that the tail of batch i runs beside the scoring
  * launch of batch i + 1 (the MFMA kernel leaves exactly the registers one re-score wave per SIMD needs and no LDS).  The
  * outputs of every call made so far are complete, in the order of `stream`, after mi_search_join(g, stream).  Default off:
- * outputs are then complete in stream order when mi_knn_search_device returns, as before. */
+ * outputs are then complete in stream order when mi_knn_search_device returns, as before.
+ * "async_tail" = 3 (deferred): the tail of a batch of > 128 queries is not enqueued by its own call but by the NEXT
+ * mi_knn_search_device call on the handle, after that batch's query ingest / bootstrap / threshold launches and right before
+ * its scoring launch (or by mi_search_join, or by any call that cannot carry it on): the re-score gather then shares the
+ * device with the power-bound scoring launch only.  The output buffers of a call must stay valid until the join. */
 int mi_search_join(mi_gallery* g, void* stream);
 
 /* Sharded search = phase 1 on every shard, all-gather of approx top-k values, phase 2, all-gather of
@@ -256,8 +260,8 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
  * "spec_max_ratio" (largest shard rows / sample rows for which the single-launch sample schedule is taken; default 160),
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
  * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "xcc_balance" (XCD shares by measured
- * speed), "async_tail" (1 | 2: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
- * query ingest and bootstrap only; see mi_search_join), "rescore_grid_x" (workgroups of 2
+ * speed), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
+ * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
  * "device_repair" (-1 = default: batches of > 128 queries follow the scoring launch with a device-conditional repair pass
