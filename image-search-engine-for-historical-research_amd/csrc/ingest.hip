@@ -8,9 +8,15 @@
 
 #include <algorithm>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
+#ifndef MI_INGEST_PROBE
+#define MI_INGEST_PROBE 0      // scripts/ingestbench.hip: 1 = no rounding statistics, 2 = no f32 row store, 4 = no image store
+#endif
 namespace mi {
 
 // 16-bit image element: fp16 (11-bit significand: 8x smaller rounding error, same MFMA rate) or bf16 (f32 range)
@@ -247,29 +253,60 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
   // one workgroup per row, whose thread 0 also initialises the query's search state.
   const int64_t nrows = INIT ? (int64_t)gridDim.x : qi.gallery_rows;
   InT nxt[PT];     // PT = columns per thread: 8 for dp <= 2048 (half the registers), 16 up to 4096
+  // the loads are unconditional (row and column clamped into the source, the value replaced by 0 afterwards): a load behind
+  // a branch makes the number of outstanding loads path-dependent, the compiler then waits with vmcnt(0) right behind the
+  // requests and the prefetch is gone
   auto request = [&](int64_t r) {
+    const int64_t rr = r < n ? r : n - 1;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const int c = t + 256 * j;
-      nxt[j] = (r < n && c < d) ? src[r * rs + (int64_t)c * cs] : (InT)0;
+#if MI_INGEST_PROBE & 64
+      nxt[j] = (InT)(rr + c);
+#else
+      nxt[j] = src[rr * rs + (int64_t)(c < d ? c : d - 1) * cs];     // replaced by 0 where it is USED (no wait here)
+#endif
     }
   };
-  request(blockIdx.x);
-  for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+  // rows of a workgroup come in runs of RUN consecutive rows (run i of workgroup b starts at (i * gridDim.x + b) * RUN): one
+  // row's piece of a slice block of the image is 64 bytes, and consecutive rows of a tile are neighbours in it, so a run
+  // written by ONE workgroup fills whole 256-byte stretches in ONE XCD's L2 instead of leaving half lines in eight of them
+  constexpr int64_t RUN = INIT ? 1 : 4;
+  auto row_of = [&](int64_t it) { return ((it / RUN) * (int64_t)gridDim.x + blockIdx.x) * RUN + it % RUN; };
+  request(row_of(0));
+  for (int64_t it = 0;; ++it) {
+  const int64_t row = row_of(it);
+  if (row >= nrows) {
+    if (it % RUN == 0) break;          // the first row of a run is past the end: so is everything after it
+    continue;
+  }
   const bool valid = row < n;
   double v[PT];
 #pragma unroll
-  for (int j = 0; j < PT; ++j) v[j] = (double)nxt[j];
-  if (!INIT && row + gridDim.x < nrows) request(row + gridDim.x);
+  for (int j = 0; j < PT; ++j) v[j] = (valid && t + 256 * j < d) ? (double)nxt[j] : 0.0;
+  if (!INIT) request(row_of(it + 1));   // past the end: a harmless re-load of the last row
   double scale = 1.0;
   if (norm_mode != 0) {
-    double ss = 0.0, z0 = 0.0, z1 = 0.0;
+    double ss = 0.0;
 #pragma unroll
     for (int j = 0; j < PT; ++j)
       if (t + 256 * j < d) ss += v[j] * v[j];
-    block_sum3(ss, z0, z1);
+    // the one-value form of block_sum3 (same adds in the same order; two thirds of its shuffles carried zeros here)
+#if !(MI_INGEST_PROBE & 32)
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    __syncthreads();
+    if (lane == 0) red[0][wv] = ss;
+    __syncthreads();
+    ss = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+#endif
+#if MI_INGEST_PROBE & 8
+    scale = ss * 1e-3;
+    if (false)
+#endif
+    {
     const double nrm = sqrt(ss);
     scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);
+    }
   }
 #pragma unroll
   for (int j = 0; j < PT; ++j)
@@ -291,18 +328,26 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     for (int e = 0; e < 8; ++e) {
       double vb;
       pk.h[e] = cvt_img(vf[e], img_f16, vb);
+#if !(MI_INGEST_PROBE & 1)
       s_b += vb * vb;
       s_d += (vb - (double)vf[e]) * (vb - (double)vf[e]);
       s_g += (double)vf[e] * (double)vf[e];
+#endif
     }
+#if !(MI_INGEST_PROBE & 4)
     *reinterpret_cast<uint4*>(blk + (swz_chunk(r, ch) << 3)) = pk.u;
-    if (valid) {
+#else
+    if (pk.u.x == 0x12345678u) *reinterpret_cast<uint4*>(blk) = pk.u;
+#endif
+    if (valid && !(MI_INGEST_PROBE & 2)) {
       float4* o = reinterpret_cast<float4*>(out_f32 + orow * dp + c0);
       o[0] = lo;
       o[1] = hi;
     }
   }
+#if !(MI_INGEST_PROBE & 16)
   block_sum3(s_g, s_b, s_d);
+#endif
   if (t == 0) {
     RowStat rsd;
     rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
@@ -401,10 +446,20 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     QueryInit none{};
     none.gallery_rows = npad;
     // persistent grid: eight 256-thread workgroups per CU (the kernel's occupancy), each looping over its rows
-    const unsigned grid = (unsigned)std::min<int64_t>(npad, (int64_t)current_device_cus() * 8);
+    // persistent grid = exactly the workgroups the device holds at once (a workgroup that starts late runs its share of the
+    // rows at a lower occupancy: the launch is bound by the per-row latency chain, not by bytes); runs of 4 rows
 #define MI_GI_LAUNCH(T, PT)                                                                                             \
-  hipLaunchKernelGGL((ingest_query_kernel<T, false, PT>), dim3(grid), dim3(256), 0, stream, (const T*)src, n, d, rs, cs, \
-                     norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base)
+  do {                                                                                                                  \
+    static int occ = 0;                                                                                                 \
+    if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ingest_query_kernel<T, false, PT>, 256, 0) !=       \
+                     hipSuccess || occ < 1))                                                                            \
+      occ = 4;                                                                                                          \
+    if (MI_INGEST_PROBE && getenv("MI_INGEST_WG_PER_CU")) occ = atoi(getenv("MI_INGEST_WG_PER_CU"));                    \
+    if (MI_INGEST_PROBE) fprintf(stderr, "ingest: %d workgroups per CU\n", occ);                                        \
+    const unsigned grid = (unsigned)std::min<int64_t>((npad + 3) / 4, (int64_t)current_device_cus() * occ);             \
+    hipLaunchKernelGGL((ingest_query_kernel<T, false, PT>), dim3(grid), dim3(256), 0, stream, (const T*)src, n, d, rs,  \
+                       cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base);               \
+  } while (0)
     if (dtype == 0) { if (dp <= 2048) MI_GI_LAUNCH(float, 8); else MI_GI_LAUNCH(float, 16); }
     else { if (dp <= 2048) MI_GI_LAUNCH(double, 8); else MI_GI_LAUNCH(double, 16); }
 #undef MI_GI_LAUNCH

@@ -1,5 +1,5 @@
 import ctypes, time, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 import isehr_amd
 from isehr_amd import _lib

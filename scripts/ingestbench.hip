@@ -1,0 +1,72 @@
+// Standalone timing of the gallery ingest kernel (csrc/ingest.hip compiled INTO this program, so that -DMI_INGEST_PROBE=n
+// builds diagnostic variants: 1 = no rounding statistics, 2 = no f32 row store, 4 = no image store; 0 = the product kernel).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -DMI_INGEST_PROBE=0 scripts/ingestbench.hip -o ingestbench
+//   ingestbench [rows] [dim]
+#include "../image-search-engine-for-historical-research_amd/csrc/ingest.hip"
+
+#include <cstdio>
+#include <cstdlib>
+
+// the one symbol ingest.hip takes from another translation unit of the library (select.hip).  The program is NOT linked
+// against libmi355_retrieval.so: with it loaded, the kernel of the same mangled name registered by the library is the one
+// that runs, whatever this file was compiled with.
+namespace mi {
+int current_device_cus() {
+  hipDeviceProp_t p;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipGetDeviceProperties(&p, dev);
+  return p.multiProcessorCount;
+}
+}  // namespace mi
+
+#define CK(e)                                                                      \
+  do {                                                                             \
+    hipError_t _e = (e);                                                           \
+    if (_e != hipSuccess) {                                                        \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(_e)); \
+      exit(2);                                                                     \
+    }                                                                              \
+  } while (0)
+
+__global__ void fill(float* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint64_t x = i * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    p[i] = (float)((int)(x & 0xFFFF) - 32768) * (1.0f / 32768.0f);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int64_t n = argc > 1 ? atoll(argv[1]) : 1005994;
+  const int d = argc > 2 ? atoi(argv[2]) : 2048;
+  const int64_t npad = (n + 255) / 256 * 256;
+  float *src, *out;
+  uint16_t* img;
+  mi::RowStat* rs;
+  CK(hipMalloc(&src, (size_t)n * d * 4));
+  CK(hipMalloc(&out, (size_t)n * d * 4 + 256));
+  CK(hipMalloc(&img, (size_t)npad * d * 2 + 256));
+  CK(hipMalloc(&rs, (size_t)npad * sizeof(mi::RowStat)));
+  hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, src, (size_t)n * d);
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 6; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    mi::launch_ingest(src, 0, n, d, d, 1, 1, out, img, 1, rs, d, npad, 0, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double gb = ((double)n * d * 4 * ((MI_INGEST_PROBE & 2) ? 1 : 2) + ((MI_INGEST_PROBE & 4) ? 0.0 : (double)npad * d * 2)) / 1e9;
+    if (rep) printf("probe %d rows %lld dim %d: %.3f ms, %.2f TB/s of %.1f GB moved\n", MI_INGEST_PROBE, (long long)n, d, ms, gb / ms, gb);
+  }
+  mi::RowStat h;
+  CK(hipMemcpy(&h, rs + 5, sizeof(h), hipMemcpyDeviceToHost));
+  float o5[2];
+  CK(hipMemcpy(o5, out + 5 * (size_t)d, 8, hipMemcpyDeviceToHost));
+  printf("row 5: norms %g %g %g, out %g %g\n", h.norm_f32, h.norm_img, h.norm_diff, o5[0], o5[1]);
+  return 0;
+}
