@@ -10,4 +10,5 @@ python -c "import sys; sys.path.insert(0, '.'); import __graft_entry__ as g; g.b
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 scripts/tile4_probe.hip -o $pkg/build/tile4_probe
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 scripts/tailbench.hip -L$pkg -lmi355_retrieval \
   -Wl,-rpath,'$ORIGIN/..' -o $pkg/build/tailbench
-echo built $pkg/build/tailbench $pkg/build/kbench $pkg/build/mfma_probe $pkg/build/denorm_probe $pkg/build/tile4_probe
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -DMI_INGEST_PROBE=128 scripts/ingestbench.hip -o $pkg/build/ingestbench 2> /dev/null
+echo built $pkg/build/ingestbench $pkg/build/tailbench $pkg/build/kbench $pkg/build/mfma_probe $pkg/build/denorm_probe $pkg/build/tile4_probe
