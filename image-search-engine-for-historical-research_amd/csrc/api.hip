@@ -112,9 +112,9 @@ struct mi_gallery {
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
   int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
-  // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 96
-  // VGPRs per SIMD lane and no LDS: exactly one re-score wave per SIMD fits next to its two); results are valid after
-  // mi_search_join
+  // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 80
+  // VGPRs per SIMD lane and no LDS: exactly one 70-register re-score wave per SIMD fits next to its two); results are
+  // valid after mi_search_join
   int async_tail = 0, tail_set = 0;
   hipStream_t tail_stream = nullptr;
   hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
@@ -2018,6 +2018,13 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
 int mi_set_option(mi_gallery* g, const char* name, double value) {
   REQUIRE(g && name, "null");
   const std::string n(name);
+  if (g->pending.valid) {
+    // a deferred tail (async_tail 3) is enqueued before ANY option changes: it must run with the buffers, caps and workspace
+    // its batch was scored with
+    HIPC(hipSetDevice(g->device));
+    const int rc = flush_pending_tail(g, nullptr, false);
+    if (rc != MI_OK) return rc;
+  }
   if (n == "chunk0_tiles") { REQUIRE(value >= 0, "chunk0_tiles >= 0 (0 = default)"); g->chunk0_tiles = (int)value; }
   else if (n == "spec_max_ratio") { REQUIRE(value >= 1 && value <= 4096, "spec_max_ratio in [1, 4096]"); g->spec_max_ratio = (int)value; }
   else if (n == "workspace_slot") {
@@ -2049,11 +2056,6 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "ladder") g->ladder = value != 0;
   else if (n == "async_tail") {
     REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
-    if (g->pending.valid) {                    // leave no deferred tail behind a change of mode
-      HIPC(hipSetDevice(g->device));
-      const int rc = flush_pending_tail(g, nullptr, false);
-      if (rc != MI_OK) return rc;
-    }
     g->async_tail = (int)value;
   }
   else if (n == "query_norm_override") {
