@@ -228,6 +228,52 @@ struct QueryInit {
   int64_t gallery_rows;    // INIT == false: rows the persistent grid produces (the shard's rows padded to whole tiles)
 };
 constexpr int QI_MAX_PER_THREAD = 16;
+// x of lane (l ^ O): O in {1, 2, 4, 8} as data-parallel-primitive moves inside the 16-lane rows (no LDS crossbar, no
+// address register, a few cycles instead of a ds_bpermute round trip per level): quad permutations for 1 and 2,
+// half-mirror + quad reversal for 4 (7 - i, then 3 - i inside the quad = i ^ 4), mirror + half-mirror for 8 (15 - i, then
+// 7 - i inside the half = i ^ 8).  The same partner as __shfl_xor, so the same sums.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int O>
+__device__ __forceinline__ double xor_lane_f64(double x) {
+  if constexpr (O == 1) return dpp_mov_f64<0xB1>(x);                        // quad_perm [1, 0, 3, 2]
+  else if constexpr (O == 2) return dpp_mov_f64<0x4E>(x);                   // quad_perm [2, 3, 0, 1]
+  else if constexpr (O == 4) return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(x));   // row_half_mirror, quad_perm [3, 2, 1, 0]
+  else if constexpr (O == 8) return dpp_mov_f64<0x141>(dpp_mov_f64<0x140>(x));  // row_mirror, row_half_mirror
+  else if constexpr ((MI_INGEST_PROBE & 256) != 0) return __shfl_xor(x, O);      // A/B: the LDS crossbar for 16 / 32
+  else {
+    // 16 / 32: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (the upper half) of one register with the
+    // even rows (the lower half) of another; fed the same value twice they return [x0 x0 x2 x2] / [x1 x1 x3 x3] (rows) resp.
+    // [lo lo] / [hi hi] (halves), of which every lane picks its partner's (checked against __shfl_xor on the device)
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    unsigned plo, phi;
+    if constexpr (O == 16) {
+      const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      const bool odd_row = (threadIdx.x >> 4) & 1;
+      plo = odd_row ? a[0] : a[1];
+      phi = odd_row ? b[0] : b[1];
+    } else {
+      static_assert(O == 32, "partner distance");
+      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      const bool upper = threadIdx.x & 32;
+      plo = upper ? a[0] : a[1];
+      phi = upper ? b[0] : b[1];
+    }
+    return __hiloint2double((int)phi, (int)plo);
+  }
+}
+// the butterfly of the block reductions below: partners 32, 16, 8, 4, 2, 1 in this order
+__device__ __forceinline__ void wave_butterfly(double& a) {
+  a += xor_lane_f64<32>(a); a += xor_lane_f64<16>(a); a += xor_lane_f64<8>(a);
+  a += xor_lane_f64<4>(a); a += xor_lane_f64<2>(a); a += xor_lane_f64<1>(a);
+}
+
 template <typename InT, bool INIT, int PT>
 __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs,
                                                            int64_t cs, int norm_mode, float* __restrict__ out_f32,
@@ -238,7 +284,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
   __shared__ __attribute__((aligned(16))) float rowbuf[256 * PT];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   auto block_sum3 = [&](double& a, double& b, double& c) {
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    wave_butterfly(a); wave_butterfly(b); wave_butterfly(c);
     __syncthreads();
     if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; }
     __syncthreads();
@@ -293,7 +339,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
       if (t + 256 * j < d) ss += v[j] * v[j];
     // the one-value form of block_sum3 (same adds in the same order; two thirds of its shuffles carried zeros here)
 #if !(MI_INGEST_PROBE & 32)
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    wave_butterfly(ss);
     __syncthreads();
     if (lane == 0) red[0][wv] = ss;
     __syncthreads();
