@@ -621,7 +621,7 @@ constexpr int RESCORE_THREADS = 64;
 constexpr uint32_t RESCORE_GRID_X = 64;     // 128 candidates per query and sweep
 
 // Resident variant for the asynchronous tail: ONE 256-thread workgroup per CU (its four waves land on the four SIMDs), so
-// that the launch occupies exactly the 96 VGPRs per SIMD lane the tile kernel leaves free and the NEXT batch's scoring
+// that the launch occupies no more than the 80 VGPRs per SIMD lane the tile kernel (2 x 216) leaves free and the NEXT batch's scoring
 // launch finds room on every CU at once (a grid of 64 k one-wave workgroups fills the SIMDs with re-score waves first
 // and the persistent kernel then waits for them to drain).  Query q belongs to SUB consecutive waves, which take its
 // candidate pairs round-robin; same arithmetic as rescore_kernel.
