@@ -560,7 +560,10 @@ def main():
             "roofline": roof,
         }
         if world == 1 and scale_10m:
-            out["deferred_tail"] = deferred_tail_block(job, gal, args)
+            try:
+                out["deferred_tail"] = deferred_tail_block(job, gal, args)
+            except (RuntimeError, AssertionError, MemoryError) as e:       # a secondary block never costs the headline
+                out["deferred_tail"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gal, q_last_pool.cpu().numpy(), n_total, args)
     gal.close()
