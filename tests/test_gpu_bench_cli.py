@@ -58,3 +58,17 @@ def test_one_gpu_line_has_the_contract_fields():
     assert {(1024, True), (70, True), (1, True)} <= pts and any(q == 70 and not one for q, one in pts)
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["launches"] == 5
+
+
+def test_default_shape_line_carries_the_secondary_blocks():
+    """The default workload (1 005 994 rows) with the secondary blocks at a reduced cost: `deferred_tail` -- the pipelined
+    mode on the same gallery, whose answer must equal the synchronous one -- and `scale_10m` on a smaller row count."""
+    out = _bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--scale-10m", "on", "--scale-10m-rows", "400000",
+                  "--scale-10m-steps", "2"])
+    assert out["config"]["gallery_rows"] == 1005994 and out["config"]["tail"] == "same stream"
+    d = out["deferred_tail"]
+    assert "error" not in d, d
+    assert d["equals_synchronous_answer"] is True and d["overflow_batches"] == 0
+    assert d["value"] > 0 and 0 < d["kernel_share_of_step"] < 1 and d["steps"] == 100
+    s = out["scale_10m"]
+    assert "error" not in s and s["gallery_rows"] == 400000 and s["image"] == "bf16"
