@@ -96,12 +96,25 @@ def drop_cached_galleries():
 
 
 def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=None, ifgenerate=False,
-                 device=0, return_scores=False):
+                 device=0, return_scores=False, devices=None):
     """Drop-in `--matching_method HIP`.  The timer spans everything the call does (for a stateless
     call that includes the gallery ingest, like matching_L2's timer includes its normalisation,
-    src/utils/nnsearch.py:688-705), device-synchronised."""
+    src/utils/nnsearch.py:688-705), device-synchronised.
+    devices: a list of GPU ids -> the gallery rows are split over them inside THIS process
+    (sharded.MultiDeviceGallery: the reference's drivers are single processes); K <= 2048, stateless."""
     t1 = time.time()
     num_test = np.shape(embedded_features_test)[0]
+    if devices is not None and len(devices) > 1:
+        from .sharded import MultiDeviceGallery
+        if int(K) > TOPK_PATH_MAX_K or isinstance(embedded_features_train, ColumnBlocks):
+            raise ValueError("devices=[...]: top-K path only (K <= %d), one host array" % TOPK_PATH_MAX_K)
+        mg = MultiDeviceGallery.from_host(np.asarray(embedded_features_train), devices, NORM_L2)
+        try:
+            idx, scores = mg.search(embedded_features_test, int(K))
+        finally:
+            mg.close()
+        tpq = (time.time() - t1) / num_test
+        return (idx, tpq, scores) if return_scores else (idx, tpq)
     g = get_gallery(embedded_features_train, dataset, ifgenerate, NORM_L2, device)
     try:
         if int(K) > TOPK_PATH_MAX_K:

@@ -288,3 +288,118 @@ class ShardedGallery:
         _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)
         idx, sc = self.search(qx, k, query_norm_none=True, join=join)
         return idx, sc, qx
+
+
+class MultiDeviceGallery:
+    """ONE process, several GPUs of the node: the reference's drivers are single processes (src/offline.py, src/online.py,
+    src/test_rOP1m.py), so a drop-in `matching_HIP(..., devices=[0, 1, ...])` cannot rely on a launcher.  The gallery rows are
+    split contiguously over `devices` (shard_bounds), one handle per device, and a query batch runs the same two-phase
+    protocol as ShardedGallery -- phase 1 on every device, the K-th largest approximate score of the union, phase 2 on
+    every device, merge -- with device-to-device copies (peer transfers over xGMI, stream-ordered by torch) where the
+    one-process-per-GPU form has its RCCL all-gathers.  Answers are those of one single-device gallery, bit for bit
+    (float32 queries; float64 queries are rounded to float32 first: the phase entry points take float32 device rows).
+    The benchmark and the scaling runs use the process-per-GPU form (bench.py); this class is the convenience for callers
+    that cannot be started N times."""
+
+    def __init__(self, shards, devices):
+        self.shards, self.devices = list(shards), [int(d) for d in devices]
+        self.n, self.d = sum(s.n for s in self.shards), self.shards[0].d
+        self.norm_mode = self.shards[0].norm_mode
+        # one error margin and one image element type for all shards (ShardedGallery._agree, DESIGN section 4 "Shards")
+        f16 = min(int(s.get_option("image_dtype")) for s in self.shards)
+        for s in self.shards:
+            if int(s.get_option("image_dtype")) != f16:
+                s.set_image_dtype(f16)
+        bounds = [max(v) for v in zip(*[s.norm_bounds() for s in self.shards])]
+        for s in self.shards:
+            s.norm_bounds(raise_to=bounds)
+            s.set_option("rescore_grid_x", max(8, min(64, round(96 / len(self.shards)))))
+
+    @classmethod
+    def from_host(cls, rows, devices, norm_mode=_lib.NORM_L2):
+        """rows: [N, D] float32 / float64 host array, any strides (`vecs.T` of the reference's [D, N])."""
+        n = rows.shape[0]
+        shards = []
+        try:
+            for r, dev in enumerate(devices):
+                lo, hi = shard_bounds(n, len(devices), r)
+                if hi <= lo:
+                    raise ValueError("more devices than gallery rows")
+                shards.append(_lib.Gallery.from_host(rows[lo:hi], norm_mode=norm_mode, device=int(dev), row_offset=lo))
+        except Exception:
+            for s in shards:
+                s.close()
+            raise
+        return cls(shards, devices)
+
+    def close(self):
+        for s in self.shards:
+            s.close()
+        self.shards = []
+
+    def _batch(self, qb, k):
+        import torch
+        G, nq = len(self.shards), qb.shape[0]
+        dev0 = torch.device("cuda", self.devices[0])
+        approx, packs = [], []
+        for s, dv in zip(self.shards, self.devices):
+            dev = torch.device("cuda", dv)
+            with torch.cuda.device(dev):
+                q = torch.from_numpy(qb).to(dev)
+                a = torch.empty((nq, k), dtype=torch.float32, device=dev)
+                s.phase1_device(q.data_ptr(), nq, k, a.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                approx.append(a)
+        with torch.cuda.device(dev0):
+            gathered = torch.stack([a.to(dev0) for a in approx]).contiguous()            # [G, nq, k]: the "all-gather"
+            L0 = torch.empty((nq,), dtype=torch.float32, device=dev0)
+            _lib.kth_of_gathered_device(gathered.data_ptr(), G, nq, k, L0.data_ptr(),
+                                        torch.cuda.current_stream(dev0).cuda_stream)
+        for s, dv in zip(self.shards, self.devices):
+            dev = torch.device("cuda", dv)
+            with torch.cuda.device(dev):
+                L = L0.to(dev)
+                pack = torch.empty((2, nq, k), dtype=torch.int64, device=dev)            # f64 score bits, global row ids
+                sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+                s.phase2_device(nq, k, L.data_ptr(), pack[1].data_ptr(), sc.data_ptr(), pack[0].data_ptr(),
+                                torch.cuda.current_stream(dev).cuda_stream)
+                packs.append(pack)
+        with torch.cuda.device(dev0):
+            allp = torch.stack([p.to(dev0) for p in packs]).contiguous()                 # [G, 2, nq, k]
+            oidx = torch.empty((nq, k), dtype=torch.int64, device=dev0)
+            osc = torch.empty((nq, k), dtype=torch.float32, device=dev0)
+            _lib.topk_merge_strided_device(allp[0, 0].data_ptr(), allp[0, 1].data_ptr(), 2 * nq * k, G, nq, k,
+                                           oidx.data_ptr(), osc.data_ptr(), torch.cuda.current_stream(dev0).cuda_stream)
+            torch.cuda.synchronize(dev0)
+        return oidx.cpu().numpy(), osc.cpu().numpy()
+
+    def search(self, queries, k):
+        """queries: [Q, D] host array -> (idx int64 [Q, k] of GLOBAL row ids, score float32 [Q, k]); any Q (batches of 1024).
+        A batch that raised a sticky flag on any shard (failed speculative threshold, candidate-buffer overflow) is answered
+        again with the fallbacks of the host entry point, like ShardedGallery.search(verify=True)."""
+        q = np.ascontiguousarray(np.asarray(queries), dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("queries must be [Q, %d]" % self.d)
+        if k > self.n:
+            raise RuntimeError("mi355_retrieval error 1: k > number of gallery rows")
+        out_i = np.empty((q.shape[0], k), dtype=np.int64)
+        out_s = np.empty((q.shape[0], k), dtype=np.float32)
+        for q0 in range(0, q.shape[0], 1024):
+            qb = q[q0:q0 + 1024]
+            idx, sc = self._batch(qb, k)
+            if any([s.flags() for s in self.shards]):          # a list: every shard's flags are read (and cleared)
+                for name, val in (("speculative", 0), ("force_exact", 1)):
+                    prev = [s.get_option(name) for s in self.shards]
+                    for s in self.shards:
+                        s.set_option(name, val)
+                    try:
+                        idx, sc = self._batch(qb, k)
+                        bad = any([s.flags() for s in self.shards])
+                    finally:
+                        for s, p in zip(self.shards, prev):
+                            s.set_option(name, p)
+                    if not bad:
+                        break
+                else:
+                    raise RuntimeError("multi-device search: candidate buffers overflow even with the f32 scorer")
+            out_i[q0:q0 + qb.shape[0]], out_s[q0:q0 + qb.shape[0]] = idx, sc
+        return out_i, out_s

@@ -493,3 +493,34 @@ def test_qge_large_branch_accepts_column_blocks():
     assert np.array_equal(a["ranks_aqe"], b["ranks_aqe"])
     assert a["map_aqe"] == b["map_aqe"]
     assert np.array_equal(a["qvecs_qe"], b["qvecs_qe"])
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_multi_device_gallery_in_one_process_equals_single_device(ndev):
+    """sharded.MultiDeviceGallery / matching_HIP(devices=[...]): the row shards of ONE process (the reference's drivers are
+    single processes).  The test box has one GPU, so every "device" is GPU 0 -- the code path (per-device handles, phase
+    API, device-to-device copies, merge) is the one several GPUs take; answers equal the single-handle search bit for bit,
+    through a strided `vecs.T` view and over a batch boundary (1100 queries), and a raised flag triggers the fallbacks."""
+    from isehr_amd import _lib, nnsearch
+    from isehr_amd.sharded import MultiDeviceGallery
+    n, d, nq, k = 41003, 192, 1100, 100
+    vecs = np.ascontiguousarray(synth_rows(301, 0, n, d).T)                  # the reference's [D, N] layout
+    qv = synth_rows(302, 0, nq, d)
+    single = _lib.Gallery.from_host(vecs.T)
+    ref_idx, ref_sc, _ = single.search(qv, k)
+    single.close()
+    idx, t, sc = nnsearch.matching_HIP(k, vecs.T, qv, devices=[0] * ndev, return_scores=True)
+    assert np.array_equal(idx, ref_idx) and np.array_equal(sc, ref_sc) and t > 0
+    mg = MultiDeviceGallery.from_host(vecs.T, [0] * ndev)
+    try:
+        assert mg.n == n and len(mg.shards) == ndev
+        # a reduced survivor capacity on every shard: whichever path ends up answering (filter, or the fallbacks after a
+        # raised overflow flag), the answer is the same
+        for s in mg.shards:
+            s.set_option("survivor_cap", 4096)
+        i2, s2 = mg.search(qv[:70], k)
+        assert np.array_equal(i2, ref_idx[:70]) and np.array_equal(s2, ref_sc[:70])
+        with pytest.raises(RuntimeError):
+            mg.search(qv[:4], n + 1)
+    finally:
+        mg.close()
