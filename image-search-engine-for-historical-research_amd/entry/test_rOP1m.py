@@ -24,15 +24,17 @@ parser.add_argument("--mode", default="100", help="'mAP' (rank as deep as the HI
 parser.add_argument("--gnd-dir", default="data/test")
 parser.add_argument("--synthetic", type=int, default=0, help="use a planted synthetic dataset with this many rows")
 parser.add_argument("--dim", type=int, default=2048)
-parser.add_argument("--gpu-id", "-g", default="0")
+parser.add_argument("--gpu-id", "-g", default="0", help="one GPU id, or a comma-separated list: the matcher then splits the "
+                                                        "gallery rows over those GPUs inside this process (top-K modes)")
 
 
-def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0):
+def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0, devices=None):
     from ..nnsearch import ColumnBlocks
     blocks = isinstance(vecs, ColumnBlocks)
     n = vecs.shape[0] if blocks else vecs.shape[1]
     K = n if mode == "mAP" else int(mode)                 # 'mAP' ranks the whole database (src/test_rOP1m.py:144-149)
-    match_idx, time_per_query = matching_HIP(K, vecs if blocks else vecs.T, qvecs.T, device=device)
+    match_idx, time_per_query = matching_HIP(K, vecs if blocks else vecs.T, qvecs.T, device=device,
+                                             devices=devices if (devices and K <= 2048 and not blocks) else None)
     ranks = match_idx.T
     print(">> {}: average matching time: {}".format(dataset, time_per_query))
     res = {"map": evaluate.compute_map_and_print(dataset, ranks, gnd)}
@@ -42,10 +44,11 @@ def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0):
 
 def main(argv=None):
     args = parser.parse_args(argv)
-    dev = int(args.gpu_id)
+    ids = [int(v) for v in str(args.gpu_id).split(",")]
+    dev, devices = ids[0], (ids if len(ids) > 1 else None)
     if args.synthetic:
         vecs, qvecs, gnd = planted_dataset(1234, args.synthetic, args.dim, 70)
-        run_dataset("roxford5k-synthetic", vecs, qvecs, gnd, args.mode, dev)
+        run_dataset("roxford5k-synthetic", vecs, qvecs, gnd, args.mode, dev, devices)
         return 0
     for dataset in args.datasets.split(","):
         vecs, _ = load_path_features(dataset + "_db")
@@ -59,7 +62,7 @@ def main(argv=None):
             vecs = ColumnBlocks([vecs, v1m])
         with open("{}/{}/gnd_{}.pkl".format(args.gnd_dir, dataset, dataset), "rb") as f:
             gnd = pickle.load(f)["gnd"]
-        run_dataset(dataset, vecs, qvecs, gnd, args.mode, dev)
+        run_dataset(dataset, vecs, qvecs, gnd, args.mode, dev, devices)
     return 0
 
 

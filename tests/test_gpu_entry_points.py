@@ -57,12 +57,13 @@ def test_offline_then_online(feature_store, capsys):
     assert ".jpg" in capsys.readouterr().out
 
 
-@pytest.mark.parametrize("mode", ["100", "mAP"])
-def test_test_rop1m_driver(feature_store, capsys, mode):
+@pytest.mark.parametrize("mode,gpus", [("100", "0"), ("mAP", "0"), ("100", "0,0")])
+def test_test_rop1m_driver(feature_store, capsys, mode, gpus):
+    """--gpu-id 0,0: two row shards inside the driver's one process (both on the test box's only GPU)."""
     from isehr_amd import evaluate
     from isehr_amd.entry import test_rOP1m
     vecs, qvecs, gnd = feature_store
-    assert test_rOP1m.main(["--datasets", "roxford5k", "--ifextracted", "--mode", mode]) == 0
+    assert test_rOP1m.main(["--datasets", "roxford5k", "--ifextracted", "--mode", mode, "--gpu-id", gpus]) == 0
     out = capsys.readouterr().out
     assert "average matching time" in out and "mAP E:" in out
     # the printed mAP is the oracle's for the same ranking depth
