@@ -111,6 +111,7 @@ struct mi_gallery {
   int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
   int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
+  int boot_ksplit = 1;          // small batches: K-split bootstrap launch (kernels.h ScoreArgs::ksplit); 0 = one workgroup per tile
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
   // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 80
   // VGPRs per SIMD lane and no LDS: exactly one 70-register re-score wave per SIMD fits next to its two); results are
@@ -369,8 +370,18 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   const uint32_t first_cnt = (uint32_t)(samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
   const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
   // query ingest (normalise, f32 rows, 16-bit image, rounding norms) and the per-query search state in one launch
+  // small batches on the sample schedule: the bootstrap launch splits K over several workgroups per (sample tile, query
+  // group) and adds its partial scores onto zeros that the query ingest writes (ScoreArgs::ksplit)
+  int32_t boot_ksplit = 1;
+  if (samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && g->debug == 0 &&
+      sample_threshold_applies(first_cnt, k, samp_r) && g->dp <= 4096) {
+    const int64_t wgs = t0 * ((nq + 63) / 64);                       // bootstrap workgroups of a batch of <= 512 queries
+    if (nq <= 512)
+      while (boot_ksplit < 8 && wgs * boot_ksplit * 2 <= 256 && (g->dp / SLICE_K) % (boot_ksplit * 2) == 0) boot_ksplit *= 2;
+  }
   if (!launch_ingest_queries(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp,
-                             qpad, g->gstat3, gamma, exact ? 0 : 1, first_cnt, st, s)) {
+                             qpad, g->gstat3, gamma, exact ? 0 : 1, first_cnt, st, s, boot_ksplit > 1 ? first_cnt : 0u)) {
+    boot_ksplit = 1;
     launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, qpad, s);
     launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
   }
@@ -422,6 +433,7 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     a.bal = g->xcc_balance ? ws.bal : nullptr;
     a.lad_k = ladder_on ? k : 0;
     a.scores_only = (on_sample && first_chunk && sample_f32) ? 1 : 0;
+    a.ksplit = a.scores_only ? boot_ksplit : 1;
     a.dbg = ws.dbg;
     a.st = st;
     profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
@@ -452,7 +464,8 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       lad_r = std::max<int32_t>(1, std::min<int32_t>(lad_r, samp_r - 1));
     }
     if (sample_threshold_applies(first_cnt, k, samp_r)) {
-      launch_sample_threshold(st, nq, k, samp_r, first_cnt, s, lad_r, sample_f32 ? 1 : 0);
+      launch_sample_threshold(st, nq, k, samp_r, first_cnt, s, lad_r, sample_f32 ? 1 : 0,
+                              (sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f);
       ladder_on = lad_r > 0;
     } else {
       launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
@@ -2008,6 +2021,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "kernel_variant") *out_value = g->kernel_variant;
   else if (n == "xcc_balance") *out_value = g->xcc_balance;
   else if (n == "ladder") *out_value = g->ladder;
+  else if (n == "boot_ksplit") *out_value = g->boot_ksplit;
   else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
@@ -2054,6 +2068,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
   else if (n == "ladder") g->ladder = value != 0;
+  else if (n == "boot_ksplit") g->boot_ksplit = value != 0;
   else if (n == "async_tail") {
     REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
     g->async_tail = (int)value;

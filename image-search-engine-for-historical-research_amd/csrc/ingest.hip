@@ -226,6 +226,8 @@ struct QueryInit {
   int32_t nq;
   QueryState st;
   int64_t gallery_rows;    // INIT == false: rows the persistent grid produces (the shard's rows padded to whole tiles)
+  uint32_t zero_scores;    // INIT: the first zero_scores 4-byte sample scores of every query are set to 0 (a K-split
+                           // bootstrap launch adds its partial scores onto them, ScoreArgs::ksplit); 0 = leave them alone
 };
 constexpr int QI_MAX_PER_THREAD = 16;
 // x of lane (l ^ O): O in {1, 2, 4, 8} as data-parallel-primitive moves inside the 16-lane rows (no LDS crossbar, no
@@ -327,6 +329,10 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     continue;
   }
   const bool valid = row < n;
+  if (INIT && qi.zero_scores && row < qi.nq) {
+    float* z = reinterpret_cast<float*>(qi.st.surv + (uint64_t)row * qi.st.cap);
+    for (uint32_t i = t; i < qi.zero_scores; i += 256) z[i] = 0.f;
+  }
   double v[PT];
 #pragma unroll
   for (int j = 0; j < PT; ++j) v[j] = (valid && t + 256 * j < d) ? (double)nxt[j] : 0.0;
@@ -442,9 +448,10 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
 bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                            float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int32_t qpad,
                            const float* gstat3, float gamma, int use_img_terms, uint32_t first_cnt, const QueryState& st,
-                           hipStream_t stream) {
+                           hipStream_t stream, uint32_t zero_scores) {
   if (dp > 256 * QI_MAX_PER_THREAD) return false;         // wider rows: the two-launch path
   QueryInit qi;
+  qi.zero_scores = zero_scores;
   qi.gstat3 = gstat3;
   qi.gamma = gamma;
   qi.use_img_terms = use_img_terms;

@@ -13,7 +13,7 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
 bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                            float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int32_t qpad,
                            const float* gstat3, float gamma, int use_img_terms, uint32_t first_cnt, const struct QueryState& st,
-                           hipStream_t stream);
+                           hipStream_t stream, uint32_t zero_scores = 0);
 // bootstrap sample image (n_s = multiple of TILE rows, one hashed draw per stratum of the shard)
 void launch_build_sample(const void* gal_img, void* samp_img, int64_t n, int64_t n_s, int32_t dp, hipStream_t stream);
 int64_t sample_source_row_host(int64_t i, int64_t n, int64_t n_s);   // row_base: output rows start here (gallery append); src row 0 <-> row_base
@@ -43,6 +43,11 @@ struct ScoreArgs {
   int32_t scores_only = 0;           // bootstrap launch on the sample image (stream_select MODE 2): store the scores as 4-byte
                                      // floats at ((float*)(surv + q * cap))[sample row] instead of 8-byte (score, row) entries --
                                      // sample_threshold_kernel reads nothing but the scores, and the entries are dropped afterwards
+  int32_t ksplit = 1;                // bootstrap launch with scores_only: workgroups per (sample tile, query group), each taking
+                                     // nslices / ksplit K-slices and ADDING its partial scores (atomic f32 adds onto zeros
+                                     // written by the query ingest): small batches have 32 .. 64 bootstrap workgroups of 64
+                                     // serial slices each otherwise.  The sum order is then not fixed -- the sample scores
+                                     // feed the speculative (verified) threshold and the ladder level only
   unsigned long long* dbg; // diagnostics (DBG & 8): per-wave cycle sums, [grid * 8][8]
   QueryState st;
 };
@@ -89,7 +94,7 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 void set_tail_debug_phase(int phase);   // diagnostics only (scripts/tailbench.hip): selection kernels return after phase N; 0 = product
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r = 0, int32_t f32_scores = 0);   // f32_scores: see ScoreArgs::scores_only
+                             int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f);   // f32_scores: see ScoreArgs::scores_only
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows = nullptr, uint32_t* cand_cnt = nullptr,

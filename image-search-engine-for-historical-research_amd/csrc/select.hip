@@ -400,7 +400,8 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
-                                                                        int32_t lad_r, int32_t f32_scores, int dbg_phase) {
+                                                                        int32_t lad_r, int32_t f32_scores, int dbg_phase,
+                                                                        float order_slack) {
   __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
   __shared__ __attribute__((aligned(16))) uint32_t hist[1024];   // the select's histograms; first 256 words: gather buffer
   __shared__ uint32_t sh[8];
@@ -458,7 +459,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist);
   }
   if (threadIdx.x == 0) {
-    const float margin = margin_q;
+    // order_slack: the sample scores were summed in another order than the scoring launch sums (K-split bootstrap,
+    // ScoreArgs::ksplit).  Two f32 summation orders of the same products differ by at most gamma |q^| |g^| <= eps = margin / 2
+    // (DESIGN section 4), and the verification below has no slack of its own: with exact duplicates at rank r the threshold
+    // would sit an ulp above the scores the scoring launch gives those very rows.  Half a margin more keeps them.
+    const float margin = margin_q * (1.0f + order_slack);
     // thr = score(r) - margin (>= the rigorous L_sample - margin since r < K); thr2 = score(min(4r, K)) - margin
     // minus the margin: the verification asks for L - margin >= thr, and L >= score(r) is what the rank guarantees
     const float thr = key2f(key1) - margin, thr2 = key2f(key2) - margin;
@@ -485,19 +490,19 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
 }
 
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r, int32_t f32_scores) {
+                             int32_t lad_r, int32_t f32_scores, float order_slack) {
   if (first_cnt == SAMP_THREADS * 2u)
     hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase);
+                       g_tail_debug_phase, order_slack);
   else if (first_cnt == SAMP_THREADS * 4u)
     hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase);
+                       g_tail_debug_phase, order_slack);
   else if (first_cnt == SAMP_THREADS * 8u)
     hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase);
+                       g_tail_debug_phase, order_slack);
   else
     hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase);
+                       g_tail_debug_phase, order_slack);
 }
 
 // ------------------------------------------------------------------------------------------------

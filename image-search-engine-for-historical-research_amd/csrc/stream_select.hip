@@ -48,8 +48,11 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   // bootstrap launches are not persistent: one workgroup per (tile, group of NQB * 16 queries), so that a 1024-query
   // batch spreads its 32 sample tiles over 256 CUs instead of 128 tile-kernel workgroups of a full tile time each
   const uint32_t ntiles = (uint32_t)p.ntiles;
-  const uint32_t qg = FIRST ? blockIdx.x / ntiles : 0u;
-  const uint32_t b = FIRST ? blockIdx.x % ntiles : blockIdx.x, nwg = FIRST ? ntiles : gridDim.x;
+  // bootstrap, small batches: KS workgroups share one (tile, query group), each a contiguous range of K-slices (ksplit)
+  const uint32_t KS = FIRST ? (uint32_t)p.ksplit : 1u;
+  const uint32_t ks = FIRST ? blockIdx.x % KS : 0u, bid = FIRST ? blockIdx.x / KS : blockIdx.x;
+  const uint32_t qg = FIRST ? bid / ntiles : 0u;
+  const uint32_t b = FIRST ? bid % ntiles : bid, nwg = FIRST ? ntiles : gridDim.x;
   const uint32_t q0 = qg * NQB * 16;                          // first query of this workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,7 +62,8 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
   }
   const uint32_t my_tiles = (ntiles - b + nwg - 1) / nwg;
   const uint32_t KSL = (uint32_t)p.nslices;
-  const uint32_t T_total = my_tiles * KSL;
+  const uint32_t s0 = ks * (KSL / KS), s1 = FIRST ? s0 + KSL / KS : KSL;      // this workgroup's K-slices of a tile
+  const uint32_t T_total = FIRST ? s1 - s0 : my_tiles * KSL;
   const int l15 = lane & 15, lq = lane >> 4;
 
   float* thr_s = reinterpret_cast<float*>(smem + THR0);       // thresholds of the NQB * 16 queries (+inf for padding)
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
 
   // ---- DMA stream: slice s of my i-th tile, continuous over tile boundaries
   const bool qloader = w < NQB;
-  uint32_t pf_i = 0, pf_sl = 0, wr_slot = 0;
+  uint32_t pf_i = 0, pf_sl = s0, wr_slot = 0;
   // wave-uniform bases (scalar registers) + one per-lane byte offset: the DMA instructions take the saddr form and
   // the second gallery piece is the instruction's immediate offset (added to the global and the LDS address)
   const char* pfa;
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
     pfa = reinterpret_cast<const char*>(p.gal_img) + (int64_t)gt * KSL * SLICE_BYTES + w * 2048;
   };
   pf_set(0);
+  pfa += (int64_t)s0 * SLICE_BYTES;
   auto issue = [&]() {
     uint32_t off = pf_lane;
     asm volatile("" : "+v"(off));          // keeps the zero extension in this block (saddr form selection)
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
 #pragma unroll
   for (int d = 0; d < SS_DEPTH - 1; ++d) issue();             // slices 0 .. DEPTH-2 in flight
 
-  uint32_t rd = 0, cur_i = 0, cur_sl = 0;
+  uint32_t rd = 0, cur_i = 0, cur_sl = s0;
   for (uint32_t S = 0; S < T_total; ++S) {
     // my pieces of slice S have landed when at most DEPTH-2 later slices of mine are outstanding
     if (qloader) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
         else
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
 
-    if (++cur_sl == KSL) {
+    if (++cur_sl == s1) {
       cur_sl = 0;
       // ---- tile finished: filter.  C layout of 16x16x32: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
       const uint32_t gt = (uint32_t)p.tile0 + b + cur_i * nwg;
@@ -172,8 +177,12 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
           for (int it = 0; it < TILE / 64; ++it) {
             const uint32_t rl = it * 64 + lane;
             if (row0 + rl < (uint64_t)p.n) {
-              if (p.scores_only) dstf[rl] = T[qi * TSTR + rl];
-              else dst[rl] = pack_entry(T[qi * TSTR + rl], row0 + rl);
+              if (p.scores_only) {
+                if (KS > 1) atomicAdd(dstf + rl, T[qi * TSTR + rl]);      // partial score of this K range, onto zeros
+                else dstf[rl] = T[qi * TSTR + rl];
+              } else {
+                dst[rl] = pack_entry(T[qi * TSTR + rl], row0 + rl);
+              }
             }
           }
         }
@@ -233,7 +242,8 @@ template <int NQB, bool F16, int MODE>
 static void launch_stream_variant(const ScoreArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)SS_DEPTH * SLICE_BYTES + (size_t)SS_DEPTH * NQB * 1024 + NQB * 16 * 4;
   ensure_dynamic_lds((const void*)stream_select_kernel<NQB, F16, MODE>);
-  const unsigned grid = MODE == 2 ? (unsigned)a.ntiles * (unsigned)((a.nq + NQB * 16 - 1) / (NQB * 16)) : gemm_select_grid();
+  const unsigned grid = MODE == 2 ? (unsigned)a.ntiles * (unsigned)((a.nq + NQB * 16 - 1) / (NQB * 16)) * (unsigned)a.ksplit
+                                  : gemm_select_grid();
   hipEvent_t e0, e1;
   take_launch_events(&e0, &e1);
   if (e0 && e1) hipExtLaunchKernelGGL((stream_select_kernel<NQB, F16, MODE>), dim3(grid), dim3(512), lds, stream, e0, e1, 0, a);

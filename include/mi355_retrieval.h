@@ -259,7 +259,8 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchro
  * be enqueued before phase 2 of batch i; sticky flags and statistics are one set for both),
  * "spec_max_ratio" (largest shard rows / sample rows for which the single-launch sample schedule is taken; default 160),
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
- * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "xcc_balance" (XCD shares by measured
+ * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "boot_ksplit" (batches of < 128 queries: the bootstrap launch
+ * on the sample splits K over several workgroups that add their partial scores; default 1), "xcc_balance" (XCD shares by measured
  * speed), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),

@@ -241,6 +241,34 @@ def test_small_batch_kernel_equals_tile_kernel(lib, nq):
     assert oracle.check_topk_parity(idx1, s, k, TAU) == []
 
 
+@pytest.mark.parametrize("nq", [1, 16, 70, 128, 300])
+def test_ksplit_bootstrap_gives_the_same_answers_and_needs_no_fallback(lib, nq):
+    """Small batches: the bootstrap launch on the sample splits K over several workgroups per (tile, query group) and ADDS
+    its partial scores (option "boot_ksplit", kernels.h ScoreArgs::ksplit) -- the sample scores then come from another
+    summation order than the scoring launch's, which is why the threshold carries half a margin more: with 300 exact
+    duplicates at the top (every one of them AT the speculative threshold) no query may lose them to an ulp and fall back.
+    Same answers with the option off; 300 queries (5 groups: no split) take the one-workgroup form either way."""
+    from isehr_amd._lib import Gallery
+    n, d, k = 60000, 512, 100
+    g = synth_rows(95, 0, n, d)
+    g[2000:2300] = g[11]                                    # 300 exact ties of query 0's best row
+    q = np.concatenate([g[11:12], synth_rows(96, 0, max(1, nq - 1), d)])[:nq]
+    G = Gallery.from_host(g)
+    try:
+        assert G.get_option("boot_ksplit") == 1
+        for rep in range(3):                                # the order of the atomic adds differs from run to run
+            idx1, sc1, _ = G.search(q, k)
+            assert G.status(reset=True)["overflow_batches"] == 0
+        G.set_option("boot_ksplit", 0)
+        idx0, sc0, _ = G.search(q, k)
+        assert G.status()["overflow_batches"] == 0
+    finally:
+        G.close()
+    assert np.array_equal(idx0, idx1) and np.array_equal(sc0, sc1)
+    assert list(idx1[0][:3]) == [11, 2000, 2001]
+    assert oracle.check_topk_parity(idx1, oracle.exact_scores_f64(g, q), k, TAU) == []
+
+
 def test_ordered_gallery_keeps_the_fast_path(lib):
     """The reference's 1M gallery is [rOxford | distractors] (src/test_rOP1m.py:136-139): every true positive of a
     query sits in the first rows.  The bootstrap sample is drawn evenly from the whole shard, so that such an ordering
