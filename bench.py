@@ -96,15 +96,15 @@ def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) as a CHILD process group
     -- this process has not imported torch nor touched the GPU, and it does not exec -- pass their output through (rank 0
     prints the one JSON line) and return their exit code."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import uuid
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    # c10d rendezvous on 127.0.0.1 with port 0: the store binds a free port ITSELF (what --standalone does, minus the host
+    # name lookup) -- no window between picking a port and using it, so concurrent bench runs cannot collide
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--rdzv-backend", "c10d", "--rdzv-endpoint", "127.0.0.1:0", "--rdzv-id", uuid.uuid4().hex,
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -553,10 +553,13 @@ def main():
                        "launch": "hipGraph replay of the per-batch launch sequence" if res["graph"] else "eager",
                        "collectives": ("asynchronous, three batches in flight (search_stream)" if res["use_stream"] else
                                        "synchronous per batch") if res["protocol"] else None,
-                       "tail": ("re-score + sort of batch i on a second stream beside the %s of batch i+1; joined inside "
-                                "the timed region" % ("scoring launch" if args.async_tail == 1 else
-                                                      "query ingest + bootstrap (not the scoring launch)"))
-                               if res["pipelined"] else "same stream",
+                       "tail": ({1: "re-score + sort of batch i on the handle's own stream from the end of its phase 1: beside "
+                                    "the query ingest, bootstrap AND scoring launch of batch i+1",
+                                 2: "re-score + sort of batch i on the handle's own stream beside the query ingest + "
+                                    "bootstrap of batch i+1 only; its scoring launch waits for the tail",
+                                 3: "deferred: re-score + sort of batch i enqueued by the call of batch i+1 right before "
+                                    "its scoring launch, and runs beside that launch only"}[args.async_tail] +
+                                "; every result joined inside the timed region") if res["pipelined"] else "same stream",
                        "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
                        # ingest_s = one normalisation + layout pass over the resident raw rows in a warm process (the second

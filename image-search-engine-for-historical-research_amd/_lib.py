@@ -26,7 +26,7 @@ class SearchStats(C.Structure):
     _fields_ = [("searches", C.c_int64), ("queries", C.c_int64), ("overflow_batches", C.c_int64),
                 ("survivors", C.c_int64), ("candidates", C.c_int64), ("gemm_ms", C.c_double),
                 ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
-                ("kernel_clock_mhz", C.c_double)]
+                ("kernel_clock_mhz", C.c_double), ("spec_retries", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -93,6 +93,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_int32, C.c_double, C.c_int, C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
+    "mi_profile_launch_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "mi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mi_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "mi_search_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
@@ -456,6 +457,13 @@ class Gallery:
         out = np.zeros((nseg, 8), dtype=np.uint64)
         check(load().mi_debug_read_cycles(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
+
+    def launch_ms(self, cap=65536):
+        """Durations (ms) of the timed scoring launches since the last status(reset=True), in launch order."""
+        out = np.zeros(cap, dtype=np.float32)
+        n = C.c_int64(0)
+        check(load().mi_profile_launch_ms(self._h, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:min(cap, n.value)].copy()
 
     def status(self, reset=False):
         st = SearchStats()

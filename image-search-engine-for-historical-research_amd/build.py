@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("HIPCC_EXTRA", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

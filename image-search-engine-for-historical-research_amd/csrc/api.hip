@@ -141,6 +141,7 @@ struct mi_gallery {
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  std::vector<float> launch_ms_log;   // duration of every timed scoring launch since the last statistics reset (capped)
   hipStream_t ev_stream = nullptr;
   // grow-only device staging of the host entry point mi_knn_search (queries in, results out): a hipMalloc / hipFree
   // pair per call costs more than a single-query search
@@ -292,6 +293,7 @@ static void prof_collect(mi_gallery* g) {
         hipEventElapsedTime(&ms, g->ev_pool[i].first, g->ev_pool[i].second) == hipSuccess) {
       g->stats.gemm_ms += ms;
       g->stats.gemm_launches += 1;
+      if (g->launch_ms_log.size() < (size_t)1 << 16) g->launch_ms_log.push_back(ms);
     }
   }
   g->ev_used = 0;
@@ -339,8 +341,12 @@ static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
 // fuse_cand: the final maintain launch also writes the candidate lists (single-shard search: its L is the global one)
 static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring);
 
+// caller_checks_flags: the caller synchronises, reads the sticky flags itself and answers a flagged batch again (the host
+// entry points): small batches then launch no device-side repair pass.  The asynchronous device / phase entry points pass
+// false -- their callers may never look at the flags, so a failed speculative threshold is repaired on the device.
 static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
-                        int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false) {
+                        int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false,
+                        bool caller_checks_flags = false) {
   Workspace& ws = g->ws;
   uint32_t* fc_rows = fuse_cand ? ws.cand_rows : nullptr;
   uint32_t* fc_cnt = fuse_cand ? ws.cand_cnt : nullptr;
@@ -483,10 +489,12 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     // repair pass for queries whose speculative threshold failed verification (1e-7 per query): conditional on the device
     // word flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip.  Batches
     // of <= 128 queries -- the reference's own shapes, one query online and 70 per test set, where three empty launches
-    // are 2 % of the batch and a failure has probability <= 1e-5 -- do without: a failed query raises FLAG_SPEC_FAIL at
-    // once and the batch is answered again by the rigorous schedule (host entry points do that themselves, device-API
-    // callers poll mi_search_flags; ShardedGallery.search(verify=True)).  Option "device_repair" overrides.
-    const bool repair_pass = g->device_repair < 0 ? nq > STREAM_MAX_QUERIES : g->device_repair != 0;
+    // are 1 % of the batch and a failure has probability <= 1e-5 -- do without WHEN THE CALLER IS A HOST ENTRY POINT: that
+    // one synchronises anyway, sees FLAG_SPEC_FAIL and answers the batch again by the rigorous schedule.  The asynchronous
+    // device and phase entry points keep the repair pass at every batch size (round 4: their callers -- sharded protocol,
+    // pipelined streams, alpha-QE re-search -- need not read the flags to get a complete answer).  Option "device_repair"
+    // overrides.
+    const bool repair_pass = g->device_repair < 0 ? (nq > STREAM_MAX_QUERIES || !caller_checks_flags) : g->device_repair != 0;
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, repair_pass ? 0 : 2, nullptr, s, fc_rows, fc_cnt,
                            ws.rcap);
     if (repair_pass) {
@@ -604,6 +612,12 @@ static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring)
   return rc;
 }
 
+// a batch whose sticky flags were raised: a buffer overflow (or fp16 range) and a failed speculative threshold are counted apart
+static void count_flagged_batch(mi_gallery* g, uint32_t flags) {
+  if (flags & ~(uint32_t)FLAG_SPEC_FAIL) g->stats.overflow_batches += 1;
+  else g->stats.spec_retries += 1;
+}
+
 static int check_k(const mi_gallery* g, int32_t k) {
   REQUIRE(k >= 1, "k must be >= 1");
   if ((int64_t)k > g->n)
@@ -617,7 +631,7 @@ static int check_k(const mi_gallery* g, int32_t k) {
 // full search of up to any nq on device inputs (strided, any dtype), outputs on device
 static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                          int64_t nq, int32_t k, int64_t* out_idx, float* out_score, double* out_score64, bool exact,
-                         hipStream_t s, bool allow_async = false) {
+                         hipStream_t s, bool allow_async = false, bool caller_checks_flags = false) {
   int rc = check_k(g, k);
   if (rc != MI_OK) return rc;
   const bool async = g->async_tail != 0 && allow_async;
@@ -657,7 +671,8 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     ws.cand_rows = ws.cand_rows_set[set];
     ws.cand_cnt = ws.cand_cnt_set[set];
     ws.cand_score = ws.cand_score_set[set];
-    if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true)) != MI_OK) return rc;
+    if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true, caller_checks_flags)) != MI_OK)
+      return rc;
     if (async && g->async_tail == 3) {
       // deferred: a schedule without the single filtered launch (chunked, f32-scored) has not picked the previous tail up
       if (g->pending.valid && (rc = flush_pending_tail(g, s, false)) != MI_OK) return rc;
@@ -1165,13 +1180,14 @@ static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs
       }
       if ((rc = search_device(g, src, q_dtype, rs, cs, q_norm, b, k, idx_dev + q0 * k,
                               score_dev ? score_dev + q0 * k : nullptr,
-                              score64_dev ? score64_dev + q0 * k : nullptr, exact, s)) != MI_OK)
+                              score64_dev ? score64_dev + q0 * k : nullptr, exact, s, /*allow_async=*/false,
+                              /*caller_checks_flags=*/true)) != MI_OK)
         return rc;
       HIPC(hipStreamSynchronize(s));
       uint32_t flags = 0;
       if ((rc = read_and_clear_flags(g, &flags)) != MI_OK) return rc;
       if (!flags) break;
-      g->stats.overflow_batches += 1;
+      count_flagged_batch(g, flags);
       if (exact && g->exact_fallback && k <= 4096) continue;      // -> dense f64 path
       if (exact || !g->exact_fallback)
         return fail(MI_ERR_OVERFLOW,
@@ -1922,7 +1938,7 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
     if (flags) {
       // sticky device flag: a device-API batch overflowed since the last status call.  Counted once and cleared, so
       // that polling without reset does not count the same event again.
-      g->stats.overflow_batches += 1;
+      count_flagged_batch(g, flags);
       HIPC(hipMemset(sw.flags, 0, 4));
     }
     // in-kernel clock of the last tile-kernel launch: median over its waves of cycles / (10 ns ticks) x 100 MHz
@@ -1937,7 +1953,22 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
     }
   }
   if (out) *out = g->stats;
-  if (reset) g->stats = mi_search_stats{};
+  if (reset) {
+    g->stats = mi_search_stats{};
+    g->launch_ms_log.clear();
+  }
+  return MI_OK;
+}
+
+int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* out_count) {
+  REQUIRE(g && out_count, "null");
+  HIPC(hipSetDevice(g->device));
+  if (g->ev_stream) HIPC(hipStreamSynchronize(g->ev_stream));
+  prof_collect(g);
+  const int64_t n = (int64_t)g->launch_ms_log.size();
+  *out_count = n;
+  if (out_host)
+    for (int64_t i = 0; i < std::min(n, cap); ++i) out_host[i] = g->launch_ms_log[(size_t)i];
   return MI_OK;
 }
 
@@ -1994,7 +2025,7 @@ int mi_search_flags(mi_gallery* g, uint32_t* out_flags) {
     HIPC(hipMemcpy(out_flags, sw.flags, 4, hipMemcpyDeviceToHost));
     if (*out_flags) {
       HIPC(hipMemset(sw.flags, 0, 4));
-      g->stats.overflow_batches += 1;
+      count_flagged_batch(g, *out_flags);
     }
   }
   return MI_OK;

@@ -479,7 +479,11 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
 // OPT (round 3): bit 0 = the first K-slice of a tile accumulates onto the inline constant 0 (no 128-register reset after the
 // filter); bit 1 = the filter's decide step (32-value maxima per lane and query block, ballots) is computed inside the MFMA
 // segment of the tile's LAST K-slice, in the issue gaps of the matrix instructions, instead of after it.
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0>
+// POL (round 4): cache policy of the DMA pieces, gallery aux | query aux << 8 (aux of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1).
+// DBG 16384: the query fragments are read from LDS once per launch (energy model of a query operand that bypasses LDS);
+// DBG 32768: every wave also loads its 4 KiB of query fragments per slice straight into (discarded) registers -- with
+// DBG 64 | 16384 the traffic of the "global -> VGPR query operand" structure without its pipeline (scripts/kbench.hip).
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
   constexpr bool ZC = (OPT & 1) != 0;
   constexpr bool INTER = (OPT & 2) != 0 && !FIRST && !(DBG & (4 | 4096 | 8192));
@@ -493,7 +497,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
   // label's measured speed (XccBalance); rounded to whole rounds of the label's workgroups when the launch is large
   // enough for that (every workgroup of an XCD then gets the same number of tiles)
   const uint32_t ntl = (uint32_t)p.ntiles;
-  uint32_t unit = (nwg >= nqt && nwg % nqt == 0) ? nwg / nqt : 1u;    // gallery tiles per round of the label's workgroups
+  // walk 1 (A/B, ScoreArgs::walk): XCD labels 2y and 2y + 1 share the gallery range of both and take one half of the query
+  // tiles each -- half the query image per L2, every gallery tile fetched by two XCDs (the second time from the Infinity Cache)
+  const bool pairs = p.walk == 1 && nqt >= 2 && (nqt & 1u) == 0;
+  const uint32_t nqt_l = pairs ? nqt / 2u : nqt;                      // query tiles this label works on
+  const uint32_t qt0 = pairs ? (xcd & 1u) * nqt_l : 0u;
+  uint32_t unit = (nwg >= nqt_l && nwg % nqt_l == 0) ? nwg / nqt_l : 1u;   // gallery tiles per round of the label's workgroups
   if (ntl < 8u * 32u * unit) unit = 1u;                               // rounding to rounds must stay below ~1.5 % of a share
   auto cum_of = [&](uint32_t x) -> uint32_t {
     if (x == 0) return 0u;
@@ -503,9 +512,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     t = (t + unit / 2u) / unit * unit;
     return t < ntl ? t : ntl;
   };
-  const uint32_t start_x = cum_of(xcd);
-  const uint32_t cnt_x = cum_of(xcd + 1u) - start_x;
-  const uint32_t nvirt = cnt_x * nqt;
+  const uint32_t start_x = cum_of(pairs ? (xcd & ~1u) : xcd);
+  const uint32_t cnt_x = cum_of(pairs ? (xcd | 1u) + 1u : xcd + 1u) - start_x;
+  const uint32_t nvirt = cnt_x * nqt_l;
   if (j >= nvirt) {
     if (!FIRST && (threadIdx.x & 63) == 0) p.rec_cnt[b * 8 + (threadIdx.x >> 6)] = 0;
     return;
@@ -547,32 +556,47 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     };
     auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
       const uint32_t v = j + i * nwg;
-      qt = v % nqt;
-      gt = (uint32_t)p.tile0 + start_x + v / nqt;
+      qt = qt0 + v % nqt_l;
+      gt = (uint32_t)p.tile0 + start_x + v / nqt_l;
     };
     // ---- DMA stream of this group's operand: wave-uniform scalar base + one constant per-lane offset (saddr form)
     uint32_t pf_i = 0, pf_sl = 0;
     const char* pf;
+    const char* pfq = nullptr;                                // DBG 32768: this wave's query fragments (both groups)
     const uint32_t pf_lane = (uint32_t)lane * 16u;
     auto pf_set = [&](uint32_t i) {
       uint32_t gt, qt;
       tile_of(i < my_tiles ? i : my_tiles - 1, gt, qt);       // past the end: harmless re-load of the last tile
       pf = (GRP == 0 ? (const char*)p.gal_img + (int64_t)gt * KSL * SLICE_BYTES
                      : (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES) + wc * 4096;
+      if (DBG & 32768) pfq = (const char*)p.qry_img + (int64_t)qt * KSL * SLICE_BYTES + wc * 4096;
     };
     pf_set(0);
     const uint32_t ring_base = (GRP == 0 ? A_RING : B_RING) + wc * 4096;
     uint32_t wr_slot = 0;
+    constexpr int AUX = GRP == 0 ? (POL & 0xFF) : ((POL >> 8) & 0xFF);
+    constexpr int VM_PER_SLICE = ((DBG & 32768) ? 4 : 0) + (dbg_nodma ? 0 : 4);   // vector-memory operations a wave issues per slice
+    u32x4 qdummy[4] = {};
     auto issue = [&]() {
       uint32_t off = pf_lane;
       asm volatile("" : "+v"(off));
       if (!dbg_nodma) {
         const GLOBAL_AS void* src = (const GLOBAL_AS void*)(pf + off);
         LDS_AS void* dst = (LDS_AS void*)(smem + ring_base + wr_slot * SLICE_BYTES);
-        __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 0, AUX);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, AUX);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, AUX);
+        __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, AUX);
+      }
+      if (DBG & 32768) {
+        // the destinations are read-write operands of every statement, so they stay allocated for the whole loop; their
+        // contents are never used (loads may land in any order relative to the next statement's issue)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+                     : "+v"(qdummy[0]), "+v"(qdummy[1]), "+v"(qdummy[2]), "+v"(qdummy[3])
+                     : "v"(off), "s"(pfq)
+                     : "memory");
+        pfq += SLICE_BYTES;
       }
       pf += SLICE_BYTES;
       if (++pf_sl == KSL) {
@@ -859,12 +883,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     // ---- prologue: all but one slot of this group's ring in flight, slice 0 landed
 #pragma unroll
     for (int d = 0; d < MY_SLOTS - 1; ++d) issue();
-    vm_wait<(MY_SLOTS - 2) * 4>();
+    vm_wait<(MY_SLOTS - 2) * VM_PER_SLICE>();
     __builtin_amdgcn_s_barrier();
     if (GRP == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
 
     uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding the current slice
     unsigned long long clk0 = 0, rt0 = 0;
+    frag_t bkeep[4] = {};                                  // DBG 16384: the query fragments of the launch's first slice
     // in-kernel clock of every launch (s_memtime / s_memrealtime around the loop, per wave): two scalar reads, and the
     // number bench.py reports next to the roofline fraction (the chip holds 1.4-1.7 GHz of its 2.4 GHz under this load)
     if (p.dbg) { clk0 = stamp(); rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -873,10 +898,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     // MY_SLOTS - 1 ahead into the slot whose reads retired before the barrier behind us
     auto frag_reads = [&](frag_t (&af)[8], frag_t (&bfr)[4], const char* abase, const char* bbase, bool first_ever) {
       if (!(DBG & 128) || first_ever) {
+        if (!(DBG & 16384)) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
+          for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
+        }
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) af[mb] = *reinterpret_cast<const frag_t*>(abase + a_off + mb * 1024);
+      }
+      if (DBG & 16384) {
+        if (first_ever) {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) bkeep[nb] = *reinterpret_cast<const frag_t*>(bbase + b_off + nb * 1024);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          asm volatile("" : "+v"(bkeep[nb]));
+          bfr[nb] = bkeep[nb];
+        }
       }
       if (DBG & 128) {
 #pragma unroll
@@ -893,7 +931,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       frag_reads(af, bfr, abase, bbase, first_ever);
       __builtin_amdgcn_sched_barrier(0);
       issue();
-      if (GRP == 1) vm_wait<(B_SLOTS - 2) * 4>();        // B(S+1) landed before the barrier that opens group 0's LOAD(S+1)
+      if (GRP == 1) vm_wait<(B_SLOTS - 2) * VM_PER_SLICE>();   // B(S+1) landed before the barrier that opens group 0's LOAD(S+1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired BEFORE the barrier: frees the slots (WAR)
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -953,7 +991,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(bfr[nb]));
       }
-      if (GRP == 0) vm_wait<(A_SLOTS - 2) * 4>();        // A(S+1) landed, A(S+2..S+4) may be in flight
+      if (GRP == 0) vm_wait<(A_SLOTS - 2) * VM_PER_SLICE>();   // A(S+1) landed, A(S+2..S+4) may be in flight
       __builtin_amdgcn_sched_barrier(0);
     };
     using pos_mid = std::integral_constant<int, 0>;
@@ -1022,6 +1060,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     if (GRP == 0) {
       tile_epilogue(prev_gt, prev_qt);
       __builtin_amdgcn_s_barrier();                        // balance the stagger barrier
+    }
+    if (DBG & 32768) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(qdummy[0]), "+v"(qdummy[1]), "+v"(qdummy[2]), "+v"(qdummy[3])::"memory");
     }
     if (p.dbg && lane == 0) {
       unsigned long long* dbgp = p.dbg + (uint64_t)(b * 8 + w) * 8;
@@ -1194,19 +1235,22 @@ static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0>
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0>
 static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
-  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT>);
+  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>);
   hipEvent_t e0, e1;
   take_launch_events(&e0, &e1);
   if (e0 && e1)
-    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT>), dim3(persistent_grid()), dim3(512), lds, stream,
-                          e0, e1, 0, a);
+    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>), dim3(persistent_grid()), dim3(512), lds,
+                          stream, e0, e1, 0, a);
   else
-    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT>), dim3(persistent_grid()), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>), dim3(persistent_grid()), dim3(512), lds, stream,
+                       a);
 }
 
-void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
+void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
+  ScoreArgs a = a_in;
+  if (a.variant == 20 || a.variant == 21) a.walk = 1;           // paired-XCD walk (A/B), 21: with nt gallery pieces
   if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
   const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * THR_WORDS * 4;      // 162,816 B of the 163,840
   if (a.variant != 1) {                                          // structure 2 (default); variant 1 = structure 1 (A/B)
@@ -1235,7 +1279,21 @@ void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream) {
       case 4096 + 2048: return launch_tile<false, 4096 + 2048, true, false, 3>(a, lds, stream);
       case 4096 + 1024: return launch_tile<false, 4096 + 1024, true, false, 3>(a, lds, stream);
       case 5 + 128: return launch_tile<false, 5 + 128, true, false, 3>(a, lds, stream);
+      // round 4: which operand's DMA costs what (gallery pieces / query pieces skipped), and the price list of a query
+      // operand that bypasses LDS (query fragments read once; + the fragment-shaped loads into discarded registers)
+      case 4 + 32: return launch_tile<false, 4 + 32, true, false, 3>(a, lds, stream);
+      case 4 + 64: return launch_tile<false, 4 + 64, true, false, 3>(a, lds, stream);
+      case 4 + 64 + 16384: return launch_tile<false, 4 + 64 + 16384, true, false, 3>(a, lds, stream);
+      case 4 + 64 + 16384 + 32768: return launch_tile<false, 4 + 64 + 16384 + 32768, true, false, 3>(a, lds, stream);
       default:
+        // round 4: cache policy of the DMA pieces (10 .. 15; gallery aux | query aux << 8) and the paired-XCD walk (20, 21)
+        if (a.variant == 10 || a.variant == 21) return launch_tile<false, 0, true, false, 3, 0, 2>(a, lds, stream);          // gallery nt
+        if (a.variant == 11) return launch_tile<false, 0, true, false, 3, 0, 16>(a, lds, stream);         // gallery sc1
+        if (a.variant == 12) return launch_tile<false, 0, true, false, 3, 0, 17>(a, lds, stream);         // gallery sc0 sc1
+        if (a.variant == 13) return launch_tile<false, 0, true, false, 3, 0, 2 | (2 << 8)>(a, lds, stream);   // both nt
+        if (a.variant == 14) return launch_tile<false, 0, true, false, 3, 0, 2 << 8>(a, lds, stream);     // query nt (control)
+        if (a.variant == 15) return launch_tile<false, 0, true, false, 3, 0, 18>(a, lds, stream);         // gallery nt sc1
+        if (a.variant == 16) return launch_tile<false, 0, true, false, 3, 0, 1>(a, lds, stream);          // gallery sc0
         if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream);
         if (a.variant == 4) return launch_tile<false, 0, true, false, 1>(a, lds, stream);
         if (a.variant == 5) return launch_tile<false, 0, true, false, 3, 1>(a, lds, stream);   // zero-C first slice

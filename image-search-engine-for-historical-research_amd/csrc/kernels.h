@@ -34,6 +34,8 @@ struct ScoreArgs {
   int32_t debug;          // diagnostics only: bit0 skip DMA, bit1 skip MFMA, bit2 skip filter (results invalid)
   int32_t small_batch_kernel;   // 1: launches with <= STREAM_MAX_QUERIES queries go to stream_select.hip
   int32_t variant = 0;          // tile-kernel structure (option "kernel_variant"; A/B of builds inside one process)
+  int32_t walk = 0;             // tile kernel: 0 = every XCD label walks all query tiles of its gallery range; 1 = labels 2y, 2y + 1
+                                // share a range and take half of the query tiles each (A/B, gemm_select.hip)
   SurvRec* rec;           // [grid * 8 waves][rec_cap] wave-private survivor records of this launch
   uint32_t* rec_cnt;      // [grid * 8]
   uint32_t rec_cap;

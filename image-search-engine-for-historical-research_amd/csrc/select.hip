@@ -635,6 +635,9 @@ __global__ __launch_bounds__(256, 6) void rescore_resident_kernel(const float* _
                                                                const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
                                                                double* __restrict__ cand_score, uint32_t sub,
                                                                uint32_t last_row, uint32_t dbg) {
+#ifndef MI_RESIDENT_PROBE
+  dbg = 0u;                                                  // product build: the probe branches below are compiled out
+#endif
   const int lane = threadIdx.x & 63;
   const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int nvec = dp >> 2;
@@ -704,8 +707,15 @@ void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t
                              const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
                              uint32_t last_row) {
   unsigned grid = (unsigned)current_device_cus();
+  // The probes of scripts/resident_probe.sh (1 = loads without the f64 arithmetic, 2 = arithmetic without the gather, 4 = a
+  // quarter of the CUs host the tail; results wrong by construction) exist only in a library built with -DMI_RESIDENT_PROBE:
+  // the product build has no path on which an environment variable could change the exact re-score.
+#ifdef MI_RESIDENT_PROBE
   static const uint32_t dbg = [] { const char* e = getenv("MI_RESIDENT_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
-  if (dbg & 4u) grid /= 4;                                             // diagnostics: a quarter of the CUs host the tail
+#else
+  constexpr uint32_t dbg = 0u;
+#endif
+  if (dbg & 4u) grid /= 4;
   uint32_t sub = 1;
   while ((uint64_t)nq * sub * 2 <= (uint64_t)grid * 4) sub *= 2;      // every wave of the grid gets a share
   hipLaunchKernelGGL(rescore_resident_kernel, dim3(grid), dim3(256), 0, stream, gal_f32, qry_f32, dp, nq, cand_rows,

@@ -33,8 +33,13 @@ def run_dataset(dataset, vecs, qvecs, gnd, mode, device=0, devices=None):
     blocks = isinstance(vecs, ColumnBlocks)
     n = vecs.shape[0] if blocks else vecs.shape[1]
     K = n if mode == "mAP" else int(mode)                 # 'mAP' ranks the whole database (src/test_rOP1m.py:144-149)
+    use_list = bool(devices) and K <= 2048 and not blocks
+    if devices and not use_list:
+        print(">> {}: --gpu-id list ignored ({}): the rows are searched on GPU {} alone".format(
+            dataset, "K = %d > 2048 takes the full-length ranking path" % K if K > 2048 else "gallery given as column blocks",
+            device))
     match_idx, time_per_query = matching_HIP(K, vecs if blocks else vecs.T, qvecs.T, device=device,
-                                             devices=devices if (devices and K <= 2048 and not blocks) else None)
+                                             devices=devices if use_list else None)
     ranks = match_idx.T
     print(">> {}: average matching time: {}".format(dataset, time_per_query))
     res = {"map": evaluate.compute_map_and_print(dataset, ranks, gnd)}

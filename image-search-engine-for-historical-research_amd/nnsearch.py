@@ -108,7 +108,7 @@ def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=Non
         from .sharded import MultiDeviceGallery
         if int(K) > TOPK_PATH_MAX_K or isinstance(embedded_features_train, ColumnBlocks):
             raise ValueError("devices=[...]: top-K path only (K <= %d), one host array" % TOPK_PATH_MAX_K)
-        mg = MultiDeviceGallery.from_host(np.asarray(embedded_features_train), devices, NORM_L2)
+        mg = MultiDeviceGallery.from_host(np.asarray(embedded_features_train), devices, NORM_L2, k_max=int(K))
         try:
             idx, scores = mg.search(embedded_features_test, int(K))
         finally:

@@ -316,9 +316,17 @@ class MultiDeviceGallery:
             s.set_option("rescore_grid_x", max(8, min(64, round(96 / len(self.shards)))))
 
     @classmethod
-    def from_host(cls, rows, devices, norm_mode=_lib.NORM_L2):
-        """rows: [N, D] float32 / float64 host array, any strides (`vecs.T` of the reference's [D, N])."""
+    def from_host(cls, rows, devices, norm_mode=_lib.NORM_L2, k_max=1):
+        """rows: [N, D] float32 / float64 host array, any strides (`vecs.T` of the reference's [D, N]).
+        k_max: the largest K the gallery will be searched with.  The shards answer phase 1 with their own K best rows, so a
+        shard must hold at least K rows: trailing devices are left out (with a note) until every shard does."""
         n = rows.shape[0]
+        devices = list(devices)
+        fit = max(1, min(len(devices), n // max(1, int(k_max))))
+        if fit < len(devices):
+            print(">> MultiDeviceGallery: %d rows / K = %d: using %d of the %d listed devices (every shard must hold >= K rows)"
+                  % (n, k_max, fit, len(devices)))
+            devices = devices[:fit]
         shards = []
         try:
             for r, dev in enumerate(devices):
@@ -381,6 +389,9 @@ class MultiDeviceGallery:
             raise ValueError("queries must be [Q, %d]" % self.d)
         if k > self.n:
             raise RuntimeError("mi355_retrieval error 1: k > number of gallery rows")
+        if k > min(s.n for s in self.shards):
+            raise RuntimeError("multi-device search: k = %d exceeds the rows of the smallest shard (%d); create the gallery "
+                               "with from_host(..., k_max=k) so that it uses fewer devices" % (k, min(s.n for s in self.shards)))
         out_i = np.empty((q.shape[0], k), dtype=np.int64)
         out_s = np.empty((q.shape[0], k), dtype=np.float32)
         for q0 in range(0, q.shape[0], 1024):

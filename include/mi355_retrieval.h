@@ -241,7 +241,8 @@ int mi_gallery_set_image_dtype(mi_gallery* g, int f16);  /* re-images the stored
 typedef struct mi_search_stats {
   int64_t searches;           /* query batches processed */
   int64_t queries;
-  int64_t overflow_batches;   /* batches re-run through the exact fallback */
+  int64_t overflow_batches;   /* batches whose candidate / survivor / record buffers overflowed (or whose queries left fp16's range):
+                               * answered again through the f32 scorer, then the dense f64 path */
   int64_t survivors;          /* sum over queries of entries kept by the filter */
   int64_t candidates;         /* sum over queries of rows re-scored exactly */
   double gemm_ms;             /* HIP-event time of the MFMA scoring launches (profiling on) */
@@ -251,23 +252,30 @@ typedef struct mi_search_stats {
   double kernel_clock_mhz;    /* shader clock inside the most recent tile-kernel launch (s_memtime / s_memrealtime around its
                                * main loop, median over waves); 0 if that kernel has not run.  The chip lowers its clock under
                                * MFMA load, so this is what the dense peak scales with */
+  int64_t spec_retries;       /* batches whose speculative threshold failed its verification (and, where a device repair pass ran,
+                               * that too): answered again by the rigorous chunk schedule.  Not an overflow */
 } mi_search_stats;
 int mi_profile_enable(mi_gallery* g, int on);      /* times the scoring launches with HIP events (dispatch timestamps) */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
+/* The durations (ms, launch order) of the timed scoring launches since the last mi_search_status(reset = 1): what gemm_ms is
+ * the sum of.  Waits for the launches enqueued so far; writes min(count, cap) values, *out_count = launches logged. */
+int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* out_count);
 /* Tunables: "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
  * "workspace_slot" (0 | 1: which of the handle's two per-batch workspaces the phase API uses -- phase 1 of batch i + 1 may
  * be enqueued before phase 2 of batch i; sticky flags and statistics are one set for both),
  * "spec_max_ratio" (largest shard rows / sample rows for which the single-launch sample schedule is taken; default 160),
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
- * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "boot_ksplit" (batches of < 128 queries: the bootstrap launch
- * on the sample splits K over several workgroups that add their partial scores; default 1), "xcc_balance" (XCD shares by measured
+ * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "boot_ksplit" (batches of <= 512 queries: the bootstrap launch
+ * on the sample splits K over several workgroups that add their partial scores with float atomics; default 1.  The order of
+ * those adds is not fixed, so the sample scores -- and with them the survivor / candidate statistics and which queries need a
+ * repair -- may differ by an ulp from run to run; the answers do not: the threshold is speculative and verified), "xcc_balance" (XCD shares by measured
  * speed), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
- * "device_repair" (-1 = default: batches of > 128 queries follow the scoring launch with a device-conditional repair pass
- * for queries whose speculative threshold failed verification, smaller batches raise the sticky flag at once and are
- * answered again; 0 / 1 = never / always launch the repair pass), "small_tail" (1 = batches of <= 128 queries re-score and
+ * "device_repair" (-1 = default: the scoring launch is followed by a device-conditional repair pass for queries whose
+ * speculative threshold failed verification -- except for batches of <= 128 queries through the HOST entry points, which
+ * synchronise anyway, see the sticky flag and answer the batch again; 0 / 1 = never / always launch the repair pass), "small_tail" (1 = batches of <= 128 queries re-score and
  * order in one launch; measured slower, default 0),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the

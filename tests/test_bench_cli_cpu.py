@@ -42,7 +42,9 @@ def test_bare_gpus_n_starts_n_ranks_as_a_child(monkeypatch):
     assert "torch" not in (set(sys.modules) - before)            # the launcher never imports torch / touches the GPU
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
-    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
+    # no pre-picked port: the c10d store binds a free one itself
+    assert cmd[cmd.index("--rdzv-endpoint") + 1] == "127.0.0.1:0" and "--master-port" not in cmd
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 

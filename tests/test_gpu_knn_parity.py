@@ -218,7 +218,64 @@ def test_speculative_threshold_verification_and_repair(lib, ndup, device_repair,
     s = oracle.exact_scores_f64(g, q)
     assert oracle.check_topk_parity(idx, s, k, TAU) == []
     assert set(rows) <= set(idx[0])
-    assert (st["overflow_batches"] >= 1) == expect_fallback
+    assert (st["spec_retries"] >= 1) == expect_fallback and st["overflow_batches"] == 0
+
+
+@pytest.mark.parametrize("nq", [1, 70])
+def test_small_batch_spec_failure_is_repaired_on_the_asynchronous_entry_points(lib, nq):
+    """a failed speculative threshold in a batch of <= 128 queries used to leave the flagged query's
+    output row empty (-1 / -inf) on the device / phase entry points, whose callers -- ShardedGallery.search(verify=False),
+    search_stream, the alpha-QE re-search -- never read the sticky flag.  Those entry points now keep the device repair pass
+    at every batch size: the reference's own batch shapes (1 and 70 queries) with 30 near-duplicates of query 0 planted
+    inside the threshold sample come back complete and exact without any host fallback, through the one-call device search
+    and through the phase API (phase 1 -> K-th of the gathered lists -> phase 2 -> merge, as the sharded protocol runs it)."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd._lib import Gallery
+    from isehr_amd.sharded import ShardedGallery
+    n, d, k = 200000, 64, 100
+    g = synth_rows(71, 0, n, d)
+    q = synth_rows(72, 0, nq, d)
+    rng = np.random.default_rng(3)
+    rows = rng.choice(lib.sample_source_rows(n), size=30, replace=False)
+    for j, r in enumerate(rows):
+        g[r] = q[0] * (1.0 + 0.01 * j) + 0.02 * synth_rows(73, j, 1, d)[0]
+    s = oracle.exact_scores_f64(g, q)
+    G = Gallery.from_host(g)
+    try:
+        G.set_option("chunk0_tiles", 32)
+        assert G.get_option("device_repair") == -1
+        # the host entry point of the same batch does fall back (no repair launches there): the failure is real
+        idx_h, sc_h, _ = G.search(q, k)
+        assert G.status(reset=True)["spec_retries"] >= 1
+        qd = torch.from_numpy(q).cuda()
+        stream = torch.cuda.current_stream().cuda_stream
+        sg = ShardedGallery(G)
+        idx, sc = sg.search(qd, k)                              # verify=False: nobody reads the flags
+        torch.cuda.synchronize()
+        idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+        assert G.flags() == 0
+        assert oracle.check_topk_parity(idx, s, k, TAU) == [] and set(rows) <= set(idx[0])
+        assert np.array_equal(idx, idx_h) and np.array_equal(sc, sc_h)
+        # phase API, one shard
+        approx = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        L = torch.empty((nq,), dtype=torch.float32, device="cuda")
+        pack = torch.empty((2, nq, k), dtype=torch.int64, device="cuda")
+        scp = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        oidx = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        osc = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        G.phase1_device(qd.data_ptr(), nq, k, approx.data_ptr(), stream)
+        _lib.kth_of_gathered_device(approx.data_ptr(), 1, nq, k, L.data_ptr(), stream)
+        G.phase2_device(nq, k, L.data_ptr(), pack[1].data_ptr(), scp.data_ptr(), pack[0].data_ptr(), stream)
+        _lib.topk_merge_strided_device(pack[0].data_ptr(), pack[1].data_ptr(), 2 * nq * k, 1, nq, k, oidx.data_ptr(),
+                                       osc.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert G.flags() == 0
+        assert np.array_equal(oidx.cpu().numpy(), idx_h) and np.array_equal(osc.cpu().numpy(), sc_h)
+        st = G.status()
+        assert st["spec_retries"] == 0 and st["overflow_batches"] == 0
+    finally:
+        G.close()
 
 
 @pytest.mark.parametrize("nq", [1, 16, 17, 64, 65, 70, 80, 81, 96, 97, 112, 113, 128, 129])

@@ -524,3 +524,48 @@ def test_multi_device_gallery_in_one_process_equals_single_device(ndev):
             mg.search(qv[:4], n + 1)
     finally:
         mg.close()
+
+
+def test_multi_device_gallery_with_more_devices_than_k_fits(capsys):
+    """3000 rows over 8 listed devices with K = 1000 -- a shard of 375 rows cannot answer phase 1 with 1000
+    rows.  matching_HIP(devices=[...]) then uses as many of the listed devices as hold >= K rows each (and says so); a
+    gallery that was created for a smaller K refuses the larger one with a message that names the cause."""
+    from isehr_amd import _lib, nnsearch
+    from isehr_amd.sharded import MultiDeviceGallery
+    n, d, k = 3000, 96, 1000
+    g = synth_rows(311, 0, n, d)
+    qv = synth_rows(312, 0, 5, d)
+    single = _lib.Gallery.from_host(g)
+    ref_idx, ref_sc, _ = single.search(qv, k)
+    single.close()
+    idx, _, sc = nnsearch.matching_HIP(k, g, qv, devices=[0] * 8, return_scores=True)
+    assert "using 3 of the 8 listed devices" in capsys.readouterr().out
+    assert np.array_equal(idx, ref_idx) and np.array_equal(sc, ref_sc)
+    mg = MultiDeviceGallery.from_host(g, [0] * 8)                     # made for small K: 8 shards of 375 rows
+    try:
+        assert len(mg.shards) == 8
+        i2, s2 = mg.search(qv, 300)
+        assert np.array_equal(i2, ref_idx[:, :300]) and np.array_equal(s2, ref_sc[:, :300])
+        with pytest.raises(RuntimeError, match="smallest shard"):
+            mg.search(qv, k)
+    finally:
+        mg.close()
+
+
+def test_multi_device_gallery_on_two_distinct_devices():
+    """The peer copies between REAL devices, the hipSetDevice of every handle call against torch's device context and the
+    per-device current streams: only where the box has two GPUs (the one-GPU test box skips; the driver's 8-GPU node runs it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from isehr_amd import _lib, nnsearch
+    n, d, nq, k = 41003, 192, 1100, 100
+    g = synth_rows(301, 0, n, d)
+    qv = synth_rows(302, 0, nq, d)
+    single = _lib.Gallery.from_host(g, device=1)                      # and a single handle on a device that is not 0
+    ref_idx, ref_sc, _ = single.search(qv, k)
+    single.close()
+    idx, _, sc = nnsearch.matching_HIP(k, g, qv, devices=[0, 1], return_scores=True)
+    assert np.array_equal(idx, ref_idx) and np.array_equal(sc, ref_sc)
+    idx, _, sc = nnsearch.matching_HIP(k, g, qv, devices=[1, 0], return_scores=True)
+    assert np.array_equal(idx, ref_idx) and np.array_equal(sc, ref_sc)
