@@ -62,11 +62,17 @@ def parse():
                     help="element type of the streamed 16-bit operand image (MFMA input type)")
     ap.add_argument("--with-aqe", action="store_true",
                     help="BASELINE configs[4]: every step = search + alpha-QE (k=3, w=4) re-search of the expanded queries")
-    ap.add_argument("--async-tail", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3],
-                    help="single GPU: re-score + sort of batch i on the handle's second stream.  1: beside the scoring launch "
-                         "of batch i+1 (measured: no gain -- the board is at its power cap and the scoring launch slows "
-                         "down by what the overlap hides).  2: beside the query ingest + bootstrap of batch i+1 only; its "
-                         "scoring launch waits for the tail.  Results of every batch are joined inside the timed region")
+    ap.add_argument("--async-tail", type=int, nargs="?", const=1, default=None, choices=[0, 1, 2, 3],
+                    help="single GPU: where the exact re-score + final order of batch i run.  0: on the caller's stream "
+                         "(synchronous).  3: deferred -- enqueued by the call of batch i+1 right before its scoring launch, "
+                         "on the handle's own stream beside that launch (the throughput mode; +2..7 %% queries/s, the scoring "
+                         "launch slows down by ~0.1 ms).  1: from the end of phase 1 of batch i.  2: beside the query ingest + "
+                         "bootstrap of batch i+1 only.  Results of every batch are joined inside the timed region.  Default: "
+                         "3 for the headline of a one-GPU run with batches of > 128 queries (the line then also carries a "
+                         "`synchronous` block, and `roofline` is quoted on ITS undisturbed launches), else 0")
+    ap.add_argument("--calibrate", type=int, default=8,
+                    help="scoring launches of mi_gallery_calibrate after the ingest (XCD shares converge before the first "
+                         "search; 0 = off)")
     ap.add_argument("--force-protocol", action="store_true",
                     help="one GPU: run the sharded two-phase protocol with its RCCL collectives on a group of ONE rank "
                          "(what a rank of a multi-GPU run executes, collectives included); diagnostic, not the headline")
@@ -86,6 +92,9 @@ def parse():
                     help="secondary block `scale_10m` (BASELINE configs[3]: 10 M x 2048 rows, bf16 image, row-sharded 1 x N "
                          "over the job's ranks), measured after the headline.  auto: on for the default workload without "
                          "--rows / --queries / --dim overrides and without diagnostic modes")
+    ap.add_argument("--multi-gpu-blocks", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: the `row_shard_1xN` block (north_star's partition of the benchmarked gallery: row shards only, "
+                         "synchronous and with pipelined collectives, per-stage timings).  auto: on for the default workload")
     ap.add_argument("--scale-10m-steps", type=int, default=10)
     ap.add_argument("--scale-10m-rows", type=int, default=10000000)
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
@@ -165,12 +174,25 @@ def cpu_baseline(gallery, q_host, n_total, args):
         # one thread: a quarter of the rows for the 1024-query GEMM keeps the leg at a few seconds
         points += [blas_point(1024, max(4096, ns // 4), 1), blas_point(70, ns, 1), blas_point(1, ns, 1)]
     full = points[0]
+    # B4: alpha-QE on the CPU = the expansion of feature_enhancement (src/utils/Reranking.py:195-204:
+    # weighted sum of the top-3 rows, w = 4, eps-normalised; float64 like the reference's promotion) followed by B2 on the
+    # expanded queries -- what one alpha-QE step costs on top of the first search, at numpy's full BLAS width
+    _, ids1 = oracle.knn_flat_ip_blas(gn, qall, 3)
+    t0 = time.time()
+    wts = oracle.qe_weights(3, 4.0)
+    qx = (gn[ids1].astype(np.float64) * wts[None, :, None]).sum(axis=1)
+    qx /= (np.linalg.norm(qx, axis=1, keepdims=True) + 1e-6)
+    oracle.knn_flat_ip_blas(gn, qx.astype(np.float32), args.topk)
+    dt_aqe = time.time() - t0
+    aqe = {"value": qall.shape[0] / dt_aqe * ns / n_total, "unit": "queries/s", "cores": blas_threads,
+           "sample": "alpha-QE step (k=3, w=4: expansion + BLAS re-search, oracle.qe_weights / knn_flat_ip_blas) of %d queries on "
+                     "the first %d gallery rows: %.2f s; scaled by rows" % (qall.shape[0], ns, dt_aqe)}
     blas = {"value": full["value"], "unit": "queries/s", "cores": blas_threads,
             "sample": "oracle.knn_flat_ip_blas (numpy sgemm + argpartition, f32) on the first %d gallery rows x %d "
                       "queries, K=%d: %.2f s; scaled by rows" % (ns, full["queries"], args.topk, full["seconds"]),
             "points": points}
     return {
-        "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port", "blas": blas,
+        "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port", "blas": blas, "aqe": aqe,
         "sample": "oracle.matching_l2 (numpy, f32, single thread like the reference) on the first %d of %d gallery "
                   "rows x %d queries, K=%d: %.2f s; scaled by rows (cost is linear in N)" % (ns, n_total, nqs,
                                                                                             args.topk, dt),
@@ -219,9 +241,13 @@ class Job:
 
 
 def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_aqe=False, async_tail=0, pipeline=False,
-                 options=(), check=True, warm_ingest=False, keep=False, graph=False):
+                 options=(), check=True, warm_ingest=False, keep=False, graph=False, also_stream=False, phases=0):
     """Ingests this rank's shard of an n_total-row synthetic gallery and times `steps` steps of nq_job queries.
-    Returns a dict of measurements (+ the gallery and the last query batch when keep=True)."""
+    Returns a dict of measurements (+ the gallery and the last query batch when keep=True).
+    also_stream: sharded runs -- after the synchronous timed region, time the same number of steps through
+    ShardedGallery.search_stream (asynchronous all-gathers, three batches in flight) on the same gallery: res["stream"].
+    phases: sharded runs -- that many searches with an event behind every stage of the protocol (search_timed); the means,
+    maximised over the ranks, in res["phases"]."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -307,30 +333,61 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     use_stream = pipeline and sg._protocol and not with_aqe
 
-    def run_steps(count):
-        """`count` steps; returns the results of the last one"""
-        if not use_stream:
-            out_ = None
-            for i in range(count):
-                out_ = one_step(pool[i % len(pool)])
-            return out_
+    def run_eager(count):
+        out_ = None
+        for i in range(count):
+            out_ = one_step(pool[i % len(pool)])
+        return out_
+
+    def run_stream(count):
         out_ = None
         for out_ in sg.search_stream((pool[i % len(pool)] for i in range(count)), k):
             pass
         last["q"] = pool[(count - 1) % len(pool)]
         return out_
 
-    if warmup:
-        run_steps(warmup)
-    if pipelined:
-        gal.join(stream)
-    job.barrier()
+    run_steps = run_stream if use_stream else run_eager
+
+    # XCD shares of the tile kernel converged before the first search (mi_gallery_calibrate: a product call, one-off
+    # `calibrate` x one batch).  Its launches are also the first sustained load after the (light) ingest, i.e. they take the
+    # power-management transient of the chip that follows every idle gap of more than a few ms -- the first ~10 launches
+    # after one run 3..25 % slow (scripts/gap_probe.py, profiles/r04a_gap_probe.txt)
+    if args.calibrate:
+        gal.calibrate(args.calibrate, stream)
+
+    def timed_region(fn, count, warm, profile_it=True):
+        """`warm` untimed steps, then EXACTLY `count` steps between barrier + synchronize on both sides.  Nothing but the
+        barrier sits between the warm-up and the timed steps: the statistics are reset BEFORE the warm-up (they then cover
+        it too: only ratios are read from them) and the launch timing is a host-side switch."""
+        gal.status(reset=True)
+        if warm:
+            fn(warm)
+        if pipelined:
+            gal.join(stream)
+        job.barrier()
+        gal.profile(profile_it)
+        t0_ = time.perf_counter()
+        out_ = fn(count)
+        if pipelined:
+            gal.join(stream)
+        job.barrier()
+        el = time.perf_counter() - t0_
+        gal.profile(False)
+        lms = gal.launch_ms()
+        st_ = gal.status(reset=True)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return out_, el, st_, lms
+
     graphs = None
     if graph:
         # one hipGraph per pooled query batch: the whole launch sequence of a search (query ingest ... emit), captured on a
         # side stream and replayed; outputs land in the ShardedGallery's (static) result buffers like the eager calls'
         if world > 1 or with_aqe or pipelined or use_stream:
             raise SystemExit("--graph: single-GPU plain search only")
+        run_eager(2)
         graphs = []
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -350,31 +407,18 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
                 gr.replay()
                 last["q"] = qb
             return out_
-        run_steps(2)
-        torch.cuda.synchronize()
-    gal.status(reset=True)
-    gal.profile(not graph)
-    job.barrier()
-    t0 = time.perf_counter()
-    idx, sc = run_steps(steps)
-    if pipelined:
-        gal.join(stream)
-    job.barrier()
-    elapsed = time.perf_counter() - t0
-    gal.profile(False)
-    st = gal.status(reset=True)
+
+    (idx, sc), elapsed, st, launch_ms = timed_region(run_steps, steps, warmup, profile_it=not graph)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        ov = torch.tensor([st["overflow_batches"]], dtype=torch.int64, device=dev)
+        ov = torch.tensor([st["overflow_batches"] + st["spec_retries"]], dtype=torch.int64, device=dev)
         dist.all_reduce(ov, op=dist.ReduceOp.SUM)
         overflow = int(ov.item())
     else:
-        overflow = st["overflow_batches"]
+        overflow = st["overflow_batches"] + st["spec_retries"]
 
     # result sanity on the last batch (size-independent properties; the oracle cannot run at this size)
     worst = None
+    dense_check = None
     if check:
         sc_h = sc.cpu().numpy()
         idx_h = idx.cpu().numpy()
@@ -388,7 +432,8 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
             q_last = q_last / q_last.norm(dim=1, keepdim=True)
         q_last = q_last.cpu().numpy()
         worst = 0.0
-        for qi in range(0, nq, max(1, nq // 16)):
+        picks = list(range(0, nq, max(1, nq // 16)))[:16]
+        for qi in picks:
             mine = np.flatnonzero((idx_h[qi] >= lo) & (idx_h[qi] < hi))
             if len(mine):
                 rows = np.stack([gal.get_rows(int(r) - lo, 1)[0] for r in idx_h[qi, mine]]).astype(np.float64)
@@ -396,12 +441,54 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
         assert worst < 3e-7 * max(1.0, float(np.abs(sc_h).max())), \
             "returned scores differ from the float64 re-computation: %g" % worst
         if overflow:
-            raise SystemExit("bench invalid: %d batches overflowed the candidate buffers" % overflow)
+            raise SystemExit("bench invalid: %d batches raised a sticky flag (buffer overflow or failed threshold)" % overflow)
+        # COMPLETENESS by an independent path (no sample, no thresholds, no survivor / candidate buffers): every score of
+        # this rank's shard for the same 16 queries in float64 + exact top-k of the dense rows (mi_knn_dense64_search).  The
+        # job's answer restricted to my rows must be exactly the head of my dense list, and no row of my dense list that
+        # beats the job's K-th score may be missing from the answer (src/utils/nnsearch.py:701-703: full argsort = nothing
+        # is missing).  The last search ran on `last["q"]` (expanded queries under --with-aqe: used as they are).
+        if (hi - lo) >= k and k <= 4096:
+            qh = last["q"][picks].cpu().numpy()
+            didx, dsc, dsc64, _ = gal.dense64_search(qh, k)
+            # (under --with-aqe the expanded queries have norm 1 - 1e-6 / ||sum|| and the host entry point normalises them
+            # once more: the order is untouched, the scores move by ~1e-6 relative)
+            tol = 3e-6 if with_aqe else 6e-8
+            for j, qi in enumerate(picks):
+                mine = (idx_h[qi] >= lo) & (idx_h[qi] < hi)
+                m = int(mine.sum())
+                assert np.array_equal(idx_h[qi][mine], didx[j, :m]), "dense f64 search disagrees (query %d)" % qi
+                assert m == 0 or np.abs(sc_h[qi][mine] - dsc[j, :m]).max() <= tol
+                # my best row that is NOT in the answer must not beat the job's K-th score
+                assert m == k or dsc64[j, m] <= float(sc_h[qi, k - 1]) + tol, \
+                    "a row of this shard is missing from the answer (query %d)" % qi
+            dense_check = "%d queries x %d rows: dense float64 scores + exact top-%d (mi_knn_dense64_search) equal the answer" \
+                          % (len(picks), hi - lo, k)
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
                ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, worst=worst,
-               use_stream=use_stream,
+               use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check,
                protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
+
+    if also_stream and sg._protocol and not use_stream and not with_aqe:
+        ref_i, ref_s = idx.clone(), sc.clone()
+        (si, ss), el2, st2, _ = timed_region(run_stream, steps, max(3, warmup))
+        res["stream"] = {"ms_per_step": el2 / steps * 1e3, "value": nq_job * steps / el2, "unit": "queries/s", "steps": steps,
+                         "equals_synchronous_answer": bool(torch.equal(si, ref_i) and torch.equal(ss, ref_s)),
+                         "scoring_share_of_step": st2["gemm_ms"] * 1e-3 / el2}
+    if phases and sg._protocol:
+        acc = {}
+        sg.search_timed(pool[0], k)
+        for i in range(phases):
+            _, ms = sg.search_timed(pool[i % len(pool)], k)
+            for name, v in ms.items():
+                acc[name] = acc.get(name, 0.0) + v / phases
+        names = sorted(acc)
+        t = torch.tensor([acc[n_] for n_ in names], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res["phases"] = {n_: round(float(v), 4) for n_, v in zip(names, t.tolist())}
+        gal.status(reset=True)
+
     if keep:
         res["gal"], res["q_last_pool"] = gal, pool[(steps - 1) % len(pool)]
     else:
@@ -411,12 +498,11 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     return res
 
 
-def deferred_tail_block(job, gal, args, steps=100):
-    """Secondary block, one GPU, same gallery: the throughput mode `async_tail` = 3 -- the exact re-score + final order of
-    batch i run on the handle's own stream beside the scoring launch of batch i + 1 (enqueued right before it), every result
-    joined inside the timed region.  Hides ~0.2 ms of tail per batch and slows the scoring launch it shares each CU's
-    vector-memory path with (profiles/r03e_resident_probe.txt), so the headline keeps the synchronous tail and the
-    undisturbed launch its roofline is quoted on; this block records what the pipelined mode delivers on the same box."""
+def synchronous_block(job, gal, args, steps):
+    """One GPU, same gallery, behind a headline measured in the deferred-tail mode: the SAME number of steps with the tail on
+    the caller's stream.  The scoring launch then runs undisturbed, which is the launch `roofline` is quoted on, and the
+    record shows both modes of the same box.  A dozen untimed steps first: the result checks of the headline left the device
+    idle for seconds, and the first ~10 launches after an idle gap run slow (power management, scripts/gap_probe.py)."""
     import torch
     from isehr_amd import _lib
     from isehr_amd.sharded import ShardedGallery
@@ -427,35 +513,58 @@ def deferred_tail_block(job, gal, args, steps=100):
         qb = torch.empty((nq, d), dtype=torch.float32, device=dev)
         _lib.synth_fill_device(qb.data_ptr(), args.seed + 1 + i, 0, nq, d, stream)
         pool.append(qb)
-    ref = [tuple(t.clone() for t in sg.search(qb, k)) for qb in pool[:1]]
     gal.set_option("async_tail", 3)
-    try:
-        for i in range(10):
-            sg.search(pool[i % 4], k, join=False)
-        gal.join(stream)
-        torch.cuda.synchronize()
-        gal.status(reset=True)
-        gal.profile(True)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            sg.search(pool[i % 4], k, join=False)
-        gal.join(stream)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        gal.profile(False)
-        st = gal.status(reset=True)
-        idx, sc = sg.search(pool[0], k, join=False)
-        gal.join(stream)
-        torch.cuda.synchronize()
-        same = bool(torch.equal(idx, ref[0][0]) and torch.equal(sc, ref[0][1]))
-    finally:
-        gal.set_option("async_tail", 0)
-    launch_ms = st["gemm_ms"] / max(1, st["gemm_launches"])
-    return {"value": nq * steps / elapsed, "unit": "queries/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-            "avg_launch_ms": launch_ms, "kernel_share_of_step": st["gemm_ms"] * 1e-3 / elapsed,
-            "scoring_frac_of_mfma_peak": (st["gemm_flops"] / (st["gemm_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS)
-            if st["gemm_ms"] else None,
-            "equals_synchronous_answer": same, "overflow_batches": st["overflow_batches"]}
+    ref = tuple(t.clone() for t in sg.search(pool[(steps - 1) % 4], k))      # join=True: complete
+    gal.set_option("async_tail", 0)
+    gal.status(reset=True)
+    out_ = None
+    for i in range(12):
+        out_ = sg.search(pool[i % 4], k)
+    torch.cuda.synchronize()
+    gal.profile(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out_ = sg.search(pool[i % 4], k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gal.profile(False)
+    lms = [float(v) for v in gal.launch_ms()]
+    st = gal.status(reset=True)
+    same = bool(torch.equal(out_[0], ref[0]) and torch.equal(out_[1], ref[1]))
+    return dict(st=st, nq=nq, elapsed=elapsed, steps=steps, launch_ms=lms, equals_pipelined_answer=same)
+
+
+def map_block(args, device, with_oracle):
+    """BASELINE.json's metric is queries/sec AND mAP: rOxford5k / +rParis6k-sized planted datasets (70 queries,
+    clusters of positives labelled easy / hard / junk by their noise band; configs[0] and configs[1] sizes), ranked to K = 100
+    by the HIP matcher exactly as src/test_rOP1m.py:155-159 does it (`matching_L2(K, vecs.T, qvecs.T)`, `ranks = idx.T`,
+    compute_map_and_print) and, beside it, by the CPU restatement of the reference's matching_L2 (the oracle: checker only).
+    mAP (E, M, H) of the two must agree to 1e-6; the reference-style time per query of both is in the record."""
+    import numpy as np
+    from isehr_amd import evaluate
+    from isehr_amd.nnsearch import matching_HIP
+    from isehr_amd.synth import planted_dataset
+    out = []
+    for name, n in (("roxford5k-sized (configs[0])", 4993), ("roxford5k+rparis6k-sized (configs[1])", 4993 + 6322)):
+        # noise bands chosen so that the hard positives (cosine ~0.10) sit where the best distractors of a 5 k .. 11 k gallery do
+        # (~0.08) and the junk band below them: mAP is then a non-trivial number that moves when a single rank moves
+        vecs, qv, gnd = planted_dataset(args.seed, n, args.dim, 70, n_pos=(20, 60), sigmas=(2.0, 10.0, 16.0))
+        matching_HIP(args.topk, vecs.T, qv.T, device=device)                        # warm (library, allocator)
+        idx, tpq = matching_HIP(args.topk, vecs.T, qv.T, device=device)            # stateless call: ingest inside its timer
+        m = evaluate.compute_map_revisited(idx.T, gnd)
+        rec = {"dataset": name, "gallery_rows": n, "queries": 70, "topk": args.topk,
+               "map": {"E": m[0], "M": m[1], "H": m[2]}, "time_per_query_s": tpq}
+        if with_oracle:
+            import oracle
+            t0 = time.time()
+            ref = oracle.matching_l2(args.topk, vecs.T, qv.T)
+            rec["time_per_query_oracle_s"] = (time.time() - t0) / 70
+            mo = oracle.compute_map_revisited(ref.T, gnd)
+            rec["map_oracle"] = {"E": mo[0], "M": mo[1], "H": mo[2]}
+            rec["max_abs_map_difference"] = float(max(abs(a - b) for a, b in zip(m, mo)))
+            assert rec["max_abs_map_difference"] <= 1e-6, "mAP of the HIP ranks differs from the oracle's: %r" % rec
+        out.append(rec)
+    return out
 
 
 def roofline_of(res, args, world, with_traffic):
@@ -486,6 +595,11 @@ def roofline_of(res, args, world, with_traffic):
             "kernel": "stream_select_kernel" if hbm_bound else "gemm_tile_kernel", "launches": st["gemm_launches"],
             "avg_launch_ms": st["gemm_ms"] / max(1, st["gemm_launches"]),
             "kernel_share_of_step": gemm_s / elapsed}
+    lms = res.get("launch_ms") or []
+    if len(lms) >= 10:
+        # is the timed region steady state?  (after an idle gap of a few ms the first ~10 launches run slow)
+        roof["launch_ms_first5"] = sum(lms[:5]) / 5
+        roof["launch_ms_last5"] = sum(lms[-5:]) / 5
     if clock and not hbm_bound:
         # the chip lowers its shader clock under MFMA load (DVFS): the dense peak it offers at the clock measured
         # INSIDE the timed launches (s_memtime / s_memrealtime, median over waves) next to the nominal 2.4 GHz peak
@@ -522,13 +636,18 @@ def main():
     n_total = args.rows or WORKLOADS[args.workload][0]
     d, k = args.dim, args.topk
     default_shape = (args.workload == "roxford5k+1m" and not args.rows and args.queries == 1024 and d == 2048)
-    scale_10m = args.scale_10m == "on" or (
-        args.scale_10m == "auto" and default_shape and not (args.diagnostic or args.force_protocol or args.with_aqe
-                                                            or args.async_tail or args.option or args.graph))
+    plain = not (args.diagnostic or args.force_protocol or args.with_aqe or args.option or args.graph or args.pipeline)
+    scale_10m = args.scale_10m == "on" or (args.scale_10m == "auto" and default_shape and plain and not args.async_tail)
+    # the headline's tail mode: one GPU and batches for the tile kernel -> the deferred tail (the throughput mode); `roofline`
+    # then comes from a synchronous block of the same length on the same gallery (the undisturbed launch)
+    auto_tail = args.async_tail is None
+    async_tail = (3 if (world == 1 and args.queries > 128 and plain) else 0) if auto_tail else args.async_tail
+    args.async_tail = async_tail
 
     res = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, args.layout,
-                       with_aqe=args.with_aqe, async_tail=args.async_tail, pipeline=args.pipeline, options=args.option,
-                       check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True, graph=args.graph)
+                       with_aqe=args.with_aqe, async_tail=async_tail, pipeline=args.pipeline, options=args.option,
+                       check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True, graph=args.graph,
+                       also_stream=(world > 1 and plain), phases=(10 if world > 1 or args.force_protocol else 0))
     gal = res.pop("gal")
     q_last_pool = res.pop("q_last_pool")
     out = None
@@ -553,37 +672,74 @@ def main():
                        "launch": "hipGraph replay of the per-batch launch sequence" if res["graph"] else "eager",
                        "collectives": ("asynchronous, three batches in flight (search_stream)" if res["use_stream"] else
                                        "synchronous per batch") if res["protocol"] else None,
+                       "value_mode": ("pipelined: deferred tail (async_tail 3), every result joined inside the timed region; "
+                                      "`synchronous` holds the same steps with the tail on the caller's stream, and "
+                                      "`roofline` is quoted on those undisturbed launches") if res["pipelined"] and auto_tail
+                                     else ("pipelined (async_tail %d)" % async_tail if res["pipelined"] else "synchronous"),
                        "tail": ({1: "re-score + sort of batch i on the handle's own stream from the end of its phase 1: beside "
                                     "the query ingest, bootstrap AND scoring launch of batch i+1",
                                  2: "re-score + sort of batch i on the handle's own stream beside the query ingest + "
                                     "bootstrap of batch i+1 only; its scoring launch waits for the tail",
                                  3: "deferred: re-score + sort of batch i enqueued by the call of batch i+1 right before "
-                                    "its scoring launch, and runs beside that launch only"}[args.async_tail] +
+                                    "its scoring launch, and runs beside that launch only"}[async_tail] +
                                 "; every result joined inside the timed region") if res["pipelined"] else "same stream",
                        "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
+                       "calibrate_launches": args.calibrate,
                        # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
                        # ingest_s = one normalisation + layout pass over the resident raw rows in a warm process (the second
                        # ingest of this run; the first one, which also initialises the library, is ingest_first_s), and the
                        # rate of ONE call that prepares the gallery and answers one batch
                        "ingest_s": round(res["ingest_s"], 4), "ingest_first_s": round(res["ingest_first_s"], 3),
                        "ingest_kernel_s": round(res["ingest_kernel_s"], 5) if res["ingest_kernel_s"] else None,
-                       "queries_per_s_incl_gallery_ingest": nq / (ms_step * 1e-3 + res["ingest_s"]),
+                       "queries_per_s_incl_gallery_ingest_per_call_of_one_batch": nq / (ms_step * 1e-3 + res["ingest_s"]),
                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                        "survivors_per_query": st["survivors"] / max(1, st["queries"]),
-                       "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e" % (k, res["worst"])
-                                      if not args.diagnostic else None},
+                       "score_check": ("16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"
+                                       % (k, res["worst"], res["dense_check"])) if not args.diagnostic else None},
             "roofline": roof,
         }
-        if world == 1 and scale_10m:
-            try:
-                out["deferred_tail"] = deferred_tail_block(job, gal, args)
-            except (RuntimeError, AssertionError, MemoryError) as e:       # a secondary block never costs the headline
-                out["deferred_tail"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if res.get("stream"):
+            out["pipelined_collectives"] = res["stream"]
+        if res.get("phases"):
+            out["protocol_phases_ms_max_over_ranks"] = res["phases"]
+        if world == 1 and res["pipelined"] and auto_tail:
+            # the same steps with the tail on the caller's stream: the undisturbed scoring launch (roofline) and what the
+            # synchronous mode delivers on this box
+            sb = synchronous_block(job, gal, args, args.steps)
+            roof_sync = roofline_of(sb, args, world, with_traffic=default_shape)
+            roof_sync["measured_on"] = ("`synchronous` block: %d steps on the same gallery with the tail on the caller's "
+                                        "stream (the launch runs undisturbed); the headline's launches, which share the "
+                                        "device with the deferred tail, are under `pipelined`" % sb["steps"])
+            roof_sync["pipelined"] = {kk: roof[kk] for kk in ("achieved", "frac", "avg_launch_ms", "kernel_share_of_step",
+                                                             "launches", "launch_ms_first5", "launch_ms_last5",
+                                                             "in_kernel_clock_mhz", "frac_at_clock") if kk in roof}
+            out["roofline"] = roof_sync
+            out["synchronous"] = {"value": args.queries * sb["steps"] / sb["elapsed"], "unit": "queries/s",
+                                  "steps": sb["steps"], "ms_per_step": sb["elapsed"] / sb["steps"] * 1e3,
+                                  "avg_launch_ms": roof_sync["avg_launch_ms"],
+                                  "kernel_share_of_step": roof_sync["kernel_share_of_step"],
+                                  "equals_pipelined_answer": sb["equals_pipelined_answer"],
+                                  "flagged_batches": sb["st"]["overflow_batches"] + sb["st"]["spec_retries"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gal, q_last_pool.cpu().numpy(), n_total, args)
     gal.close()
     del gal, q_last_pool
     torch.cuda.empty_cache()
+
+    if world > 1 and plain and (args.multi_gpu_blocks == "on" or (args.multi_gpu_blocks == "auto" and default_shape)):
+        # north_star's literal partition on the benchmarked gallery: row shards only (1 x N), every rank scores all queries
+        # against its rows, two all-gathers per batch -- synchronous and with the pipelined collectives, plus what every
+        # stage of the protocol costs (events behind every stage, maxima over the ranks)
+        r1 = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, "1x%d" % world, check=True,
+                          keep=False, also_stream=True, phases=10)
+        if rank == 0:
+            rf = roofline_of(r1, args, world, with_traffic=False)
+            out["row_shard_1xN"] = {
+                "parallelism": "row-shard x%d (two-phase protocol, RCCL all-gathers of the per-shard top-K)" % world,
+                "value": args.queries * r1["steps"] / r1["elapsed"], "unit": "queries/s", "steps": r1["steps"],
+                "ms_per_step": r1["elapsed"] / r1["steps"] * 1e3, "scoring_frac_of_mfma_peak": rf["frac"],
+                "scoring_share_of_step": rf["kernel_share_of_step"], "pipelined_collectives": r1.get("stream"),
+                "protocol_phases_ms_max_over_ranks": r1.get("phases"), "score_check": r1["dense_check"]}
 
     if scale_10m:
         # BASELINE configs[3]: 10 M x 2048 rows, bf16 image, 1024-query batches, row-sharded over the job's ranks
@@ -591,7 +747,7 @@ def main():
         r10 = None
         try:
             r10 = run_workload(job, args.scale_10m_rows, 1024, "bf16", args.scale_10m_steps, 2, "1x%d" % world,
-                               check=True, keep=False)
+                               check=True, keep=False, also_stream=world > 1, phases=(5 if world > 1 else 0))
         except (RuntimeError, AssertionError, MemoryError, SystemExit) as e:
             # the secondary block must never cost the headline line (one rank: report and go on; several ranks: a rank that
             # fails alone would leave the others in a collective, so there the error ends the job)
@@ -608,7 +764,16 @@ def main():
                 "ingest_s": round(r10["ingest_first_s"], 3),
                 "scoring_frac_of_mfma_peak": roof10["frac"], "scoring_share_of_step": roof10["kernel_share_of_step"],
                 "scoring_launches_per_step": r10["st"]["gemm_launches"] / max(1, r10["steps"]),
-                "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e" % (k, r10["worst"])}
+                "pipelined_collectives": r10.get("stream"), "protocol_phases_ms_max_over_ranks": r10.get("phases"),
+                "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"
+                               % (k, r10["worst"], r10["dense_check"])}
+
+    if rank == 0 and default_shape and plain and not args.diagnostic:
+        # the metric's other half: mAP (E / M / H) on planted rOxford5k- / +rParis6k-sized datasets, HIP ranks vs the oracle's
+        try:
+            out["map"] = map_block(args, job.dev_index, with_oracle=not args.no_cpu_baseline)
+        except (RuntimeError, MemoryError) as e:
+            out["map"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         sys.stdout.flush()

@@ -65,12 +65,17 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_aqe_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                         C.c_double, C.c_void_p, C.c_void_p]),
+    "mi_aqe_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+    "mi_aqe_combine_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "mi_aqe_finish_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "mi_aqe_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
                                 C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_f64p]),
     "mi_knn_dense_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_void_p, C.c_void_p, c_f64p]),
+    "mi_knn_dense64_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, c_f64p]),
     "mi_rank_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                               C.c_void_p, c_f64p]),
     "mi_rank_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64,
@@ -91,6 +96,7 @@ SIGNATURES = {
     "mi_column_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "mi_whiten_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_double, C.c_int, C.c_void_p]),
+    "mi_gallery_calibrate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_profile_launch_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -289,6 +295,23 @@ class Gallery:
                                        qx.ctypes.data_as(C.c_void_p) if return_qexp else None, C.byref(secs)))
         return idx, sc, qx, secs.value
 
+    def dense64_search(self, queries, k):
+        """Every score of the gallery in float64 + exact top-k (no threshold logic): the independent checker of the filtered
+        search.  -> (idx int64 [Q,k], scores float32 [Q,k], scores float64 [Q,k], seconds)."""
+        a, code, rs, cs = _strided(queries)
+        if a.shape[1] != self.d:
+            raise ValueError("query dimension %d != gallery dimension %d" % (a.shape[1], self.d))
+        nq = a.shape[0]
+        idx = np.empty((nq, k), dtype=np.int64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        sc64 = np.empty((nq, k), dtype=np.float64)
+        secs = C.c_double()
+        with self._lock:
+            check(load().mi_knn_dense64_search(self._h, C.c_void_p(_base_pointer(a)), nq, code, rs, cs, k,
+                                               idx.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                               sc64.ctypes.data_as(C.c_void_p), C.byref(secs)))
+        return idx, sc, sc64, secs.value
+
     def dense_search(self, queries, k):
         """Exact f32 inner-product top-k for large k (k <= 4096): -> (idx [Q,k], scores [Q,k], seconds)."""
         a, code, rs, cs = _strided(queries)
@@ -417,6 +440,10 @@ class Gallery:
         check(load().mi_knn_phase2_device(self._h, nq, k, C.c_void_p(L_ptr), C.c_void_p(idx_ptr),
                                           C.c_void_p(score_ptr), C.c_void_p(score64_ptr), C.c_void_p(stream)))
 
+    def aqe_rows_device(self, ranks_ptr, stride_j, stride_q, nq, k_qe, rows_ptr, stream=None):
+        check(load().mi_aqe_rows_device(self._h, C.c_void_p(ranks_ptr), stride_j, stride_q, nq, k_qe, C.c_void_p(rows_ptr),
+                                        C.c_void_p(stream)))
+
     def aqe_partial_device(self, ranks_ptr, stride_j, stride_q, nq, k_qe, w, sum_ptr, stream=None):
         check(load().mi_aqe_partial_device(self._h, C.c_void_p(ranks_ptr), stride_j, stride_q, nq, k_qe, float(w),
                                            C.c_void_p(sum_ptr), C.c_void_p(stream)))
@@ -449,6 +476,10 @@ class Gallery:
         f = C.c_uint32(0)
         check(load().mi_search_flags(self._h, C.byref(f)))
         return f.value
+
+    def calibrate(self, launches=8, stream=None):
+        """Converges the tile kernel's per-XCD shares of the gallery before the first real search (mi_gallery_calibrate)."""
+        check(load().mi_gallery_calibrate(self._h, launches, C.c_void_p(stream)))
 
     def profile(self, on=True):
         check(load().mi_profile_enable(self._h, 1 if on else 0))
@@ -484,6 +515,10 @@ def topk_merge_strided_device(score64_ptr, idx_ptr, shard_stride, nshards, nq, k
 def topk_merge_device(score64_ptr, idx_ptr, nshards, nq, k, out_idx_ptr, out_score_ptr, stream=None):
     check(load().mi_topk_merge_device(C.c_void_p(score64_ptr), C.c_void_p(idx_ptr), nshards, nq, k,
                                       C.c_void_p(out_idx_ptr), C.c_void_p(out_score_ptr), C.c_void_p(stream)))
+
+
+def aqe_combine_device(rows_ptr, nq, d, k_qe, w, sum_ptr, stream=None):
+    check(load().mi_aqe_combine_device(C.c_void_p(rows_ptr), nq, d, k_qe, float(w), C.c_void_p(sum_ptr), C.c_void_p(stream)))
 
 
 def aqe_finish_device(sum_ptr, nq, d, eps, out_q_ptr, out_q64_ptr=None, stream=None):

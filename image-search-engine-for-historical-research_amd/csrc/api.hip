@@ -112,6 +112,7 @@ struct mi_gallery {
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
   int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
   int boot_ksplit = 1;          // small batches: K-split bootstrap launch (kernels.h ScoreArgs::ksplit); 0 = one workgroup per tile
+  int stream_tail = 1;          // host entry points with more than one batch of queries: deferred tail between their batches
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
   // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 80
   // VGPRs per SIMD lane and no LDS: exactly one 70-register re-score wave per SIMD fits next to its two); results are
@@ -1166,6 +1167,26 @@ static int search_sync(mi_gallery* g, const void* q_dev, int q_dtype, int64_t rs
   if (rc != MI_OK) return rc;
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
   const size_t esz = q_dtype == MI_F32 ? 4 : 8;
+  if (nq > QB && g->stream_tail && g->async_tail == 0 && !g->force_exact) {
+    // More than one batch: the N x N callers of the path (AQE / DBA / k-reciprocal re-ranking, src/utils/Reranking.py:314-432,
+    // the diffusion re-search) and query sets beyond 1024.  Their batches run as a stream with the DEFERRED tail (async_tail 3):
+    // the exact re-score + final order of batch i is enqueued right before the scoring launch of batch i + 1 and runs beside
+    // it on the handle's own stream (+2 ... 7 % queries/s); a failed threshold is repaired on the device (no host
+    // round trip between the batches) and the sticky flags are read ONCE, after the last batch.  A raised flag -- an
+    // overflow somewhere in the stream -- sends the whole call through the verified per-batch loop below.
+    g->async_tail = 3;
+    rc = search_device(g, q_dev, q_dtype, rs, cs, q_norm, nq, k, idx_dev, score_dev, score64_dev, false, s,
+                       /*allow_async=*/true, /*caller_checks_flags=*/false);
+    const int rc2 = join_tails(g, s);
+    g->async_tail = 0;
+    if (rc != MI_OK) return rc;
+    if (rc2 != MI_OK) return rc2;
+    HIPC(hipStreamSynchronize(s));
+    uint32_t flags = 0;
+    if ((rc = read_and_clear_flags(g, &flags)) != MI_OK) return rc;
+    if (!flags) return MI_OK;
+    count_flagged_batch(g, flags);
+  }
   for (int64_t q0 = 0; q0 < nq; q0 += QB) {
     const int64_t b = std::min<int64_t>(QB, nq - q0);
     const char* src = (const char*)q_dev + (size_t)q0 * rs * esz;
@@ -1250,6 +1271,28 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
                        /*allow_async=*/true);
 }
 
+int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream) {
+  REQUIRE(g, "null handle");
+  REQUIRE(launches >= 0 && launches <= 64, "launches must be in [0, 64]");
+  HIPC(hipSetDevice(g->device));
+  // only the tile kernel's weighted split has something to measure: a launch over >= 512 gallery tiles (launch_scatter_records)
+  if (launches == 0 || !g->xcc_balance || g->npad / TILE < 8 * 64 || g->force_exact) return MI_OK;
+  const int32_t nq = (int32_t)std::min<int64_t>(QB, g->n);
+  const int32_t k = (int32_t)std::min<int64_t>(100, g->n);
+  int rc = check_k(g, k);
+  if (rc != MI_OK) return rc;
+  if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
+  if (g->pending.valid && (rc = flush_pending_tail(g, (hipStream_t)stream, false)) != MI_OK) return rc;
+  // queries = the first stored rows of the gallery itself (resident, already in the gallery's own normalisation): what the
+  // launches score is irrelevant, every workgroup's loop time is what block 0 of the scatter kernel turns into shares
+  for (int32_t i = 0; i < launches; ++i)
+    if ((rc = phase1_batch(g, g->gal_f32, MI_F32, g->dp, 1, MI_NORM_NONE, nq, k, false, (hipStream_t)stream)) != MI_OK) return rc;
+  // the answers are discarded, and so is whatever these launches flagged (a gallery that starts with duplicate rows can
+  // overflow their candidate lists): sticky flags raised from here on belong to real searches again
+  HIPC(hipMemsetAsync(g->ws.flags, 0, 8, (hipStream_t)stream));
+  return MI_OK;
+}
+
 int mi_search_join(mi_gallery* g, void* stream) {
   REQUIRE(g, "null handle");
   HIPC(hipSetDevice(g->device));
@@ -1330,6 +1373,26 @@ int mi_aqe_partial_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_
   HIPC(hipSetDevice(g->device));
   launch_aqe_partial(g->gal_f32, g->dp, g->d, g->n, g->row_offset, ranks_dev, rank_stride_j, rank_stride_q, nq, k_qe,
                      w, nullptr, out_sum_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_aqe_rows_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_stride_j, int64_t rank_stride_q, int64_t nq,
+                       int32_t k_qe, float* out_rows_dev, void* stream) {
+  REQUIRE(g && ranks_dev && out_rows_dev, "null pointer");
+  REQUIRE(nq >= 1 && k_qe >= 1 && k_qe <= 65535, "bad sizes");
+  HIPC(hipSetDevice(g->device));
+  launch_aqe_rows(g->gal_f32, g->dp, g->d, g->n, g->row_offset, ranks_dev, rank_stride_j, rank_stride_q, nq, k_qe,
+                  out_rows_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_aqe_combine_device(const float* rows_dev, int64_t nq, int32_t d, int32_t k_qe, double w, double* out_sum_dev,
+                          void* stream) {
+  REQUIRE(rows_dev && out_sum_dev, "null pointer");
+  REQUIRE(nq >= 1 && k_qe >= 1 && d >= 1, "bad sizes");
+  launch_aqe_combine(rows_dev, nq, d, k_qe, w, nullptr, out_sum_dev, (hipStream_t)stream);
   HIPC(hipGetLastError());
   return MI_OK;
 }
@@ -1493,6 +1556,35 @@ int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int
     return rc;
   HIPC(hipMemcpy(out_idx, idx_d, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
   if (out_score) HIPC(hipMemcpy(out_score, sc_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return MI_OK;
+}
+
+extern "C" int mi_knn_dense64_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride, int64_t col_stride,
+                                     int32_t k, int64_t* out_idx, float* out_score, double* out_score64, double* out_seconds) {
+  REQUIRE(g && q && out_idx, "null pointer");
+  REQUIRE(nq >= 1, "no queries");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int64_t elems;
+  int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
+  if (rc != MI_OK) return rc;
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  char* qd = tmp.get<char>((size_t)elems * esz);
+  int64_t* idx_d = tmp.get<int64_t>((size_t)nq * k);
+  float* sc_d = tmp.get<float>((size_t)nq * k);
+  double* sc64_d = tmp.get<double>((size_t)nq * k);
+  if (!qd || !idx_d || !sc_d || !sc64_d) return fail(MI_ERR_NOMEM, "dense search buffers");
+  HIPC(hipMemcpy(qd, q, (size_t)elems * esz, hipMemcpyHostToDevice));
+  if ((rc = dense64_search_device(g, qd, dtype, row_stride, col_stride, g->norm_mode, nq, k, idx_d, sc_d, sc64_d, g->stream)) !=
+      MI_OK)
+    return rc;
+  HIPC(hipMemcpy(out_idx, idx_d, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+  if (out_score) HIPC(hipMemcpy(out_score, sc_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+  if (out_score64) HIPC(hipMemcpy(out_score64, sc64_d, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
   if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return MI_OK;
 }
@@ -2053,6 +2145,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "xcc_balance") *out_value = g->xcc_balance;
   else if (n == "ladder") *out_value = g->ladder;
   else if (n == "boot_ksplit") *out_value = g->boot_ksplit;
+  else if (n == "stream_tail") *out_value = g->stream_tail;
   else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
@@ -2100,6 +2193,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
   else if (n == "ladder") g->ladder = value != 0;
   else if (n == "boot_ksplit") g->boot_ksplit = value != 0;
+  else if (n == "stream_tail") g->stream_tail = value != 0;
   else if (n == "async_tail") {
     REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
     g->async_tail = (int)value;

@@ -10,6 +10,13 @@
 
 namespace mi {
 
+// One weight and one accumulation step for every form of the sum (one shard, partial sums, gathered rows): the expanded
+// query of a sharded gallery must be the single-GPU one bit for bit, so all kernels share the operation, not just the formula.
+__device__ __forceinline__ double aqe_weight(int j, int32_t k_qe, double w, const double* __restrict__ weights) {
+  return weights ? weights[j] : pow((double)(k_qe - j) / (double)k_qe, w);
+}
+__device__ __forceinline__ double aqe_step(double acc, float x, double wt) { return fma((double)x, wt, acc); }
+
 __global__ __launch_bounds__(256) void aqe_partial_kernel(const float* __restrict__ gal, int32_t dp, int32_t d,
                                                           int64_t n, int64_t row_offset,
                                                           const int64_t* __restrict__ ranks, int64_t sj, int64_t sq,
@@ -21,9 +28,32 @@ __global__ __launch_bounds__(256) void aqe_partial_kernel(const float* __restric
     for (int j = 0; j < k_qe; ++j) {
       const int64_t gid = ranks[j * sj + q * sq] - row_offset;
       if (gid < 0 || gid >= n) continue;
-      const double wt = weights ? weights[j] : pow((double)(k_qe - j) / (double)k_qe, w);
-      acc += (double)gal[gid * dp + c] * wt;
+      acc = aqe_step(acc, gal[gid * dp + c], aqe_weight(j, k_qe, w, weights));
     }
+    out_sum[q * d + c] = acc;
+  }
+}
+
+// Sharded alpha-QE, round 4: every shard contributes the ROWS it owns of the k_qe x Q requested ones (zeros elsewhere),
+// the [k_qe][Q][d] f32 blocks are summed across the shards -- every element has exactly one non-zero contributor, so that sum
+// is exact in any order -- and every rank then adds the rows in j order with the single-GPU kernel's own step.
+__global__ __launch_bounds__(256) void aqe_rows_kernel(const float* __restrict__ gal, int32_t dp, int32_t d, int64_t n,
+                                                       int64_t row_offset, const int64_t* __restrict__ ranks, int64_t sj,
+                                                       int64_t sq, int64_t nq, float* __restrict__ out_rows) {
+  const int64_t q = blockIdx.x, j = blockIdx.y;
+  const int64_t gid = ranks[j * sj + q * sq] - row_offset;
+  const bool mine = gid >= 0 && gid < n;
+  float* dst = out_rows + (j * nq + q) * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = mine ? gal[gid * dp + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void aqe_combine_kernel(const float* __restrict__ rows, int64_t nq, int32_t d, int32_t k_qe,
+                                                          double w, const double* __restrict__ weights,
+                                                          double* __restrict__ out_sum) {
+  const int64_t q = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < k_qe; ++j) acc = aqe_step(acc, rows[((int64_t)j * nq + q) * d + c], aqe_weight(j, k_qe, w, weights));
     out_sum[q * d + c] = acc;
   }
 }
@@ -54,6 +84,17 @@ void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, 
                         const double* weights, double* out_sum, hipStream_t stream) {
   hipLaunchKernelGGL(aqe_partial_kernel, dim3((unsigned)nq), dim3(256), 0, stream, gal_f32, dp, d, n, row_offset,
                      ranks, sj, sq, k_qe, w, weights, out_sum);
+}
+
+void launch_aqe_rows(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset, const int64_t* ranks,
+                     int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, float* out_rows, hipStream_t stream) {
+  hipLaunchKernelGGL(aqe_rows_kernel, dim3((unsigned)nq, (unsigned)k_qe), dim3(256), 0, stream, gal_f32, dp, d, n, row_offset,
+                     ranks, sj, sq, nq, out_rows);
+}
+
+void launch_aqe_combine(const float* rows, int64_t nq, int32_t d, int32_t k_qe, double w, const double* weights,
+                        double* out_sum, hipStream_t stream) {
+  hipLaunchKernelGGL(aqe_combine_kernel, dim3((unsigned)nq), dim3(256), 0, stream, rows, nq, d, k_qe, w, weights, out_sum);
 }
 
 void launch_aqe_finish(const double* sum, int64_t nq, int32_t d, double eps, float* out_q, double* out_q64,

@@ -176,6 +176,10 @@ void launch_ms_finish(float* acc, int32_t b, int32_t d, int32_t nscales, float m
 void launch_aqe_partial(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset,
                         const int64_t* ranks, int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, double w,
                         const double* weights, double* out_sum, hipStream_t stream);
+void launch_aqe_rows(const float* gal_f32, int32_t dp, int32_t d, int64_t n, int64_t row_offset, const int64_t* ranks,
+                     int64_t sj, int64_t sq, int64_t nq, int32_t k_qe, float* out_rows, hipStream_t stream);
+void launch_aqe_combine(const float* rows, int64_t nq, int32_t d, int32_t k_qe, double w, const double* weights,
+                        double* out_sum, hipStream_t stream);
 void launch_column_sum(const void* X, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, double* out,
                        hipStream_t stream);
 void launch_aqe_finish(const double* sum, int64_t nq, int32_t d, double eps, float* out_q, double* out_q64,

@@ -257,36 +257,74 @@ class ShardedGallery:
                                        nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), stream)
         return b["oidx"], b["osc"]
 
-    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6, join=True):
-        """alpha-QE across shards (src/utils/Reranking.py:195-208): every rank adds the rows it owns into a
-        float64 partial sum [Q, D] (`mi_aqe_partial_device`), the partials are all-gathered and added in rank order
-        on every rank (a fixed summation order, unlike an all-reduce; the rows of one query may live on any shard), every rank normalises redundantly
-        (`mi_aqe_finish_device`) and the expanded queries go through the sharded search as they are (no second
-        normalisation).  ranks: int64 cuda tensor [K_in, Q] of GLOBAL row ids (any strides).
-        Returns (idx [Q,k], score [Q,k], q_exp float32 [Q,D])."""
+    def search_timed(self, q, k):
+        """One synchronous search of the two-phase protocol with an event behind every stage on the caller's stream:
+        returns ((idx, score), {"phase1", "allgather1", "kth", "phase2", "allgather2", "merge", "total"} in ms).  A collective
+        of torch.distributed runs on the communicator's own stream and the caller's stream waits for it, so the interval up
+        to the next event is what the collective costs THIS rank, waiting for its slowest peer included.  Synchronises.
+        Diagnostic (bench.py reports the maxima over the ranks): what the RCCL all-gathers cost beside the kernels."""
+        import torch
+        if not self._protocol:
+            raise RuntimeError("search_timed: the two-phase protocol is not active (one rank, no force_protocol)")
+        nq = q.shape[0]
+        b = self._buffers(nq, k, q.device)
+        st = torch.cuda.current_stream()
+        stream = st.cuda_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        ev[0].record(st)
+        self.g.phase1_device(q.data_ptr(), nq, k, b["approx"].data_ptr(), stream)
+        ev[1].record(st)
+        gathered = all_gather_stacked(b["approx"], self.group)
+        ev[2].record(st)
+        _lib.kth_of_gathered_device(gathered.data_ptr(), self.world, nq, k, b["L"].data_ptr(), stream)
+        ev[3].record(st)
+        pack = b["pack"]
+        self.g.phase2_device(nq, k, b["L"].data_ptr(), pack[1].data_ptr(), b["sc"].data_ptr(), pack[0].data_ptr(), stream)
+        ev[4].record(st)
+        gathered2 = all_gather_stacked(pack, self.group)
+        ev[5].record(st)
+        _lib.topk_merge_strided_device(gathered2[0, 0].data_ptr(), gathered2[0, 1].data_ptr(), 2 * nq * k, self.world,
+                                       nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), stream)
+        ev[6].record(st)
+        ev[6].synchronize()
+        names = ("phase1", "allgather1", "kth", "phase2", "allgather2", "merge")
+        ms = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
+        ms["total"] = ev[0].elapsed_time(ev[6])
+        return (b["oidx"], b["osc"]), ms
+
+    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6, join=True, verify=False):
+        """alpha-QE across shards (src/utils/Reranking.py:195-208).  The k_qe rows of a query may live on any shard, and the
+        expanded query must not depend on where: every rank writes the f32 rows IT owns of the k_qe x Q requested ones into a
+        [k_qe, Q, D] block (zeros elsewhere, `mi_aqe_rows_device`), the blocks are summed over the group -- each element has
+        exactly one non-zero contributor, so the all-reduce is exact in whatever order the collective adds; 24 MiB at
+        k_qe = 3, Q = 1024, D = 2048 -- and every rank adds the rows in j = 0 .. k_qe-1 order in float64 with the single-shard
+        kernel's own step (`mi_aqe_combine_device`): the sum, and with it q', is the single-GPU one bit for bit.  (Round 3
+        all-gathered world x Q x D float64 partial sums, 128 MiB at 8 ranks, and was only equal up to the order of the
+        additions across shard boundaries.)  Every rank normalises redundantly (`mi_aqe_finish_device`) and the expanded
+        queries go through the sharded search as they are (no second normalisation).
+        ranks: int64 cuda tensor [K_in, Q] of GLOBAL row ids (any strides).  Returns (idx [Q,k], score [Q,k], q_exp f32 [Q,D])."""
         import torch
         import torch.distributed as dist
         nq = ranks.shape[1]
         d = self.g.d
         stream = torch.cuda.current_stream().cuda_stream
         part = torch.empty((nq, d), dtype=torch.float64, device=ranks.device)
-        self.g.aqe_partial_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, w, part.data_ptr(),
-                                  stream)
         if self._protocol:
-            # The partial sums are float64 and their total must not depend on the collective's algorithm: an all-reduce adds
-            # in ring / tree order, which differs between world sizes and libraries, so two runs of one job could disagree in
-            # the last bit of an expanded query (and with it in near-ties of the re-search).  The partials are therefore
-            # all-gathered (world x Q x D x 8 bytes: 128 MiB at 8 ranks, Q = 1024, D = 2048) and every rank adds them in rank
-            # order: one fixed order, bit-identical on every rank.  Against the single-shard sum (rows added in the order
-            # j = 0 .. k_qe-1) the order of the f64 additions can still differ when a query's rows sit on several shards:
-            # |difference| <= a few ulp of f64 (1e-16 relative), nine orders below the f32 rounding of the expanded query.
-            parts = all_gather_stacked(part, self.group)                  # [world, Q, D]
-            part = parts[0].clone()
-            for r in range(1, parts.shape[0]):
-                part += parts[r]
+            rows = torch.empty((k_qe, nq, d), dtype=torch.float32, device=ranks.device)
+            self.g.aqe_rows_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, rows.data_ptr(), stream)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+            else:                                   # gloo (CPU rehearsals and tests): reduce on the host
+                h = rows.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                rows.copy_(h)
+            _lib.aqe_combine_device(rows.data_ptr(), nq, d, k_qe, w, part.data_ptr(), stream)
+        else:
+            self.g.aqe_partial_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, w, part.data_ptr(),
+                                      stream)
         qx = torch.empty((nq, d), dtype=torch.float32, device=ranks.device)
         _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)
-        idx, sc = self.search(qx, k, query_norm_none=True, join=join)
+        idx, sc = self.search(qx, k, query_norm_none=True, join=join, verify=verify)
         return idx, sc, qx
 
 
@@ -379,6 +417,50 @@ class MultiDeviceGallery:
                                            oidx.data_ptr(), osc.data_ptr(), torch.cuda.current_stream(dev0).cuda_stream)
             torch.cuda.synchronize(dev0)
         return oidx.cpu().numpy(), osc.cpu().numpy()
+
+    def aqe_search(self, ranks, k_qe, w, k, eps=1e-6):
+        """alpha-QE + re-search on the shards of one process (src/utils/Reranking.py:195-208): ranks int64 host array
+        [K_in, Q] of global row ids (any strides).  Every device writes the rows it owns (zeros elsewhere), device 0 adds the
+        blocks -- one non-zero contributor per element: exact -- and sums them in j order with the single-shard kernel's step,
+        so q' and the re-search are those of one handle, bit for bit.  Returns (idx [Q, k], score [Q, k], q_exp f32 [Q, D])."""
+        import torch
+        ranks = np.ascontiguousarray(np.asarray(ranks)[:k_qe], dtype=np.int64)
+        nq = ranks.shape[1]
+        out_i = np.empty((nq, k), dtype=np.int64)
+        out_s = np.empty((nq, k), dtype=np.float32)
+        out_q = np.empty((nq, self.d), dtype=np.float32)
+        dev0 = torch.device("cuda", self.devices[0])
+        for q0 in range(0, nq, 1024):
+            rb = np.ascontiguousarray(ranks[:, q0:q0 + 1024])
+            b = rb.shape[1]
+            total = None
+            for s, dv in zip(self.shards, self.devices):
+                dev = torch.device("cuda", dv)
+                with torch.cuda.device(dev):
+                    r = torch.from_numpy(rb).to(dev)
+                    rows = torch.empty((k_qe, b, self.d), dtype=torch.float32, device=dev)
+                    s.aqe_rows_device(r.data_ptr(), r.stride(0), r.stride(1), b, k_qe, rows.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+                    torch.cuda.synchronize(dev)
+                with torch.cuda.device(dev0):
+                    rows0 = rows.to(dev0)
+                    total = rows0 if total is None else total.add_(rows0)
+            with torch.cuda.device(dev0):
+                st0 = torch.cuda.current_stream(dev0).cuda_stream
+                part = torch.empty((b, self.d), dtype=torch.float64, device=dev0)
+                qx = torch.empty((b, self.d), dtype=torch.float32, device=dev0)
+                _lib.aqe_combine_device(total.data_ptr(), b, self.d, k_qe, w, part.data_ptr(), st0)
+                _lib.aqe_finish_device(part.data_ptr(), b, self.d, eps, qx.data_ptr(), None, st0)
+                torch.cuda.synchronize(dev0)
+                out_q[q0:q0 + b] = qx.cpu().numpy()
+        for s in self.shards:
+            s.set_option("query_norm_override", _lib.NORM_NONE)
+        try:
+            out_i, out_s = self.search(out_q, k)
+        finally:
+            for s in self.shards:
+                s.set_option("query_norm_override", -1)
+        return out_i, out_s, out_q
 
     def search(self, queries, k):
         """queries: [Q, D] host array -> (idx int64 [Q, k] of GLOBAL row ids, score float32 [Q, k]); any Q (batches of 1024).

@@ -143,6 +143,16 @@ int mi_topk_merge_strided_device(const double* score64_dev, const int64_t* idx_d
 int mi_aqe_partial_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_stride_j,
                           int64_t rank_stride_q, int64_t nq, int32_t k_qe, double w,
                           double* out_sum_dev, void* stream);
+/* Across shards (round 4; replaces the all-gather of f64 partial sums): `rows` writes, for every requested (j, q), the f32 row
+ * this shard owns -- zeros when another shard owns it -- into out_rows_dev [k_qe][nq][d]; the blocks of all shards are SUMMED
+ * (all-reduce: every element has exactly one non-zero contributor, so the sum is exact whatever order the collective adds
+ * in; k_qe * nq * d * 4 bytes, 24 MiB at k_qe = 3, nq = 1024, d = 2048); `combine` adds the rows in j order with the
+ * single-shard kernel's own weight and fused multiply-add -> the f64 sum [nq][d] of ONE gallery, bit for bit, independent of
+ * the shard boundaries. */
+int mi_aqe_rows_device(mi_gallery* g, const int64_t* ranks_dev, int64_t rank_stride_j, int64_t rank_stride_q, int64_t nq,
+                       int32_t k_qe, float* out_rows_dev, void* stream);
+int mi_aqe_combine_device(const float* rows_dev, int64_t nq, int32_t d, int32_t k_qe, double w, double* out_sum_dev,
+                          void* stream);
 int mi_aqe_finish_device(const double* sum_dev, int64_t nq, int32_t d, double eps, float* out_q_dev,
                          double* out_q64_dev, void* stream);
 /* Host convenience (single shard): ranks host int64; out_qexp (may be NULL) f64 [nq][d]. */
@@ -156,6 +166,15 @@ int mi_aqe_search(mi_gallery* g, const int64_t* ranks, int64_t rank_stride_j, in
 int mi_knn_dense_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride,
                         int64_t col_stride, int32_t k, int64_t* out_idx, float* out_score,
                         double* out_seconds);
+/* The same at full precision and with no threshold logic at all: EVERY score of the gallery in float64 (f32 stored rows,
+ * exact f64 products, f64 accumulation -- the arithmetic of the certificate's re-score) into a dense [queries, N] matrix,
+ * then the exact top-k of it by (score desc, idx asc), k <= 4096.  The last resort of mi_knn_search on massively tied
+ * data, and the INDEPENDENT checker of the filtered path at full size: whatever the filter, thresholds or candidate
+ * buffers did, the two answers must agree (tests/test_gpu_full_size.py, bench.py `score_check`).  Replaces the full
+ * argsort of src/utils/nnsearch.py:701-703 as the definition of "nothing is missing".  out_score / out_score64 may be NULL. */
+int mi_knn_dense64_search(mi_gallery* g, const void* q, int64_t nq, int dtype, int64_t row_stride,
+                          int64_t col_stride, int32_t k, int64_t* out_idx, float* out_score,
+                          double* out_score64, double* out_seconds);
 
 /* ---- full-length ranking: `np.argsort(-scores, axis=0)` over ALL rows (src/main_retrieve.py:176,
  * src/utils/Reranking.py:207; --mode mAP of src/test_rOP1m.py:144-149).  Exact f32 inner products, stable radix sort:
@@ -237,6 +256,15 @@ int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_
 int mi_gallery_norm_bounds(mi_gallery* g, float* bounds3 /* in-out */, int raise);  /* raise=0: read; 1: bounds = max(own, given) */
 int mi_gallery_set_image_dtype(mi_gallery* g, int f16);  /* re-images the stored f32 rows (1 = fp16, 0 = bf16); no-op if equal */
 
+/* The eight XCDs of one MI355X hold different clocks under the same load, so the tile kernel splits the gallery tiles over
+ * them by their MEASURED speed (option "xcc_balance"); the shares start equal and converge over the first ~4 large launches
+ * of a handle (finish times spread by 2-3 % until then).  mi_gallery_calibrate runs `launches` (<= 64; 8 is plenty) scoring
+ * launches of up to 1024 of the gallery's own rows against the whole gallery on `stream`, asynchronously, and discards the
+ * answers: the shares are converged before the first real search instead of during it.  No-op for galleries of < 512 tiles
+ * (131 072 rows).  One-off cost: `launches` x one batch (27 ms for 8 launches at 1 M x 2048 rows).  Clears the sticky flags
+ * (read them first if asynchronous searches are outstanding). */
+int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream);
+
 /* ---- status / instrumentation */
 typedef struct mi_search_stats {
   int64_t searches;           /* query batches processed */
@@ -269,7 +297,8 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
  * on the sample splits K over several workgroups that add their partial scores with float atomics; default 1.  The order of
  * those adds is not fixed, so the sample scores -- and with them the survivor / candidate statistics and which queries need a
  * repair -- may differ by an ulp from run to run; the answers do not: the threshold is speculative and verified), "xcc_balance" (XCD shares by measured
- * speed), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
+ * speed), "stream_tail" (default 1: a HOST entry point called with more than 1024 queries runs its internal batches with the
+ * deferred tail of "async_tail" 3 and reads the sticky flags once at the end; 0 = one verified batch after the other), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),

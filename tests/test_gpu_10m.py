@@ -98,3 +98,18 @@ def test_10m_full_batch_tile_kernel_equals_the_f32_scored_path(huge):
     _check_scores_f64(g, q, idx, sc, range(0, 1024, 128))
     idx2, sc2 = _search(g, q, 1024)                                   # idempotent
     assert np.array_equal(idx, idx2) and np.array_equal(sc, sc2)
+
+
+def test_10m_answers_equal_the_dense_float64_search(huge):
+    """The independent completeness check at 10 M rows (bf16 image, chunk schedule): 8 queries -- the planted ones on both
+    sides of every chunk seam -- through `mi_knn_dense64_search` (every score in float64, exact top-100 of the dense row, no
+    threshold logic) equal the filter path's answer inside the 1024-query batch."""
+    g, q = huge
+    qh = q.cpu().numpy()
+    pick = np.array([0, 1, 2, 3, 4, 5, 6, 700])
+    didx, dsc, dsc64, _ = g.dense64_search(qh[pick], K)
+    for j, qi in enumerate(pick[:7]):
+        assert didx[j, 0] == PLANTS[int(qi)]
+    idx, sc = _search(g, q, 1024)
+    assert np.array_equal(idx[pick], didx)
+    assert np.abs(sc[pick] - dsc).max() <= 6e-8 and np.abs(sc[pick].astype(np.float64) - dsc64).max() < 6e-8

@@ -61,14 +61,49 @@ def test_one_gpu_line_has_the_contract_fields():
 
 
 def test_default_shape_line_carries_the_secondary_blocks():
-    """The default workload (1 005 994 rows) with the secondary blocks at a reduced cost: `deferred_tail` -- the pipelined
-    mode on the same gallery, whose answer must equal the synchronous one -- and `scale_10m` on a smaller row count."""
+    """The default workload (1 005 994 rows) at a reduced cost.  The headline runs in the deferred-tail mode; the line then
+    carries `synchronous` -- the same steps with the tail on the caller's stream, whose answer must equal the pipelined one
+    and on whose undisturbed launches `roofline` is quoted --, `scale_10m` (here on a smaller row count) and `map`: mAP
+    (E / M / H) of the HIP ranks on the planted rOxford5k- / +rParis6k-sized datasets."""
     out = _bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--scale-10m", "on", "--scale-10m-rows", "400000",
                   "--scale-10m-steps", "2"])
-    assert out["config"]["gallery_rows"] == 1005994 and out["config"]["tail"] == "same stream"
-    d = out["deferred_tail"]
-    assert "error" not in d, d
-    assert d["equals_synchronous_answer"] is True and d["overflow_batches"] == 0
-    assert d["value"] > 0 and 0 < d["kernel_share_of_step"] < 1 and d["steps"] == 100
+    assert out["config"]["gallery_rows"] == 1005994 and out["config"]["tail"].startswith("deferred")
+    assert out["config"]["value_mode"].startswith("pipelined") and "mi_knn_dense64_search" in out["config"]["score_check"]
+    d = out["synchronous"]
+    assert d["equals_pipelined_answer"] is True and d["flagged_batches"] == 0
+    assert d["value"] > 0 and 0 < d["kernel_share_of_step"] < 1 and d["steps"] == 6
+    r = out["roofline"]
+    assert r["launches"] == 6 and "synchronous" in r["measured_on"] and r["pipelined"]["launches"] == 6
+    assert r["pipelined"]["kernel_share_of_step"] > r["kernel_share_of_step"]        # the tail left the step
     s = out["scale_10m"]
     assert "error" not in s and s["gallery_rows"] == 400000 and s["image"] == "bf16"
+    assert "mi_knn_dense64_search" in s["score_check"]
+    m = out["map"]
+    assert [b["gallery_rows"] for b in m] == [4993, 11315]
+    for b in m:
+        assert 0 < b["map"]["H"] <= b["map"]["M"] <= 1 and 0 < b["map"]["E"] <= 1 and b["time_per_query_s"] > 0
+
+
+def test_explicit_synchronous_headline():
+    out = _bench(["--rows", "150000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--async-tail", "0"])
+    assert out["config"]["tail"] == "same stream" and out["config"]["value_mode"] == "synchronous"
+    assert "synchronous" not in out and out["roofline"]["launches"] == 4
+
+
+def test_bare_gpus_2_line_answers_layout_overlap_and_collective_cost():
+    """what ONE hardware run at N > 1 must be able to answer.  Two ranks (sharing the test box's GPU over
+    gloo), reduced sizes: the auto-layout headline, the `row_shard_1xN` block -- north_star's partition, synchronous AND with
+    pipelined collectives, with the per-stage timings of the protocol -- and `scale_10m` with both as well."""
+    out = _bench(["--gpus", "2", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                  "--multi-gpu-blocks", "on", "--scale-10m", "on", "--scale-10m-rows", "600000", "--scale-10m-steps", "3"],
+                 {"ISEHR_DIST_BACKEND": "gloo", "ISEHR_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2
+    assert out["config"]["collectives"] is None                         # auto layout at N = 2: two query groups, no exchange
+    for blk in (out["row_shard_1xN"], out["scale_10m"]):
+        assert blk["value"] > 0 and blk["pipelined_collectives"]["value"] > 0
+        assert blk["pipelined_collectives"]["equals_synchronous_answer"] is True
+        ph = blk["protocol_phases_ms_max_over_ranks"]
+        assert set(ph) == {"phase1", "allgather1", "kth", "phase2", "allgather2", "merge", "total"}
+        assert ph["total"] >= ph["phase1"] > 0 and ph["allgather1"] >= 0 and ph["allgather2"] >= 0
+        assert "mi_knn_dense64_search" in blk["score_check"]
+    assert out["row_shard_1xN"]["parallelism"].startswith("row-shard x2")

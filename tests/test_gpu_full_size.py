@@ -171,3 +171,22 @@ def test_full_size_bf16_image_equals_exact_path(big):
         g.set_image_dtype(1)
     idx, sc = _search(g, q, 64)                                       # back on fp16: same answers as before
     assert int(g.get_option("image_dtype")) == 1 and np.array_equal(idx, idx_e[:64]) and np.array_equal(sc, sc_e[:64])
+
+
+def test_full_size_answers_equal_the_dense_float64_search(big):
+    """Completeness by an INDEPENDENT path (missing #3): `mi_knn_dense64_search` computes every one of the
+    1,005,994 scores of a query in float64 and selects the exact top-100 of the dense row -- no sample, no threshold, no
+    survivor or candidate buffers.  A row that the filter path AND its f32-scored twin both dropped would show here.  The
+    tile kernel's answer (16 queries of the 1024-query batch, the planted ones among them) and the streaming kernel's (a
+    16-query batch) must be those indices; scores agree to the last float32 bit or its neighbour (two float64 summation orders)."""
+    g, _, _, q = big
+    qh = q.cpu().numpy()
+    pick = np.r_[0:6, np.arange(100, 1024, 100)][:16]
+    didx, dsc, dsc64, _ = g.dense64_search(qh[pick], K)
+    assert didx[0, 0] == 7 and didx[1, 0] == 500000 and didx[2, 0] == N - 1
+    idx, sc = _search(g, q, 1024)                                     # tile kernel, speculative single launch
+    assert np.array_equal(idx[pick], didx)
+    assert np.abs(sc[pick] - dsc).max() <= 6e-8 and np.abs(sc[pick].astype(np.float64) - dsc64).max() < 6e-8
+    didx16, dsc16, _, _ = g.dense64_search(qh[:16], K)
+    idx16, sc16 = _search(g, q, 16)                                   # streaming kernel
+    assert np.array_equal(idx16, didx16) and np.abs(sc16 - dsc16).max() <= 6e-8

@@ -365,6 +365,21 @@ def test_alpha_qe_across_shards_equals_single_shard():
     _lib.aqe_finish_device(total.data_ptr(), nq, d, 1e-6, qx.data_ptr(), qx64.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.abs(qx64.cpu().numpy() - ref_qx).max() < 1e-15
+    # round 4, what the multi-rank aqe_search does: the shards' ROW blocks (zeros for rows of other shards) summed -- one
+    # non-zero contributor per element, exact in any order -- then added in j order by the single-shard kernel's own step:
+    # the single-shard expanded query bit for bit, wherever the shard boundaries fall
+    for k_qe in (3, 10):
+        ref_i, ref_s, ref_q, _ = single.aqe_search(ranks_h, k_qe, 4.0, k, return_qexp=True)
+        rows_sum = torch.zeros((k_qe, nq, d), dtype=torch.float32, device=dev)
+        for sh in reversed(shards):                                        # any order
+            rows = torch.empty((k_qe, nq, d), dtype=torch.float32, device=dev)
+            sh.aqe_rows_device(ranks.data_ptr(), ranks.stride(0), ranks.stride(1), nq, k_qe, rows.data_ptr(), stream)
+            rows_sum += rows
+        tot = torch.empty((nq, d), dtype=torch.float64, device=dev)
+        _lib.aqe_combine_device(rows_sum.data_ptr(), nq, d, k_qe, 4.0, tot.data_ptr(), stream)
+        _lib.aqe_finish_device(tot.data_ptr(), nq, d, 1e-6, qx.data_ptr(), qx64.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(qx64.cpu().numpy(), ref_q)
     # world-size-1 ShardedGallery.aqe_search on the single shard: same code path as the multi-rank one minus the collective
     sg = ShardedGallery(single)
     idx, sc, _ = sg.aqe_search(ranks, 3, 4.0, k)
@@ -372,6 +387,15 @@ def test_alpha_qe_across_shards_equals_single_shard():
     assert np.array_equal(idx.cpu().numpy(), ref_idx) and np.array_equal(sc.cpu().numpy(), ref_sc)
     for sh in shards:
         sh.close()
+    # the row shards of ONE process (MultiDeviceGallery.aqe_search): same answers, same expanded queries
+    from isehr_amd.sharded import MultiDeviceGallery
+    mg = MultiDeviceGallery.from_host(g, [0, 0, 0], norm_mode=_lib.NORM_NONE)
+    try:
+        mi, ms, mq = mg.aqe_search(ranks_h, 3, 4.0, k)
+        assert np.array_equal(mi, ref_idx) and np.array_equal(ms, ref_sc)
+        assert np.array_equal(mq, ref_qx.astype(np.float32))
+    finally:
+        mg.close()
     single.close()
 
 

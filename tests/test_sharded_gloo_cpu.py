@@ -172,3 +172,52 @@ def test_query_groups_times_row_shards_over_gloo(world, layout):
     gq, gs = (int(v) for v in layout.split("x"))
     assert sorted((ret[r][3], ret[r][4]) for r in range(world)) == [(a, b) for a in range(gq) for b in range(gs)]
     assert all(ret[r][0] is True and ret[r][1:3] == (gq, gs) for r in range(world))
+
+
+def _worker_aqe(rank, world, port, n, d, nq, k_qe, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth_rows(15, 0, n, d)
+        g[7, :5] = [-0.0, 0.0, 1e-42, -1e-42, np.float32(3.0e38)]         # signed zeros, denormals, a huge value
+        rng = np.random.default_rng(9)
+        ranks = rng.integers(0, n, size=(k_qe, nq)).astype(np.int64)
+        ranks[0, 0] = 7
+        ranks[1, 1] = -3                                                   # nobody's row: stays zero
+        lo, hi = shard_bounds(n, world, rank)
+        # the shard's block (mi_aqe_rows_device): its own rows, zeros for everybody else's
+        rows = np.zeros((k_qe, nq, d), dtype=np.float32)
+        mine = (ranks >= lo) & (ranks < hi)
+        rows[mine] = g[ranks[mine]]
+        t = torch.from_numpy(rows)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                           # ShardedGallery.aqe_search's exchange
+        want = np.where(((ranks >= 0) & (ranks < n))[..., None], g[np.clip(ranks, 0, n - 1)], np.float32(0.0))
+        # exact in any order: every element has one non-zero contributor (x + 0 == x); the sign of a zero is the one thing
+        # that may differ, and the weighted f64 sum downstream treats both zeros alike
+        ok = np.array_equal(t.numpy(), want)
+        nz = want != 0
+        ok = ok and np.array_equal(t.numpy().view(np.uint32)[nz], want.view(np.uint32)[nz])
+        # the j-ordered f64 sum of the exchanged rows = the single-gallery sum (oracle: feature_enhancement's weights)
+        wts = (np.arange(k_qe, 0, -1) / k_qe) ** 4.0
+        got = np.zeros((nq, d))
+        ref = np.zeros((nq, d))
+        for j in range(k_qe):
+            got += t.numpy()[j].astype(np.float64) * wts[j]
+            ref += want[j].astype(np.float64) * wts[j]
+        ret[rank] = bool(ok and np.array_equal(got, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_aqe_row_exchange_is_exact_over_gloo(world):
+    """Sharded alpha-QE (round 4): the shards exchange ROWS by an all-reduce in which every element has exactly one non-zero
+    contributor -- exact whatever order the collective adds in -- so the j-ordered float64 sum is that of ONE gallery."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_aqe, args=(world, port, 1000, 48, 33, 3, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)) and len(ret) == world
