@@ -307,6 +307,9 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
         name, val = opt.split("=")
         gal.set_option(name, float(val))
     sg = ShardedGallery(gal, group=group, force_protocol=args.force_protocol)
+    for opt in options:                           # (the constructor sizes the re-score launch for ITS group: --option wins)
+        name, val = opt.split("=")
+        gal.set_option(name, float(val))
 
     # a small pool of query batches (seeded), cycled over the steps
     pool = []

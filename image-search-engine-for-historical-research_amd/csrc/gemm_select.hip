@@ -1294,6 +1294,8 @@ void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
         if (a.variant == 14) return launch_tile<false, 0, true, false, 3, 0, 2 << 8>(a, lds, stream);     // query nt (control)
         if (a.variant == 15) return launch_tile<false, 0, true, false, 3, 0, 18>(a, lds, stream);         // gallery nt sc1
         if (a.variant == 16) return launch_tile<false, 0, true, false, 3, 0, 1>(a, lds, stream);          // gallery sc0
+        if (a.variant == 17) return launch_tile<false, 0, true, false, 3, 1, 1>(a, lds, stream);          // zero-C + gallery sc0
+        if (a.variant == 18) return launch_tile<false, 0, true, false, 3, 1, 17>(a, lds, stream);         // zero-C + gallery sc0 sc1
         if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream);
         if (a.variant == 4) return launch_tile<false, 0, true, false, 1>(a, lds, stream);
         if (a.variant == 5) return launch_tile<false, 0, true, false, 3, 1>(a, lds, stream);   // zero-C first slice

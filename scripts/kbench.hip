@@ -87,7 +87,7 @@ struct Variant {
 
 int main(int argc, char** argv) {
   int64_t rows = 1005994;
-  int d = 2048, nq = 1024, rounds = 3, reps = 5, f16 = 1;
+  int d = 2048, nq = 1024, rounds = 3, reps = 5, f16 = 1, rotate = 0;
   float thr = 0.0663f;
   std::vector<Variant> vs;
   for (int i = 1; i < argc; ++i) {
@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
     else if (a == "--reps") reps = atoi(next().c_str());
     else if (a == "--thr") thr = (float)atof(next().c_str());
     else if (a == "--bf16") f16 = 0;
+    else if (a == "--rotate") rotate = 1;     // round r starts at variant r: no variant is always the one behind the same neighbour
     else {
       Variant v;
       const size_t c1 = a.find(':');
@@ -172,7 +173,8 @@ int main(int argc, char** argv) {
   printf("# rows=%lld d=%d q=%d tiles=%lld slices=%d thr=%.4f %s grid=%u\n", (long long)rows, d, nq, (long long)ntiles,
          nsl, thr, f16 ? "f16" : "bf16", nseg / 8);
   for (int r = 0; r < rounds; ++r)
-    for (auto& v : vs) {
+    for (size_t vi = 0; vi < vs.size(); ++vi) {
+      auto& v = vs[(vi + (rotate ? (size_t)r : 0)) % vs.size()];
       a.debug = v.debug;
       a.variant = v.variant;
       CK(hipMemset(rec_cnt, 0, nseg * 4));

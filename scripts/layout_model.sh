@@ -5,7 +5,7 @@ for cfg in "1 1" "2 1" "1 2" "4 1" "2 2" "1 4" "8 1" "4 2" "2 4" "1 8"; do
   set -- $cfg; gq=$1; gs=$2
   rows=$(( (1005994 + gs - 1) / gs )); q=$(( 1024 / gq ))
   extra=""; [ $gs -gt 1 ] && extra="--force-protocol --option rescore_grid_x=$(( 96 / gs ))"
-  python bench.py --scale-10m off --no-cpu-baseline --rows $rows --queries $q $extra 2>/dev/null | python -c "
+  python bench.py --scale-10m off --no-cpu-baseline --async-tail 0 --rows $rows --queries $q $extra 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 n=$gq*$gs

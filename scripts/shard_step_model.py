@@ -24,13 +24,17 @@ def main():
     torch.cuda.set_device(0)
     stream = torch.cuda.current_stream().cuda_stream
     shards = []
+    opts = [o for o in sys.argv[3:] if not o.startswith("image_dtype=")]
+    for o in sys.argv[3:]:
+        if o.startswith("image_dtype="):                 # process-wide default of the galleries created below: 0 = bf16
+            _lib.set_global_option("image_dtype", float(o.split("=")[1]))
     for r in range(G):
         lo, hi = shard_bounds(n, G, r)
         raw = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
         _lib.synth_fill_device(raw.data_ptr(), 1234, lo, hi - lo, d, stream)
         torch.cuda.synchronize()
         shards.append(_lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, device=0, row_offset=lo))
-        for opt in sys.argv[3:]:
+        for opt in opts:
             name, val = opt.split("=")
             shards[-1].set_option(name, float(val))
         torch.cuda.synchronize()
