@@ -70,6 +70,12 @@ def parse():
                          "bootstrap of batch i+1 only.  Results of every batch are joined inside the timed region.  Default: "
                          "3 for the headline of a one-GPU run with batches of > 128 queries (the line then also carries a "
                          "`synchronous` block, and `roofline` is quoted on ITS undisturbed launches), else 0")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="announce the next batch to every search (mi_knn_set_lookahead): its query ingest / bootstrap / "
+                         "thresholds then run on the handle's own stream beside the previous batch's scatter / maintain "
+                         "launches.  Built and measured in round 4: no gain (the empty repair launch of the previous batch "
+                         "needs a whole CU's LDS and waits for the bootstrap; cross-queue waits cost what the overlap "
+                         "saves) -- an option, off by default")
     ap.add_argument("--calibrate", type=int, default=8,
                     help="scoring launches of mi_gallery_calibrate after the ingest (XCD shares converge before the first "
                          "search; 0 = off)")
@@ -326,8 +332,12 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
         gal.set_option("async_tail", async_tail)
     last = {}
 
-    def one_step(qb):
-        idx_, sc_ = sg.search(qb, k, join=not pipelined or with_aqe)
+    # --lookahead: the next batch is announced to every search (mi_knn_set_lookahead: its query ingest / bootstrap / thresholds
+    # run beside this batch's scatter / maintain launches).  Single shard, plain search only
+    lookahead = world == 1 and not with_aqe and not sg._protocol and args.lookahead
+
+    def one_step(qb, nxt=None):
+        idx_, sc_ = sg.search(qb, k, join=not pipelined or with_aqe, next_q=nxt if lookahead else None)
         last["q"] = qb
         if with_aqe:
             # ranks[K,Q] view of the [Q,K] result, like `ranks = match_idx.T` (src/test_rOP1m.py:157) -> QGE (N >= 120000)
@@ -339,7 +349,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     def run_eager(count):
         out_ = None
         for i in range(count):
-            out_ = one_step(pool[i % len(pool)])
+            out_ = one_step(pool[i % len(pool)], pool[(i + 1) % len(pool)] if i + 1 < count else None)
         return out_
 
     def run_stream(count):
@@ -469,7 +479,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
                ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, worst=worst,
-               use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check,
+               use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check, lookahead=lookahead,
                protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
 
     if also_stream and sg._protocol and not use_stream and not with_aqe:
@@ -521,13 +531,14 @@ def synchronous_block(job, gal, args, steps):
     gal.set_option("async_tail", 0)
     gal.status(reset=True)
     out_ = None
+    la = args.lookahead
     for i in range(12):
-        out_ = sg.search(pool[i % 4], k)
+        out_ = sg.search(pool[i % 4], k, next_q=pool[(i + 1) % 4] if la else None)
     torch.cuda.synchronize()
     gal.profile(True)
     t0 = time.perf_counter()
     for i in range(steps):
-        out_ = sg.search(pool[i % 4], k)
+        out_ = sg.search(pool[i % 4], k, next_q=pool[(i + 1) % 4] if (la and i + 1 < steps) else None)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gal.profile(False)
@@ -688,6 +699,9 @@ def main():
                                 "; every result joined inside the timed region") if res["pipelined"] else "same stream",
                        "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
                        "calibrate_launches": args.calibrate,
+                       "lookahead": ("the next batch is announced to every search: its query ingest, bootstrap and thresholds "
+                                     "run beside the previous batch's scatter / maintain launches (mi_knn_set_lookahead)")
+                                    if res["lookahead"] else None,
                        # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
                        # ingest_s = one normalisation + layout pass over the resident raw rows in a warm process (the second
                        # ingest of this run; the first one, which also initialises the library, is ingest_first_s), and the

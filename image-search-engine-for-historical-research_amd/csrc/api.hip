@@ -52,6 +52,7 @@ struct Workspace {
   uint32_t* cnt = nullptr;
   uint64_t* surv = nullptr;
   uint32_t* flags = nullptr;
+  uint32_t* repair = nullptr;       // this workspace's own 'repair needed' word (never aliased)
   float *topvals = nullptr, *L = nullptr;
   uint32_t *cand_rows = nullptr, *cand_cnt = nullptr;
   double* cand_score = nullptr;
@@ -77,6 +78,20 @@ struct TmpAlloc {
     v.push_back(p);
     return reinterpret_cast<T*>(p);
   }
+};
+// what phase 1 of one batch will do (pure arithmetic on the shapes; plan_phase1)
+struct P1Plan {
+  int32_t nq = 0, k = 0, qpad = 0;
+  bool exact = false;
+  int64_t ntiles = 0, t0 = 0;
+  int32_t samp_r = 0;              // > 0: single-launch schedule on the threshold sample, speculative rank
+  uint32_t first_cnt = 0;
+  float gamma = 0.f;
+  int32_t boot_ksplit = 1;
+  bool sample_f32 = false;         // the bootstrap launch stores bare 4-byte scores
+  bool thr_kernel = false;         // sample_threshold_kernel takes the thresholds (else select_maintain mode 0)
+  int32_t lad_r = 0;               // ladder level (sample rank), 0 = off
+  bool zero_scores = false;        // the query ingest writes zeros for the K-split bootstrap to add onto
 };
 }  // namespace
 
@@ -113,6 +128,7 @@ struct mi_gallery {
   int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
   int boot_ksplit = 1;          // small batches: K-split bootstrap launch (kernels.h ScoreArgs::ksplit); 0 = one workgroup per tile
   int stream_tail = 1;          // host entry points with more than one batch of queries: deferred tail between their batches
+  int stream_lookahead = 0;     // ... and the pre part of batch i + 1 beside the scatter / maintain launches of batch i (no gain)
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
   // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 80
   // VGPRs per SIMD lane and no LDS: exactly one 70-register re-score wave per SIMD fits next to its two); results are
@@ -130,11 +146,33 @@ struct mi_gallery {
     bool valid = false;
     int32_t b = 0, k = 0;
     int set = 0;
+    int slot = 0;                             // workspace slot (ws_slot) the batch ran in
     int64_t* out_idx = nullptr;
     float* out_score = nullptr;
     double* out_score64 = nullptr;
   } pending;
   hipEvent_t ev_pre = nullptr;                // recorded on the caller's stream right before the scoring launch
+  // Lookahead (mi_knn_set_lookahead, and the internal batches of a multi-batch host call): the PRE part of the next batch --
+  // query ingest, bootstrap launch on the sample, thresholds -- is enqueued on pre_stream right behind the scoring launch of
+  // the current batch and runs in the PARKED workspace beside the current batch's scatter / maintain launches: two chains of
+  // small latency-bound launches share the chip instead of following each other.  The next search call finds its batch
+  // prepared, switches the workspaces and goes straight to its scoring launch.
+  struct Lookahead {
+    bool armed = false;                       // a next batch was announced
+    const void* q = nullptr;
+    int32_t nq = 0;
+    int dtype = MI_F32, norm = 0;
+    int64_t rs = 0, cs = 1;
+    int32_t k_cur = 0;                        // k of the search call in progress (the next batch uses the same)
+    bool prepared = false;                    // its pre part is enqueued (in ws_alt, on pre_stream; ev_ready behind it)
+    const void* pq = nullptr;
+    int32_t pnq = 0, pk = 0;
+    int pdtype = MI_F32, pnorm = 0, pset = 0;
+    int64_t prs = 0, pcs = 1;
+    P1Plan plan;
+  } la;
+  hipStream_t pre_stream = nullptr;
+  hipEvent_t ev_scored = nullptr, ev_ready = nullptr;
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -212,6 +250,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cnt, (size_t)QB * CNT_STRIDE);
   A(surv, (size_t)QB * ws.cap);
   A(flags, 4);
+  A(repair, 4);
   A(topvals, (size_t)QB * kcap);
   A(L, QB);
   A(cand_rows, (size_t)QB * ws.rcap);
@@ -234,6 +273,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cand_score_set[1], (size_t)QB * ws.rcap);
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
+  HIPC(hipMemset(ws.repair, 0, 16));
   HIPC(hipMemset(ws.stats2, 0, 2 * (size_t)QB * 8));
   HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
   HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
@@ -259,6 +299,7 @@ static QueryState make_state(const Workspace& ws) {
   st.cnt = ws.cnt;
   st.surv = ws.surv;
   st.flags = ws.flags;
+  st.repair = ws.repair;
   st.thr2 = ws.thr2;
   st.qflag = ws.qflag;
   st.lad_tc = ws.lad_tc;
@@ -339,144 +380,172 @@ static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
 }
 
 // ---- phase 1 for one batch (nq <= QB): query ingest, chunked scoring + threshold maintenance ----------
-// fuse_cand: the final maintain launch also writes the candidate lists (single-shard search: its L is the global one)
+// Split in three since round 4: a PLAN (pure arithmetic: which schedule, which sample rank), the PRE part -- everything that
+// depends on the queries but not on a finished scoring launch: query ingest, bootstrap launch on the sample image, thresholds --
+// and the MAIN part (scoring launches, scatter, maintain, repair).  The pre part of batch i + 1 can run on the handle's own
+// stream in the OTHER workspace while the main part of batch i finishes (mi_knn_set_lookahead): both are latency-bound
+// chains of small launches that leave most of the chip idle.
 static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring);
 
-// caller_checks_flags: the caller synchronises, reads the sticky flags itself and answers a flagged batch again (the host
-// entry points): small batches then launch no device-side repair pass.  The asynchronous device / phase entry points pass
-// false -- their callers may never look at the flags, so a failed speculative threshold is repaired on the device.
-static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
-                        int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false,
-                        bool caller_checks_flags = false) {
-  Workspace& ws = g->ws;
-  uint32_t* fc_rows = fuse_cand ? ws.cand_rows : nullptr;
-  uint32_t* fc_cnt = fuse_cand ? ws.cand_cnt : nullptr;
-  const int32_t qpad = (int32_t)round_up(nq, TILE);
-  QueryState st = make_state(ws);
-  const int64_t ntiles = g->npad / TILE;
+
+static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, int32_t k, bool exact) {
+  P1Plan pl;
+  pl.nq = nq;
+  pl.k = k;
+  pl.exact = exact;
+  pl.qpad = (int32_t)round_up(nq, TILE);
+  pl.ntiles = g->npad / TILE;
   // bootstrap chunk: stored completely (no threshold yet); must hold >= K rows and fit the survivor buffer
   int64_t t0 = std::max<int64_t>(bootstrap_tiles(g), (2 * (int64_t)k + TILE - 1) / TILE);
   t0 = std::min<int64_t>(t0, ws.cap / TILE);
-  t0 = std::min<int64_t>(t0, ntiles);
+  t0 = std::min<int64_t>(t0, pl.ntiles);
+  pl.t0 = t0;
   // Single-launch schedule?  The speculative threshold is an order statistic of the scores of a SAMPLE: t0 * 256
   // rows drawn evenly (one hashed draw per stratum) into their own small image, so that the order in which the shard
   // was ingested cannot bias it.  With n_s sampled rows the shard's K-th largest score sits near sample rank
   // lambda = K * n_s / N; the r-th largest sample score with r = spec_rank(lambda) lies below it except with
   // probability 1e-7 per query (Poisson tail) and keeps the expected survivors at r * N / n_s.  The sample entries
   // are dropped once the threshold is taken (the scoring launch visits every tile, sample rows included).
-  int32_t samp_r = 0;
-  if (g->speculative && !exact && ntiles >= 2 * t0 && g->n / (t0 * TILE) <= g->spec_max_ratio) {
+  if (g->speculative && !exact && pl.ntiles >= 2 * t0 && g->n / (t0 * TILE) <= g->spec_max_ratio) {
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
     const int32_t r = spec_rank(lambda);
-    if (r < k) samp_r = r;
+    if (r < k) pl.samp_r = r;
   }
-  if (samp_r > 0) {
-    const int rc = ensure_sample(g, t0, s);
-    if (rc != MI_OK) return rc;
-  }
-  const uint32_t first_cnt = (uint32_t)(samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
-  const float gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
-  // query ingest (normalise, f32 rows, 16-bit image, rounding norms) and the per-query search state in one launch
+  pl.first_cnt = (uint32_t)(pl.samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
+  pl.gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
+  pl.thr_kernel = pl.samp_r > 0 && sample_threshold_applies(pl.first_cnt, k, pl.samp_r);
   // small batches on the sample schedule: the bootstrap launch splits K over several workgroups per (sample tile, query
   // group) and adds its partial scores onto zeros that the query ingest writes (ScoreArgs::ksplit)
-  int32_t boot_ksplit = 1;
-  if (samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && g->debug == 0 &&
-      sample_threshold_applies(first_cnt, k, samp_r) && g->dp <= 4096) {
+  if (pl.samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && g->debug == 0 && pl.thr_kernel && g->dp <= 4096) {
     const int64_t wgs = t0 * ((nq + 63) / 64);                       // bootstrap workgroups of a batch of <= 512 queries
     if (nq <= 512)
-      while (boot_ksplit < 8 && wgs * boot_ksplit * 2 <= 256 && (g->dp / SLICE_K) % (boot_ksplit * 2) == 0) boot_ksplit *= 2;
+      while (pl.boot_ksplit < 8 && wgs * pl.boot_ksplit * 2 <= 256 && (g->dp / SLICE_K) % (pl.boot_ksplit * 2) == 0)
+        pl.boot_ksplit *= 2;
   }
-  if (!launch_ingest_queries(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp,
-                             qpad, g->gstat3, gamma, exact ? 0 : 1, first_cnt, st, s, boot_ksplit > 1 ? first_cnt : 0u)) {
-    boot_ksplit = 1;
-    launch_ingest(q_src, q_dtype, nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, qpad, s);
-    launch_init_query_state(ws.q_stat, g->gstat3, nq, qpad, gamma, exact ? 0 : 1, first_cnt, st, s);
-  }
-  // chunk boundaries (cumulative tiles): t0, t0*g, then x max(2, g/2) per step (thresholds keep tightening as the
-  // sample grows; a 10M-row shard needs more steps than a 1M-row one); a tail shorter than half a step is merged
-  const int64_t gr = std::max(1, g->chunk_growth);
-  const int64_t gr2 = std::max<int64_t>(2, gr / 2);
-  int64_t bound = t0;
-  int64_t t = 0, len = t0;
-  bool first = true;
-  bool ladder_on = false;           // set for the one filtered launch of the sample-based schedule
   // sample-based schedule with the dedicated threshold kernel: the bootstrap launch (stream_select MODE 2) stores bare
   // 4-byte scores, all that kernel reads (half the bytes written and read back; ScoreArgs::scores_only)
-  const bool sample_f32 = samp_r > 0 && sample_threshold_applies(first_cnt, k, samp_r) && g->small_batch_kernel &&
-                          g->debug == 0;
-  auto score_launch = [&](int64_t tile_from, int64_t ntile, bool first_chunk, const uint32_t* cond, bool profile_it,
-                          bool on_sample = false) {
-    const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
-    if (exact) {
-      ExactArgs a;
-      a.gal_f32 = g->gal_f32;
-      a.qry_f32 = ws.q_f32;
-      a.dp = g->dp;
-      a.row0 = rows0;
-      a.row1 = rows1;
-      a.n = g->n;
-      a.nq = nq;
-      a.st = st;
-      launch_exact_select(a, first_chunk, s);
-      return;
-    }
-    ScoreArgs a;
-    a.gal_img = on_sample ? g->samp_img : g->gal_img;
-    a.qry_img = ws.q_img;
-    a.img_f16 = g->img_f16;
-    a.nslices = g->dp / SLICE_K;
-    a.tile0 = (int32_t)tile_from;
-    a.ntiles = (int32_t)ntile;
-    a.nqt = qpad / TILE;
-    a.n = on_sample ? ntile * TILE : g->n;
-    a.nq = nq;
-    a.debug = g->debug;
-    a.small_batch_kernel = g->small_batch_kernel;
-    a.variant = g->kernel_variant;
-    a.rec = ws.rec;
-    a.rec_cnt = ws.rec_cnt;
-    a.rec_cap = ws.rec_cap;
-    a.cond = cond;
-    a.bal = g->xcc_balance ? ws.bal : nullptr;
-    a.lad_k = ladder_on ? k : 0;
-    a.scores_only = (on_sample && first_chunk && sample_f32) ? 1 : 0;
-    a.ksplit = a.scores_only ? boot_ksplit : 1;
-    a.dbg = ws.dbg;
+  pl.sample_f32 = pl.thr_kernel && g->small_batch_kernel && g->debug == 0;
+  // in-launch ladder: a tighter sample order statistic (rank j < r) becomes a rigorous threshold once K rows above it have
+  // been counted during the launch.  In units of N / n_s rows: score(j) has expected rank j in the shard and is validated
+  // after the fraction lambda / j of the rows (lambda = K n_s / N), so the survivors are ~ (lambda / j) r + (1 - lambda / j) j,
+  // smallest at j = sqrt(lambda r) (3 at N = 1M, K = 100: 1500 -> 900 survivors per query)
+  if (g->ladder && pl.samp_r > 1 && pl.thr_kernel) {
+    const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
+    int32_t lr = (int32_t)std::lround(std::sqrt(lambda * pl.samp_r));
+    pl.lad_r = std::max<int32_t>(1, std::min<int32_t>(lr, pl.samp_r - 1));
+  }
+  return pl;
+}
+
+// one scoring launch (+ the scatter of its records) of a phase-1 schedule
+static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, const P1Plan& pl, int64_t tile_from, int64_t ntile,
+                            bool first_chunk, const uint32_t* cond, bool profile_it, bool on_sample, bool ladder_on,
+                            hipStream_t s, bool* lookahead_after_launch = nullptr);
+
+// PRE part.  With pl.samp_r > 0: query ingest + per-query state, bootstrap launch on the sample image, thresholds (+ ladder
+// levels).  Otherwise (chunk schedules): the query ingest alone.
+static int p1_pre(mi_gallery* g, Workspace& ws, const P1Plan& pl, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs,
+                  int q_norm, hipStream_t s) {
+  QueryState st = make_state(ws);
+  if (pl.samp_r > 0) {
+    const int rc = ensure_sample(g, pl.t0, s);
+    if (rc != MI_OK) return rc;
+  }
+  int32_t boot_ksplit = pl.boot_ksplit;
+  // query ingest (normalise, f32 rows, 16-bit image, rounding norms) and the per-query search state in one launch
+  if (!launch_ingest_queries(q_src, q_dtype, pl.nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp,
+                             pl.qpad, g->gstat3, pl.gamma, pl.exact ? 0 : 1, pl.first_cnt, st, s,
+                             boot_ksplit > 1 ? pl.first_cnt : 0u)) {
+    boot_ksplit = 1;
+    launch_ingest(q_src, q_dtype, pl.nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, pl.qpad, s);
+    launch_init_query_state(ws.q_stat, g->gstat3, pl.nq, pl.qpad, pl.gamma, pl.exact ? 0 : 1, pl.first_cnt, st, s);
+  }
+  if (pl.samp_r > 0) {
+    P1Plan p2 = pl;
+    p2.boot_ksplit = boot_ksplit;
+    p1_score_launch(g, ws, st, p2, 0, pl.t0, true, nullptr, false, true, false, s);     // bootstrap on the sample image
+    if (pl.thr_kernel)
+      launch_sample_threshold(st, pl.nq, pl.k, pl.samp_r, pl.first_cnt, s, pl.lad_r, pl.sample_f32 ? 1 : 0,
+                              (pl.sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f);
+    else
+      launch_select_maintain(st, pl.nq, pl.k, 0, ws.topvals, ws.L, ws.stats2, pl.samp_r, 1, 0, nullptr, s);
+  }
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, const P1Plan& pl, int64_t tile_from, int64_t ntile,
+                            bool first_chunk, const uint32_t* cond, bool profile_it, bool on_sample, bool ladder_on,
+                            hipStream_t s, bool* lookahead_after_launch) {
+  const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
+  if (pl.exact) {
+    ExactArgs a;
+    a.gal_f32 = g->gal_f32;
+    a.qry_f32 = ws.q_f32;
+    a.dp = g->dp;
+    a.row0 = rows0;
+    a.row1 = rows1;
+    a.n = g->n;
+    a.nq = pl.nq;
     a.st = st;
-    profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
-    size_t slot = (size_t)-1;
-    if (profile_it) prof_begin(g, s, &slot);
-    launch_gemm_select(a, first_chunk, s);
-    if (profile_it) prof_end(g, s, slot);
-    if (profile_it && g->profile) {
-      const double rows = (double)(rows1 - rows0);
-      g->stats.gemm_flops += 2.0 * nq * rows * g->d;
-      g->stats.gemm_bytes += rows * g->d * 2.0 + (double)nq * g->d * 2.0;
-    }
-    if (!first_chunk)
-      launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s,
-                             (g->xcc_balance && !on_sample && !stream_select_applies(a)) ? ws.bal : nullptr, ws.dbg,
-                             (uint32_t)ntile, nq);
-  };
-  if (samp_r > 0) {
-    score_launch(0, t0, true, nullptr, false, true);                           // bootstrap on the sample image
-    // in-launch ladder: a tighter sample order statistic (rank j < r) becomes a rigorous threshold once K rows above it have
-    // been counted during the launch.  In units of N / n_s rows: score(j) has expected rank j in the shard and is validated
-    // after the fraction lambda / j of the rows (lambda = K n_s / N), so the survivors are ~ (lambda / j) r + (1 - lambda / j) j,
-    // smallest at j = sqrt(lambda r) (3 at N = 1M, K = 100: 1500 -> 900 survivors per query)
-    int32_t lad_r = 0;
-    if (g->ladder && samp_r > 1) {
-      const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
-      lad_r = (int32_t)std::lround(std::sqrt(lambda * samp_r));
-      lad_r = std::max<int32_t>(1, std::min<int32_t>(lad_r, samp_r - 1));
-    }
-    if (sample_threshold_applies(first_cnt, k, samp_r)) {
-      launch_sample_threshold(st, nq, k, samp_r, first_cnt, s, lad_r, sample_f32 ? 1 : 0,
-                              (sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f);
-      ladder_on = lad_r > 0;
-    } else {
-      launch_select_maintain(st, nq, k, 0, ws.topvals, ws.L, ws.stats2, samp_r, 1, 0, nullptr, s);
-    }
+    launch_exact_select(a, first_chunk, s);
+    return;
+  }
+  ScoreArgs a;
+  a.gal_img = on_sample ? g->samp_img : g->gal_img;
+  a.qry_img = ws.q_img;
+  a.img_f16 = g->img_f16;
+  a.nslices = g->dp / SLICE_K;
+  a.tile0 = (int32_t)tile_from;
+  a.ntiles = (int32_t)ntile;
+  a.nqt = pl.qpad / TILE;
+  a.n = on_sample ? ntile * TILE : g->n;
+  a.nq = pl.nq;
+  a.debug = g->debug;
+  a.small_batch_kernel = g->small_batch_kernel;
+  a.variant = g->kernel_variant;
+  a.rec = ws.rec;
+  a.rec_cnt = ws.rec_cnt;
+  a.rec_cap = ws.rec_cap;
+  a.cond = cond;
+  a.bal = g->xcc_balance ? ws.bal : nullptr;
+  a.lad_k = ladder_on ? pl.k : 0;
+  a.scores_only = (on_sample && first_chunk && pl.sample_f32) ? 1 : 0;
+  a.ksplit = a.scores_only ? pl.boot_ksplit : 1;
+  a.dbg = ws.dbg;
+  a.st = st;
+  profile_it = profile_it && !first_chunk;      // the roofline is quoted on the filtered scoring launches only
+  size_t slot = (size_t)-1;
+  if (profile_it) prof_begin(g, s, &slot);
+  launch_gemm_select(a, first_chunk, s);
+  if (profile_it) prof_end(g, s, slot);
+  if (profile_it && g->profile) {
+    const double rows = (double)(rows1 - rows0);
+    g->stats.gemm_flops += 2.0 * pl.nq * rows * g->d;
+    g->stats.gemm_bytes += rows * g->d * 2.0 + (double)pl.nq * g->d * 2.0;
+  }
+  if (lookahead_after_launch) *lookahead_after_launch = true;    // the caller enqueues the next batch's pre part HERE
+  if (!first_chunk)
+    launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s,
+                           (g->xcc_balance && !on_sample && !stream_select_applies(a)) ? ws.bal : nullptr, ws.dbg,
+                           (uint32_t)ntile, pl.nq);
+}
+
+static int enqueue_lookahead(mi_gallery* g, hipStream_t s);
+
+// MAIN part: the filtered scoring launch(es) with their scatter / maintain launches, the conditional repair pass.
+// fuse_cand: the final maintain launch also writes the candidate lists (single-shard search: its L is the global one).
+// caller_checks_flags: the caller synchronises, reads the sticky flags itself and answers a flagged batch again (the host
+// entry points): small batches then launch no device-side repair pass.  The asynchronous device / phase entry points pass
+// false -- their callers may never look at the flags, so a failed speculative threshold is repaired on the device.
+static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s, bool fuse_cand, bool caller_checks_flags) {
+  uint32_t* fc_rows = fuse_cand ? ws.cand_rows : nullptr;
+  uint32_t* fc_cnt = fuse_cand ? ws.cand_cnt : nullptr;
+  QueryState st = make_state(ws);
+  const int32_t nq = pl.nq, k = pl.k;
+  const int64_t ntiles = pl.ntiles, t0 = pl.t0;
+  const bool exact = pl.exact;
+  if (pl.samp_r > 0) {
     if (g->gate_before_scoring) {               // the previous batch's tail ran beside this batch's ingest / bootstrap
       HIPC(hipStreamWaitEvent(s, g->gate_before_scoring, 0));
       g->gate_before_scoring = nullptr;
@@ -485,10 +554,15 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
       const int rc = flush_pending_tail(g, s, /*beside_scoring=*/true);
       if (rc != MI_OK) return rc;
     }
-    score_launch(0, ntiles, false, nullptr, true);                             // every tile, one launch
-    ladder_on = false;
+    // every tile, one launch; the pre part of an announced NEXT batch is enqueued right behind it (before this batch's
+    // scatter / maintain launches, with which it then shares the chip)
+    p1_score_launch(g, ws, st, pl, 0, ntiles, false, nullptr, true, false, pl.lad_r > 0 && pl.thr_kernel, s);
+    if (g->la.armed) {
+      const int rc = enqueue_lookahead(g, s);
+      if (rc != MI_OK) return rc;
+    }
     // repair pass for queries whose speculative threshold failed verification (1e-7 per query): conditional on the device
-    // word flags[1], i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip.  Batches
+    // word *ws.repair, i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip.  Batches
     // of <= 128 queries -- the reference's own shapes, one query online and 70 per test set, where three empty launches
     // are 1 % of the batch and a failure has probability <= 1e-5 -- do without WHEN THE CALLER IS A HOST ENTRY POINT: that
     // one synchronises anyway, sees FLAG_SPEC_FAIL and answers the batch again by the rigorous schedule.  The asynchronous
@@ -499,8 +573,8 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, repair_pass ? 0 : 2, nullptr, s, fc_rows, fc_cnt,
                            ws.rcap);
     if (repair_pass) {
-      const uint32_t* cond = ws.flags + 1;
-      score_launch(0, ntiles, false, cond, false);
+      const uint32_t* cond = ws.repair;
+      p1_score_launch(g, ws, st, pl, 0, ntiles, false, cond, false, false, false, s);
       launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s, fc_rows, fc_cnt, ws.rcap);
     }
     HIPC(hipGetLastError());
@@ -512,19 +586,26 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   }
   // chunk schedule (shards too small or too large for the sample-based single launch): thresholds come from the rows
   // scored and kept so far; once those are >= 1/160 of the shard the rest goes out as one speculative launch
+  // chunk boundaries (cumulative tiles): t0, t0*g, then x max(2, g/2) per step (thresholds keep tightening as the
+  // sample grows; a 10M-row shard needs more steps than a 1M-row one); a tail shorter than half a step is merged
+  const int64_t gr = std::max(1, g->chunk_growth);
+  const int64_t gr2 = std::max<int64_t>(2, gr / 2);
+  int64_t bound = t0;
+  int64_t t = 0, len = t0;
+  bool first = true;
   bool spec_next = false, spec_cur = false;
   while (t < ntiles) {
     int64_t cur = std::min<int64_t>(len, ntiles - t);
     if (spec_next) cur = ntiles - t;
     spec_cur = spec_next;
-    score_launch(t, cur, first, nullptr, true);
+    p1_score_launch(g, ws, st, pl, t, cur, first, nullptr, true, false, false, s);
     t += cur;
     if (t >= ntiles) {
       launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, spec_cur ? 1 : 0, 0, nullptr, s, fc_rows, fc_cnt,
                              ws.rcap);
       if (spec_cur) {
-        const uint32_t* cond = ws.flags + 1;
-        score_launch(0, ntiles, false, cond, false);
+        const uint32_t* cond = ws.repair;
+        p1_score_launch(g, ws, st, pl, 0, ntiles, false, cond, false, false, false, s);
         launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, 1, cond, s, fc_rows, fc_cnt, ws.rcap);
       }
     } else {
@@ -551,10 +632,23 @@ static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q
   return MI_OK;
 }
 
+static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
+                        int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false,
+                        bool caller_checks_flags = false, bool pre_done = false) {
+  Workspace& ws = g->ws;
+  const P1Plan pl = pre_done ? g->la.plan : plan_phase1(g, ws, nq, k, exact);
+  if (!pre_done) {
+    const int rc = p1_pre(g, ws, pl, q_src, q_dtype, q_rs, q_cs, q_norm, s);
+    if (rc != MI_OK) return rc;
+  }
+  return p1_main(g, ws, pl, s, fuse_cand, caller_checks_flags);
+}
+
 // ---- phase 2 for one batch: candidates within the margin of L, exact f64 re-score, sorted emit --------
 static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev, int64_t* out_idx, float* out_score,
-                        double* out_score64, hipStream_t s, bool have_cand = false, bool resident = false) {
-  Workspace& ws = g->ws;
+                        double* out_score64, hipStream_t s, bool have_cand = false, bool resident = false,
+                        Workspace* wsp = nullptr) {
+  Workspace& ws = wsp ? *wsp : g->ws;
   QueryState st = make_state(ws);
   if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
   const uint32_t last_row = (uint32_t)std::max<int64_t>(0, g->n - 1);
@@ -582,7 +676,7 @@ static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring)
   if (!g->pending.valid) return MI_OK;
   const mi_gallery::PendingTail p = g->pending;
   g->pending.valid = false;
-  Workspace& ws = g->ws;
+  Workspace& ws = (p.slot == g->ws_slot) ? g->ws : g->ws_alt;     // the workspace the batch ran in (lookahead alternates them)
   float* q_keep = ws.q_f32;
   uint32_t* rows_keep = ws.cand_rows;
   uint32_t* cnt_keep = ws.cand_cnt;
@@ -600,7 +694,7 @@ static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring)
   if (e != hipSuccess) rc = fail(MI_ERR_HIP, hipGetErrorString(e));
   if (rc == MI_OK)
     rc = phase2_batch(g, p.b, p.k, ws.L, p.out_idx, p.out_score, p.out_score64, g->tail_stream, /*have_cand=*/true,
-                      /*resident=*/true);
+                      /*resident=*/true, &ws);
   if (rc == MI_OK) {
     e = hipEventRecord(g->ev_tail[p.set], g->tail_stream);
     if (e != hipSuccess) rc = fail(MI_ERR_HIP, hipGetErrorString(e));
@@ -611,6 +705,50 @@ static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring)
   ws.cand_cnt = cnt_keep;
   ws.cand_score = sc_keep;
   return rc;
+}
+
+// The pre part of the announced next batch, enqueued on the handle's pre_stream behind the scoring launch that `s` has just
+// received; it runs in the parked workspace.  Skipped (the next call then does its own pre part) when that batch would not
+// take the single-launch sample schedule or the parked workspace does not exist yet.
+static int enqueue_lookahead(mi_gallery* g, hipStream_t s) {
+  mi_gallery::Lookahead& la = g->la;
+  la.armed = false;
+  la.prepared = false;
+  const int32_t k = la.k_cur;
+  Workspace& alt = g->ws_alt;
+  if (la.nq < 1 || la.nq > QB || alt.qcap < QB || alt.kcap < k || alt.cap != g->surv_cap || alt.rcap != g->rescore_cap)
+    return MI_OK;
+  const P1Plan pl = plan_phase1(g, alt, la.nq, k, false);
+  if (!(pl.samp_r > 0 && pl.thr_kernel)) return MI_OK;
+  if (!g->pre_stream) {
+    HIPC(hipStreamCreateWithFlags(&g->pre_stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&g->ev_scored, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming));
+  }
+  HIPC(hipEventRecord(g->ev_scored, s));                          // behind the scoring launch of the current batch
+  HIPC(hipStreamWaitEvent(g->pre_stream, g->ev_scored, 0));
+  // the buffer set the next batch will use (the asynchronous modes alternate two; this batch toggled already): whoever
+  // read it last -- the tail of the batch before this one -- must be done with it
+  const int nset = g->async_tail != 0 ? g->tail_set : 0;
+  if (g->tail_stream && g->ev_tail_valid[nset]) HIPC(hipStreamWaitEvent(g->pre_stream, g->ev_tail[nset], 0));
+  alt.q_f32 = alt.q_f32_set[nset];
+  alt.cand_rows = alt.cand_rows_set[nset];
+  alt.cand_cnt = alt.cand_cnt_set[nset];
+  alt.cand_score = alt.cand_score_set[nset];
+  const int rc = p1_pre(g, alt, pl, la.q, la.dtype, la.rs, la.cs, la.norm, g->pre_stream);
+  if (rc != MI_OK) return rc;
+  HIPC(hipEventRecord(g->ev_ready, g->pre_stream));
+  la.prepared = true;
+  la.pq = la.q;
+  la.pnq = la.nq;
+  la.pk = k;
+  la.pdtype = la.dtype;
+  la.prs = la.rs;
+  la.pcs = la.cs;
+  la.pnorm = la.norm;
+  la.pset = nset;
+  la.plan = pl;
+  return MI_OK;
 }
 
 // a batch whose sticky flags were raised: a buffer overflow (or fp16 range) and a failed speculative threshold are counted apart
@@ -629,10 +767,23 @@ static int check_k(const mi_gallery* g, int32_t k) {
   return MI_OK;
 }
 
+// makes sure the PARKED workspace exists with the active one's capacities (lookahead runs the next batch's pre part there)
+static int ensure_parked_workspace(mi_gallery* g, int32_t k) {
+  Workspace& alt = g->ws_alt;
+  if (alt.qcap >= QB && alt.kcap >= k && alt.cap == g->surv_cap && alt.rcap == g->rescore_cap) return MI_OK;
+  std::swap(g->ws, g->ws_alt);
+  g->ws_slot ^= 1;
+  const int rc = ws_ensure(g, k);
+  std::swap(g->ws, g->ws_alt);
+  g->ws_slot ^= 1;
+  return rc;
+}
+
 // full search of up to any nq on device inputs (strided, any dtype), outputs on device
+// device_api: called by mi_knn_search_device (a batch prepared by a lookahead may be waiting for exactly this call)
 static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                          int64_t nq, int32_t k, int64_t* out_idx, float* out_score, double* out_score64, bool exact,
-                         hipStream_t s, bool allow_async = false, bool caller_checks_flags = false) {
+                         hipStream_t s, bool allow_async = false, bool caller_checks_flags = false, bool device_api = false) {
   int rc = check_k(g, k);
   if (rc != MI_OK) return rc;
   const bool async = g->async_tail != 0 && allow_async;
@@ -643,6 +794,12 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     if ((rc = flush_pending_tail(g, s, false)) != MI_OK) return rc;
     HIPC(hipStreamWaitEvent(s, g->ev_tail[set], 0));
   }
+  // a batch prepared by a lookahead belongs to a device-API call (or to the next internal batch of a streaming call) for
+  // exactly those queries; anything else drops it and the announcement (the work of its pre part is lost, nothing else)
+  // internal batches of a multi-batch call announce their successors when option "stream_lookahead" is on (default off:
+  // measured, no gain -- DESIGN 5.5)
+  const bool streaming = g->stream_lookahead && nq > QB && async && g->async_tail == 3 && !exact;
+  if (!device_api && !streaming) g->la.armed = g->la.prepared = false;
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
   const size_t esz = q_dtype == MI_F32 ? 4 : 8;
   if (async && !g->tail_stream) {
@@ -659,8 +816,31 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     const char* src = (const char*)q_src + (size_t)q0 * q_rs * esz;
     hipStream_t tail = s;
     int set = 0;
+    if (async) set = g->tail_set;
+    // is this batch waiting in the parked workspace, prepared by the previous call / the previous internal batch?
+    bool pre_hit = false;
+    if (g->la.prepared) {
+      const mi_gallery::Lookahead& la = g->la;
+      pre_hit = (device_api || streaming) && la.pq == (const void*)src && la.pnq == b && la.pk == k && la.pdtype == q_dtype &&
+                la.prs == q_rs && la.pcs == q_cs && la.pnorm == q_norm && la.pset == set && !exact;
+      g->la.prepared = false;
+      if (pre_hit) {                              // its state is in the parked workspace: make that one the active one
+        std::swap(g->ws, g->ws_alt);
+        g->ws_slot ^= 1;
+      }
+    }
+    if (streaming && q0 + QB < nq) {              // announce the next internal batch
+      g->la.armed = true;
+      g->la.q = src + (size_t)QB * q_rs * esz;
+      g->la.nq = (int32_t)std::min<int64_t>(QB, nq - q0 - QB);
+      g->la.dtype = q_dtype;
+      g->la.rs = q_rs;
+      g->la.cs = q_cs;
+      g->la.norm = q_norm;
+    }
+    g->la.k_cur = k;
+    if (g->la.armed && (rc = ensure_parked_workspace(g, k)) != MI_OK) return rc;
     if (async) {
-      set = g->tail_set;
       g->tail_set ^= 1;
       tail = g->tail_stream;
       if (g->ev_tail_valid[set]) HIPC(hipStreamWaitEvent(s, g->ev_tail[set], 0));   // the tail that last read this set is done
@@ -672,8 +852,10 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     ws.cand_rows = ws.cand_rows_set[set];
     ws.cand_cnt = ws.cand_cnt_set[set];
     ws.cand_score = ws.cand_score_set[set];
-    if ((rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true, caller_checks_flags)) != MI_OK)
-      return rc;
+    if (pre_hit) HIPC(hipStreamWaitEvent(s, g->ev_ready, 0));      // its thresholds are there
+    rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true, caller_checks_flags, pre_hit);
+    g->la.armed = false;                          // an announcement is for the call it was made before, whatever became of it
+    if (rc != MI_OK) return rc;
     if (async && g->async_tail == 3) {
       // deferred: a schedule without the single filtered launch (chunked, f32-scored) has not picked the previous tail up
       if (g->pending.valid && (rc = flush_pending_tail(g, s, false)) != MI_OK) return rc;
@@ -683,6 +865,7 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
         g->pending.b = b;
         g->pending.k = k;
         g->pending.set = set;
+        g->pending.slot = g->ws_slot;
         g->pending.out_idx = out_idx + q0 * k;
         g->pending.out_score = out_score ? out_score + q0 * k : nullptr;
         g->pending.out_score64 = out_score64 ? out_score64 + q0 * k : nullptr;
@@ -749,6 +932,12 @@ int mi_gallery_destroy(mi_gallery* g) {
   }
   if (g->ev_pre) (void)hipEventDestroy(g->ev_pre);
   if (g->tail_stream) (void)hipStreamDestroy(g->tail_stream);
+  if (g->pre_stream) {
+    (void)hipStreamSynchronize(g->pre_stream);
+    (void)hipStreamDestroy(g->pre_stream);
+    (void)hipEventDestroy(g->ev_scored);
+    (void)hipEventDestroy(g->ev_ready);
+  }
   ws_free(g->ws);
   ws_free(g->ws_alt);
   for (auto& e : g->ev_pool) {
@@ -1268,7 +1457,20 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   HIPC(hipSetDevice(g->device));
   return search_device(g, q_dev, MI_F32, g->d, 1, g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode, nq, k,
                        out_idx_dev, out_score_dev, out_score64_dev, g->force_exact != 0, (hipStream_t)stream,
-                       /*allow_async=*/true);
+                       /*allow_async=*/true, /*caller_checks_flags=*/false, /*device_api=*/true);
+}
+
+int mi_knn_set_lookahead(mi_gallery* g, const float* q_next_dev, int64_t nq_next) {
+  REQUIRE(g, "null handle");
+  REQUIRE(q_next_dev == nullptr || (nq_next >= 1 && nq_next <= QB), "lookahead: one batch of at most 1024 queries");
+  g->la.armed = q_next_dev != nullptr;
+  g->la.q = q_next_dev;
+  g->la.nq = (int32_t)nq_next;
+  g->la.dtype = MI_F32;
+  g->la.rs = g->d;
+  g->la.cs = 1;
+  g->la.norm = g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode;
+  return MI_OK;
 }
 
 int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream) {
@@ -1289,7 +1491,7 @@ int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream) {
     if ((rc = phase1_batch(g, g->gal_f32, MI_F32, g->dp, 1, MI_NORM_NONE, nq, k, false, (hipStream_t)stream)) != MI_OK) return rc;
   // the answers are discarded, and so is whatever these launches flagged (a gallery that starts with duplicate rows can
   // overflow their candidate lists): sticky flags raised from here on belong to real searches again
-  HIPC(hipMemsetAsync(g->ws.flags, 0, 8, (hipStream_t)stream));
+  HIPC(hipMemsetAsync(g->ws.flags, 0, 4, (hipStream_t)stream));
   return MI_OK;
 }
 
@@ -1305,6 +1507,7 @@ int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   REQUIRE(nq >= 1 && nq <= QB, "phase API handles one batch of at most 1024 queries");
   HIPC(hipSetDevice(g->device));
   REQUIRE(k >= 1, "k must be >= 1");
+  g->la.armed = g->la.prepared = false;          // the phase API manages the workspace slots itself
   // a shard may hold fewer than k rows: clamp the local k, pad the tail with -inf
   const int32_t kl = (int32_t)std::min<int64_t>(k, g->n);
   int rc = check_k(g, kl);
@@ -2146,6 +2349,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "ladder") *out_value = g->ladder;
   else if (n == "boot_ksplit") *out_value = g->boot_ksplit;
   else if (n == "stream_tail") *out_value = g->stream_tail;
+  else if (n == "stream_lookahead") *out_value = g->stream_lookahead;
   else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
@@ -2167,6 +2371,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "spec_max_ratio") { REQUIRE(value >= 1 && value <= 4096, "spec_max_ratio in [1, 4096]"); g->spec_max_ratio = (int)value; }
   else if (n == "workspace_slot") {
     REQUIRE(value == 0 || value == 1, "workspace_slot: 0 or 1");
+    g->la.armed = g->la.prepared = false;
     if ((int)value != g->ws_slot) {
       std::swap(g->ws, g->ws_alt);
       g->ws_slot = (int)value;
@@ -2194,6 +2399,7 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "ladder") g->ladder = value != 0;
   else if (n == "boot_ksplit") g->boot_ksplit = value != 0;
   else if (n == "stream_tail") g->stream_tail = value != 0;
+  else if (n == "stream_lookahead") g->stream_lookahead = value != 0;
   else if (n == "async_tail") {
     REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
     g->async_tail = (int)value;

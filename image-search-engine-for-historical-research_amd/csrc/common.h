@@ -101,7 +101,9 @@ struct QueryState {       // all arrays sized for qpad queries
   float* margin;          // 2 * eps_q  (rigorous |approx - exact| bound, both sides)
   uint32_t* cnt;          // survivors appended: counter of query q at cnt[q * CNT_STRIDE]
   uint64_t* surv;         // [qpad][cap]
-  uint32_t* flags;        // [0] sticky error flags, [1] 'repair needed' word of the current batch (speculative threshold)
+  uint32_t* flags;        // [0] sticky error flags (one word for both workspaces of a handle)
+  uint32_t* repair;       // 'repair needed' word of the CURRENT batch (speculative threshold failed for some query): per
+                          // workspace, since the pre part of the next batch may run beside this batch's maintain launch
   float* thr2;            // fallback (looser) speculative threshold per query
   uint32_t* qflag;        // per query: 1 = its speculative threshold failed verification, repair it
   // in-launch threshold ladder (tile kernel, single-launch schedule; DESIGN.md "Thresholds while streaming" (iii)):

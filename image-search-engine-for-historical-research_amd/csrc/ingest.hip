@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
     // ---- per-query search state (select.hip init_query_state_kernel, same arithmetic)
     const QueryState& st = qi.st;
     const int q = (int)row;
-    if (q == 0) st.flags[1] = 0;          // flags[0] is sticky across batches (read and cleared by the host)
+    if (q == 0) *st.repair = 0;           // (st.flags is sticky across batches: read and cleared by the host)
     if (q < qi.nq) {
       const float g_f32 = qi.gstat3[0], g_bf = qi.gstat3[1], g_diff = qi.gstat3[2];
       float eps;

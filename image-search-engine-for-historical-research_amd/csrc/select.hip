@@ -138,7 +138,7 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
                                         int32_t nq, int32_t qpad, float gamma, int use_img_terms,
                                         uint32_t first_cnt, QueryState st) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q == 0) st.flags[1] = 0;          // flags[0] is sticky across batches (read and cleared by the host)
+  if (q == 0) *st.repair = 0;           // (st.flags is sticky across batches: read and cleared by the host)
   if (q >= qpad) return;
   if (q < nq) {
     const RowStat r = qstat[q];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
         st.thr[q] = thr_new;                       // = thr2: the repair pass re-scans every tile for this query
         st.cnt[q * CNT_STRIDE] = 0;
         st.qflag[q] = 1;
-        atomicOr(&st.flags[1], 1u);
+        atomicOr(st.repair, 1u);
       } else {
         if (failed) atomicOr(st.flags, FLAG_SPEC_FAIL);
         st.thr[q] = INFINITY;                      // verified: invisible to a repair pass

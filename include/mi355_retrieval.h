@@ -108,6 +108,19 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
  * its scoring launch (or by mi_search_join, or by any call that cannot carry it on): the re-score gather then shares the
  * device with the power-bound scoring launch only.  The output buffers of a call must stay valid until the join. */
 int mi_search_join(mi_gallery* g, void* stream);
+/* Lookahead for streams of mi_knn_search_device calls (round 4).  Everything a batch does BEFORE its scoring launch -- query
+ * ingest, the bootstrap launch on the threshold sample, the thresholds -- depends on its queries only, and so does not have to
+ * wait for the previous batch's scatter / maintain (/ re-score) launches; both are chains of small latency-bound launches
+ * that leave most of the chip idle.  mi_knn_set_lookahead(handle, q_next, nq_next) announces the batch of the NEXT
+ * mi_knn_search_device call (device rows [nq_next][d] f32, valid on the stream of the search call that follows, nq_next <= 1024,
+ * same k): that search call enqueues the announced batch's pre part on the handle's own stream right behind its scoring
+ * launch, in the handle's second workspace, and the next search call -- same pointer, count and k -- goes straight to its scoring
+ * launch.  One-shot; a next call that does not match simply does its own pre part.  Answers are unchanged, bit for bit.
+ * A host call with more than 1024 queries does this between its internal batches with option "stream_lookahead".  q_next = NULL
+ * withdraws.  Measured on MI355X (profiles/r04e_lookahead_*): the overlap happens and buys nothing -- the empty repair launch
+ * of the current batch needs a whole CU's LDS and waits for the announced batch's bootstrap launch, and the waits between
+ * hardware queues cost what the overlap saves; bench.py uses it only with --lookahead. */
+int mi_knn_set_lookahead(mi_gallery* g, const float* q_next_dev, int64_t nq_next);
 
 /* Sharded search = phase 1 on every shard, all-gather of approx top-k values, phase 2, all-gather of
  * exact (score64, idx), merge.  New functionality (the reference is single-process).
@@ -298,7 +311,8 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
  * those adds is not fixed, so the sample scores -- and with them the survivor / candidate statistics and which queries need a
  * repair -- may differ by an ulp from run to run; the answers do not: the threshold is speculative and verified), "xcc_balance" (XCD shares by measured
  * speed), "stream_tail" (default 1: a HOST entry point called with more than 1024 queries runs its internal batches with the
- * deferred tail of "async_tail" 3 and reads the sticky flags once at the end; 0 = one verified batch after the other), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
+ * deferred tail of "async_tail" 3 and reads the sticky flags once at the end; 0 = one verified batch after the other),
+ * "stream_lookahead" (default 0: such a call also announces every internal batch to its predecessor, see mi_knn_set_lookahead), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),

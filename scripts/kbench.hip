@@ -133,6 +133,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&st.cnt, (size_t)qpad * CNT_STRIDE * 4));
   CK(hipMalloc((void**)&st.flags, 16));
   CK(hipMemset(st.flags, 0, 16));
+  st.repair = st.flags + 1;
   CK(hipMemset(st.cnt, 0, (size_t)qpad * CNT_STRIDE * 4));
   st.cap = 12288;
   st.surv = nullptr;                                     // only the FIRST (bootstrap) variant writes survivors directly

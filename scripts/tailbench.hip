@@ -151,6 +151,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&st.surv, (size_t)nq * cap * 8));
   CK(hipMalloc((void**)&st.flags, 16));
   CK(hipMemset(st.flags, 0, 16));
+  st.repair = st.flags + 1;
   CK(hipMemset(st.qflag, 0, nq * 4));
   CK(hipMemset(st.lad_cnt, 0, nq * 4));
   st.cap = cap;

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
+from isehr_amd.synth import synth_rows
 
 pytestmark = pytest.mark.gpu
 TAU = 1e-6          # cosine scale; stored rows are f32 (|ds| <= 2.4e-7), DESIGN.md "Parity definition"
@@ -227,3 +228,167 @@ def test_sample_sizes_2048_4096_8192(tiles):
     assert st["survivors"] / st["queries"] < 2500            # one filtered launch with a useful threshold
     assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
     assert oracle.check_topk_parity(i1, oracle.exact_scores_f64(g, q), k, TAU) == []
+
+
+def test_multi_batch_host_search_streams_with_the_deferred_tail_and_falls_back_on_a_flag():
+    """Round 4: a host call with more than 1024 queries (the N x N callers, src/utils/Reranking.py:314-432) runs its internal
+    batches as a stream with the deferred tail and reads the sticky flags once at the end (option "stream_tail", default on).
+    Same answers bit for bit as one verified batch after the other; and a batch that overflows (3000 exact duplicates of one
+    query's best row with the default caps) sends the call through the verified loop, which answers it through the fallbacks."""
+    from isehr_amd._lib import Gallery
+    n, d, nq, k = 150000, 256, 2500, 100
+    g = synth_rows(401, 0, n, d)
+    q = synth_rows(402, 0, nq, d)
+    G = Gallery.from_host(g)
+    try:
+        assert G.get_option("stream_tail") == 1
+        idx1, sc1, _ = G.search(q, k)
+        st = G.status(reset=True)
+        assert st["overflow_batches"] == 0 and st["spec_retries"] == 0 and st["queries"] == nq
+        G.set_option("stream_lookahead", 1)              # + every internal batch announced to its predecessor
+        idx3, sc3, _ = G.search(q, k)
+        assert np.array_equal(idx3, idx1) and np.array_equal(sc3, sc1) and G.status()["overflow_batches"] == 0
+        G.set_option("stream_lookahead", 0)
+        G.set_option("stream_tail", 0)
+        idx0, sc0, _ = G.search(q, k)
+        assert np.array_equal(idx0, idx1) and np.array_equal(sc0, sc1)
+        s = oracle.exact_scores_f64(g, q[:64])
+        assert oracle.check_topk_parity(idx1[:64], s, k, 1e-6) == []
+    finally:
+        G.close()
+    g[5000:8000] = g[77]                                    # 3000 exact copies: the candidate lists of query 1500 overflow
+    q[1500] = g[77]
+    G = Gallery.from_host(g)
+    try:
+        idx2, sc2, _ = G.search(q, k)
+        st = G.status()
+        assert st["overflow_batches"] >= 1                  # the stream raised the flag; the verified loop answered
+        assert set(idx2[1500]) <= set(range(5000, 8000)) | {77} and np.abs(sc2[1500] - 1.0).max() < 1e-6
+        assert list(idx2[1500]) == sorted(idx2[1500])       # ties to the lower index
+        s = oracle.exact_scores_f64(g, q[1400:1410])
+        assert oracle.check_topk_parity(idx2[1400:1410], s, k, 1e-6) == []
+    finally:
+        G.close()
+
+
+def test_calibrate_converges_the_xcd_shares_and_changes_no_answer():
+    """mi_gallery_calibrate: scoring launches of the gallery's own first rows against the whole gallery, answers discarded,
+    sticky flags cleared; a no-op below 512 gallery tiles.  The search after it equals the search before it."""
+    import torch
+    from isehr_amd import _lib
+    n, d, nq, k = 140000, 128, 300, 50                      # 547 tiles: the weighted split is live
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), 411, 0, n, d, s)
+    raw[1:400] = raw[0]                                     # duplicate rows at the start: the calibration's own queries tie massively
+    q = torch.from_numpy(synth_rows(412, 0, nq, d)).to(dev)
+    torch.cuda.synchronize()
+    G = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+    try:
+        idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        G.search_device(q.data_ptr(), nq, k, idx.data_ptr(), sc.data_ptr(), None, s)
+        torch.cuda.synchronize()
+        ref = (idx.cpu().numpy().copy(), sc.cpu().numpy().copy())
+        assert G.flags() == 0
+        G.calibrate(6, s)
+        torch.cuda.synchronize()
+        assert G.flags() == 0                               # whatever the calibration launches flagged is gone
+        G.status(reset=True)
+        G.profile(True)
+        G.search_device(q.data_ptr(), nq, k, idx.data_ptr(), sc.data_ptr(), None, s)
+        torch.cuda.synchronize()
+        ms = G.launch_ms()
+        st = G.status()
+        assert len(ms) == st["gemm_launches"] >= 1 and abs(float(ms.sum()) - st["gemm_ms"]) < 1e-3
+        assert np.array_equal(idx.cpu().numpy(), ref[0]) and np.array_equal(sc.cpu().numpy(), ref[1])
+    finally:
+        G.close()
+    small = _lib.Gallery.from_host(synth_rows(413, 0, 3000, 64))
+    try:
+        small.calibrate(8)                                  # 12 tiles: nothing to measure, nothing launched
+        assert small.status()["searches"] == 0
+    finally:
+        small.close()
+
+
+@pytest.mark.parametrize("async_tail", [0, 3])
+def test_lookahead_gives_the_same_answers(async_tail):
+    """mi_knn_set_lookahead: the pre part (query ingest, bootstrap on the sample, thresholds) of the announced next batch runs
+    in the handle's second workspace on its own stream, beside the current batch's scatter / maintain launches.  Batches of
+    mixed sizes (tile kernel and streaming kernel), with the synchronous and the deferred tail: every answer equals the
+    one-call-at-a-time answer bit for bit -- also when the announcement was wrong (other queries, other count, other k), was
+    withdrawn, or was followed by an entry point that manages the workspaces itself."""
+    import torch
+    from isehr_amd import _lib
+    n, d, k = 300000, 256, 100
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), 421, 0, n, d, s)
+    sizes = [1024, 1024, 700, 1024, 130, 1024, 64, 1024, 1024]
+    qs = []
+    for i, m in enumerate(sizes):
+        t = torch.empty((m, d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(t.data_ptr(), 430 + i, 0, m, d, s)
+        qs.append(t)
+    torch.cuda.synchronize()
+    G = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
+    try:
+        def outs(kk=k):
+            return [(torch.empty((m, kk), dtype=torch.int64, device=dev), torch.empty((m, kk), dtype=torch.float32, device=dev))
+                    for m in sizes]
+        ref = outs()
+        for q, (oi, os_) in zip(qs, ref):
+            G.search_device(q.data_ptr(), q.shape[0], k, oi.data_ptr(), os_.data_ptr(), None, s)
+            torch.cuda.synchronize()
+        assert G.flags() == 0
+        G.set_option("async_tail", async_tail)
+        # 1. every batch announced correctly
+        got = outs()
+        for i, (q, (oi, os_)) in enumerate(zip(qs, got)):
+            if i + 1 < len(qs):
+                G.set_lookahead(qs[i + 1].data_ptr(), qs[i + 1].shape[0])
+            G.search_device(q.data_ptr(), q.shape[0], k, oi.data_ptr(), os_.data_ptr(), None, s)
+        G.join(s)
+        torch.cuda.synchronize()
+        assert G.flags() == 0
+        for (ri, rs), (gi, gs) in zip(ref, got):
+            assert torch.equal(ri, gi) and torch.equal(rs, gs)
+        # 2. wrong, withdrawn and stale announcements; a phase-API call in between
+        got = outs()
+        approx = torch.empty((1024, k), dtype=torch.float32, device=dev)
+        for i, (q, (oi, os_)) in enumerate(zip(qs, got)):
+            if i == 0:
+                G.set_lookahead(qs[3].data_ptr(), qs[3].shape[0])          # batch 1 comes next, not batch 3
+            elif i == 1:
+                G.set_lookahead(qs[2].data_ptr(), 512)                      # right pointer, wrong count
+            elif i == 2:
+                G.set_lookahead(qs[3].data_ptr(), qs[3].shape[0])
+                G.set_lookahead(None, 0)                                    # withdrawn
+            elif i == 3:
+                G.set_lookahead(qs[4].data_ptr(), qs[4].shape[0])          # correct ...
+            elif i == 5:
+                G.set_lookahead(qs[6].data_ptr(), qs[6].shape[0])
+            G.search_device(q.data_ptr(), q.shape[0], k, oi.data_ptr(), os_.data_ptr(), None, s)
+            if i == 5:                                                      # ... but the phase API runs before batch 6
+                G.join(s)
+                G.phase1_device(qs[0].data_ptr(), 1024, k, approx.data_ptr(), s)
+        G.join(s)
+        torch.cuda.synchronize()
+        for (ri, rs), (gi, gs) in zip(ref, got):
+            assert torch.equal(ri, gi) and torch.equal(rs, gs)
+        # 3. an announcement made for another k
+        k2 = 37
+        oi2 = torch.empty((1024, k2), dtype=torch.int64, device=dev)
+        os2 = torch.empty((1024, k2), dtype=torch.float32, device=dev)
+        G.set_lookahead(qs[1].data_ptr(), 1024)
+        G.search_device(qs[0].data_ptr(), 1024, k, got[0][0].data_ptr(), got[0][1].data_ptr(), None, s)
+        G.search_device(qs[1].data_ptr(), 1024, k2, oi2.data_ptr(), os2.data_ptr(), None, s)
+        G.join(s)
+        torch.cuda.synchronize()
+        assert torch.equal(oi2, ref[1][0][:, :k2]) and torch.equal(os2, ref[1][1][:, :k2]) and G.flags() == 0
+    finally:
+        G.set_option("async_tail", 0)
+        G.close()
