@@ -264,11 +264,19 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     # ---- layout of the job: gq query groups x gs row shards (gq * gs = world).  Every batch is split into gq slices of
     # queries; the gs ranks of a group shard the gallery rows among themselves and run the two-phase protocol inside the
     # group.  Groups never exchange anything: a query's answer lives with the group that computed it.
+    # layout "replicas": every rank holds the WHOLE gallery (288 GB of HBM per GPU: both BASELINE galleries fit one GPU) and the
+    # job's steps are dealt to the ranks -- rank r answers batches r, r + N, ... with the one-GPU pipeline, nothing is exchanged
+    replicas = layout == "replicas" and world > 1
+    job_steps = steps
     try:
-        gq, gs, qgroup, shard = job_layout(world, rank, nq_job, layout)
+        gq, gs, qgroup, shard = (1, 1, 0, 0) if replicas else job_layout(world, rank, nq_job, layout)
     except ValueError as e:
         raise SystemExit(str(e))
-    group = layout_groups(gq, gs)[qgroup] if world > 1 else None
+    if replicas:
+        group = layout_groups(world, 1)[rank]      # one-rank groups: no collective anywhere on the search path
+        steps = steps // world + (1 if rank < steps % world else 0)
+    else:
+        group = layout_groups(gq, gs)[qgroup] if world > 1 else None
     nq = nq_job // gq                             # queries THIS rank answers per step
     q_lo = qgroup * nq
     lo, hi = shard_bounds(n_total, gs, shard)
@@ -327,7 +335,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     # single GPU: the exact re-score + sort of a batch runs on the handle's second stream beside the scoring launch of the
     # next batch (mi_set_option "async_tail"); every batch's results are complete after gal.join(), inside the timed region
-    pipelined = world == 1 and async_tail > 0
+    pipelined = (world == 1 or replicas) and async_tail > 0
     if pipelined:
         gal.set_option("async_tail", async_tail)
     last = {}
@@ -373,14 +381,13 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
         barrier sits between the warm-up and the timed steps: the statistics are reset BEFORE the warm-up (they then cover
         it too: only ratios are read from them) and the launch timing is a host-side switch."""
         gal.status(reset=True)
-        if warm:
-            fn(warm)
+        out_w = fn(warm) if warm else None
         if pipelined:
             gal.join(stream)
         job.barrier()
         gal.profile(profile_it)
         t0_ = time.perf_counter()
-        out_ = fn(count)
+        out_ = fn(count) if count else out_w          # (a replica rank may have no step of a very short job)
         if pipelined:
             gal.join(stream)
         job.barrier()
@@ -421,7 +428,8 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
                 last["q"] = qb
             return out_
 
-    (idx, sc), elapsed, st, launch_ms = timed_region(run_steps, steps, warmup, profile_it=not graph)
+    (idx, sc), elapsed, st, launch_ms = timed_region(run_steps, steps, max(1, warmup) if replicas else warmup,
+                                                     profile_it=not graph)
     if world > 1:
         ov = torch.tensor([st["overflow_batches"] + st["spec_retries"]], dtype=torch.int64, device=dev)
         dist.all_reduce(ov, op=dist.ReduceOp.SUM)
@@ -478,6 +486,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
                           % (len(picks), hi - lo, k)
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
+               job_steps=job_steps,
                ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, worst=worst,
                use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check, lookahead=lookahead,
                protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
@@ -757,6 +766,19 @@ def main():
                 "ms_per_step": r1["elapsed"] / r1["steps"] * 1e3, "scoring_frac_of_mfma_peak": rf["frac"],
                 "scoring_share_of_step": rf["kernel_share_of_step"], "pipelined_collectives": r1.get("stream"),
                 "protocol_phases_ms_max_over_ranks": r1.get("phases"), "score_check": r1["dense_check"]}
+
+    if world > 1 and plain and (args.multi_gpu_blocks == "on" or (args.multi_gpu_blocks == "auto" and default_shape)):
+        # and the layout a deployment would pick for a gallery that fits one GPU (12 GB of 288): every rank holds ALL rows and
+        # the job's batches are dealt to the ranks, each answered by the one-GPU pipeline (deferred tail), nothing exchanged
+        rr = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, "replicas", check=True,
+                          keep=False, async_tail=3 if args.queries > 128 else 0)
+        if rank == 0:
+            out["batch_replicas"] = {
+                "parallelism": "%d replicas of the whole gallery; batch i of the job is answered by rank i mod %d with the "
+                               "one-GPU pipeline; no collective on the search path" % (world, world),
+                "value": args.queries * rr["job_steps"] / rr["elapsed"], "unit": "queries/s", "steps": rr["job_steps"],
+                "steps_of_rank_0": rr["steps"], "ms_per_step": rr["elapsed"] / rr["job_steps"] * 1e3,
+                "score_check": rr["dense_check"]}
 
     if scale_10m:
         # BASELINE configs[3]: 10 M x 2048 rows, bf16 image, 1024-query batches, row-sharded over the job's ranks

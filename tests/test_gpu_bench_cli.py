@@ -107,3 +107,5 @@ def test_bare_gpus_2_line_answers_layout_overlap_and_collective_cost():
         assert ph["total"] >= ph["phase1"] > 0 and ph["allgather1"] >= 0 and ph["allgather2"] >= 0
         assert "mi_knn_dense64_search" in blk["score_check"]
     assert out["row_shard_1xN"]["parallelism"].startswith("row-shard x2")
+    br = out["batch_replicas"]                                         # whole-gallery replicas, the batches dealt to the ranks
+    assert br["value"] > 0 and br["steps"] == 3 and br["steps_of_rank_0"] == 2 and "mi_knn_dense64_search" in br["score_check"]
