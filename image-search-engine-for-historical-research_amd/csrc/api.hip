@@ -1484,7 +1484,12 @@ int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream) {
   int rc = check_k(g, k);
   if (rc != MI_OK) return rc;
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
+  // the calibration launches reuse the query buffers of the searches before them: an asynchronous tail (deferred or already
+  // running on the handle's own stream) must be done with them first
   if (g->pending.valid && (rc = flush_pending_tail(g, (hipStream_t)stream, false)) != MI_OK) return rc;
+  for (int i = 0; i < 2; ++i)
+    if (g->ev_tail_valid[i]) HIPC(hipStreamWaitEvent((hipStream_t)stream, g->ev_tail[i], 0));
+  g->la.armed = g->la.prepared = false;
   // queries = the first stored rows of the gallery itself (resident, already in the gallery's own normalisation): what the
   // launches score is irrelevant, every workgroup's loop time is what block 0 of the scatter kernel turns into shares
   for (int32_t i = 0; i < launches; ++i)

@@ -190,3 +190,37 @@ def test_full_size_answers_equal_the_dense_float64_search(big):
     didx16, dsc16, _, _ = g.dense64_search(qh[:16], K)
     idx16, sc16 = _search(g, q, 16)                                   # streaming kernel
     assert np.array_equal(idx16, didx16) and np.abs(sc16 - dsc16).max() <= 6e-8
+
+
+def test_full_size_every_mode_gives_the_same_answers(big):
+    """The benchmarked gallery through every mode a stream of batches can run in -- synchronous tail / deferred tail, with and
+    without the next batch announced (mi_knn_set_lookahead), after a calibration, batches of 1024 / 700 / 129 queries in one
+    stream -- against the plain one-call-at-a-time answers, bit for bit."""
+    import torch
+    g, _, _, q = big
+    dev, s = q.device, torch.cuda.current_stream().cuda_stream
+    batches = [q[:1024], q[100:800], q[200:329], q[:1024], q[300:1000]]
+    ref = []
+    for b in batches:
+        i_, s_ = _search(g, b.contiguous(), b.shape[0])
+        ref.append((i_, s_))
+    qs = [b.contiguous() for b in batches]
+    g.calibrate(4, s)
+    for tail in (0, 3):
+        for announce in (False, True):
+            g.set_option("async_tail", tail)
+            try:
+                outs = [(torch.empty((b.shape[0], K), dtype=torch.int64, device=dev),
+                         torch.empty((b.shape[0], K), dtype=torch.float32, device=dev)) for b in qs]
+                for rep in range(2):
+                    for j, (b, (oi, os_)) in enumerate(zip(qs, outs)):
+                        if announce and j + 1 < len(qs):
+                            g.set_lookahead(qs[j + 1].data_ptr(), qs[j + 1].shape[0])
+                        g.search_device(b.data_ptr(), b.shape[0], K, oi.data_ptr(), os_.data_ptr(), None, s)
+                g.join(s)
+                torch.cuda.synchronize()
+                assert g.flags() == 0
+                for (ri, rs), (oi, os_) in zip(ref, outs):
+                    assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(os_.cpu().numpy(), rs), (tail, announce)
+            finally:
+                g.set_option("async_tail", 0)

@@ -75,15 +75,26 @@ def test_tile_kernel_structures_agree(lib):
     g = lib.Gallery.from_device_ptr(raw.data_ptr(), n, 320)
     try:
         res = {}
-        for v in (0, 1, 2):
+        # 1, 2, 4: structure 1 / other MFMA issue orders; 5-7: zero-C and decide-in-the-last-slice (round 3); 10-18: cache
+        # policies of the DMA pieces, alone and with zero-C; 20, 21: the paired-XCD walk (round 4)
+        variants = (1, 2, 4, 5, 6, 7, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21)
+        for v in (0,) + variants:
             g.set_option("kernel_variant", v)
             g.status(reset=True)
             res[v] = _search(g, q, 50) + (g.status()["candidates"],)
-        for v in (1, 2):
-            assert np.array_equal(res[0][0], res[v][0]) and np.array_equal(res[0][1], res[v][1])
-            assert res[0][2] == res[v][2]
+        for v in variants:
+            assert np.array_equal(res[0][0], res[v][0]) and np.array_equal(res[0][1], res[v][1]), v
+            assert res[0][2] == res[v][2], v
         s = oracle.exact_scores_f64(raw.cpu().numpy(), q.cpu().numpy())
         assert oracle.check_topk_parity(res[0][0], s, 50, TAU) == []
+        # four query tiles (the paired walk needs an even number: labels 2y / 2y + 1 take two of them each)
+        q4 = _device_rows(lib, 43, 1024, 320)
+        res4 = {}
+        for v in (0, 10, 20, 21):
+            g.set_option("kernel_variant", v)
+            res4[v] = _search(g, q4, 50)
+        for v in (10, 20, 21):
+            assert np.array_equal(res4[0][0], res4[v][0]) and np.array_equal(res4[0][1], res4[v][1]), v
     finally:
         g.close()
 
