@@ -76,9 +76,10 @@ def parse():
                          "launches.  Built and measured in round 4: no gain (the empty repair launch of the previous batch "
                          "needs a whole CU's LDS and waits for the bootstrap; cross-queue waits cost what the overlap "
                          "saves) -- an option, off by default")
-    ap.add_argument("--calibrate", type=int, default=8,
-                    help="scoring launches of mi_gallery_calibrate after the ingest (XCD shares converge before the first "
-                         "search; 0 = off)")
+    ap.add_argument("--calibrate", type=int, default=16,
+                    help="scoring launches of mi_gallery_calibrate after the ingest (the XCD shares converge within ~4; the rest "
+                         "carries the chip through the 15-20 slow launches that follow the light-load ingest phase, "
+                         "scripts/gap_probe.py; 0 = off)")
     ap.add_argument("--force-protocol", action="store_true",
                     help="one GPU: run the sharded two-phase protocol with its RCCL collectives on a group of ONE rank "
                          "(what a rank of a multi-GPU run executes, collectives included); diagnostic, not the headline")
@@ -523,8 +524,8 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 def synchronous_block(job, gal, args, steps):
     """One GPU, same gallery, behind a headline measured in the deferred-tail mode: the SAME number of steps with the tail on
     the caller's stream.  The scoring launch then runs undisturbed, which is the launch `roofline` is quoted on, and the
-    record shows both modes of the same box.  A dozen untimed steps first: the result checks of the headline left the device
-    idle for seconds, and the first ~10 launches after an idle gap run slow (power management, scripts/gap_probe.py)."""
+    record shows both modes of the same box.  Twenty untimed steps first: the result checks of the headline left the device
+    idle for seconds, and the first 10-20 launches after an idle gap run slow (power management, scripts/gap_probe.py)."""
     import torch
     from isehr_amd import _lib
     from isehr_amd.sharded import ShardedGallery
@@ -541,7 +542,7 @@ def synchronous_block(job, gal, args, steps):
     gal.status(reset=True)
     out_ = None
     la = args.lookahead
-    for i in range(12):
+    for i in range(20):
         out_ = sg.search(pool[i % 4], k, next_q=pool[(i + 1) % 4] if la else None)
     torch.cuda.synchronize()
     gal.profile(True)
@@ -557,37 +558,50 @@ def synchronous_block(job, gal, args, steps):
     return dict(st=st, nq=nq, elapsed=elapsed, steps=steps, launch_ms=lms, equals_pipelined_answer=same)
 
 
-def map_block(args, device, with_oracle):
+MAP_DATASETS = (("roxford5k-sized (configs[0])", 4993), ("roxford5k+rparis6k-sized (configs[1])", 4993 + 6322))
+
+
+def _planted(args, n):
+    from isehr_amd.synth import planted_dataset
+    # noise bands chosen so that the hard positives (cosine ~0.10) sit where the best distractors of a 5 k .. 11 k gallery do
+    # (~0.08) and the junk band below them: mAP is then a non-trivial number that moves when a single rank moves
+    return planted_dataset(args.seed, n, args.dim, 70, n_pos=(20, 60), sigmas=(2.0, 10.0, 16.0))
+
+
+def map_block(args, device):
     """BASELINE.json's metric is queries/sec AND mAP: rOxford5k / +rParis6k-sized planted datasets (70 queries,
     clusters of positives labelled easy / hard / junk by their noise band; configs[0] and configs[1] sizes), ranked to K = 100
     by the HIP matcher exactly as src/test_rOP1m.py:155-159 does it (`matching_L2(K, vecs.T, qvecs.T)`, `ranks = idx.T`,
-    compute_map_and_print) and, beside it, by the CPU restatement of the reference's matching_L2 (the oracle: checker only).
-    mAP (E, M, H) of the two must agree to 1e-6; the reference-style time per query of both is in the record."""
-    import numpy as np
+    compute_map_and_print).  The CPU restatement's mAP and time per query of the same datasets are added by the cpu_baseline
+    leg (cpu_baseline_map), which also asserts that the two agree to 1e-6."""
     from isehr_amd import evaluate
     from isehr_amd.nnsearch import matching_HIP
-    from isehr_amd.synth import planted_dataset
     out = []
-    for name, n in (("roxford5k-sized (configs[0])", 4993), ("roxford5k+rparis6k-sized (configs[1])", 4993 + 6322)):
-        # noise bands chosen so that the hard positives (cosine ~0.10) sit where the best distractors of a 5 k .. 11 k gallery do
-        # (~0.08) and the junk band below them: mAP is then a non-trivial number that moves when a single rank moves
-        vecs, qv, gnd = planted_dataset(args.seed, n, args.dim, 70, n_pos=(20, 60), sigmas=(2.0, 10.0, 16.0))
+    for name, n in MAP_DATASETS:
+        vecs, qv, gnd = _planted(args, n)
         matching_HIP(args.topk, vecs.T, qv.T, device=device)                        # warm (library, allocator)
         idx, tpq = matching_HIP(args.topk, vecs.T, qv.T, device=device)            # stateless call: ingest inside its timer
         m = evaluate.compute_map_revisited(idx.T, gnd)
-        rec = {"dataset": name, "gallery_rows": n, "queries": 70, "topk": args.topk,
-               "map": {"E": m[0], "M": m[1], "H": m[2]}, "time_per_query_s": tpq}
-        if with_oracle:
-            import oracle
-            t0 = time.time()
-            ref = oracle.matching_l2(args.topk, vecs.T, qv.T)
-            rec["time_per_query_oracle_s"] = (time.time() - t0) / 70
-            mo = oracle.compute_map_revisited(ref.T, gnd)
-            rec["map_oracle"] = {"E": mo[0], "M": mo[1], "H": mo[2]}
-            rec["max_abs_map_difference"] = float(max(abs(a - b) for a, b in zip(m, mo)))
-            assert rec["max_abs_map_difference"] <= 1e-6, "mAP of the HIP ranks differs from the oracle's: %r" % rec
-        out.append(rec)
+        out.append({"dataset": name, "gallery_rows": n, "queries": 70, "topk": args.topk,
+                    "map": {"E": m[0], "M": m[1], "H": m[2]}, "time_per_query_s": tpq})
     return out
+
+
+def cpu_baseline_map(args, recs):
+    """cpu_baseline leg, second half: the oracle's matching_l2 (the reference's numpy path, timer over normalisation + ranking
+    like src/utils/nnsearch.py:688-705) on the planted datasets of map_block, its mAP by the oracle's evaluator, and the
+    assertion that the HIP ranks' mAP equals it to 1e-6.  The oracle is the checker here, nothing else."""
+    import oracle
+    for rec, (_, n) in zip(recs, MAP_DATASETS):
+        vecs, qv, gnd = _planted(args, n)
+        t0 = time.time()
+        ref = oracle.matching_l2(args.topk, vecs.T, qv.T)
+        rec["time_per_query_oracle_s"] = (time.time() - t0) / 70
+        mo = oracle.compute_map_revisited(ref.T, gnd)
+        rec["map_oracle"] = {"E": mo[0], "M": mo[1], "H": mo[2]}
+        m = (rec["map"]["E"], rec["map"]["M"], rec["map"]["H"])
+        rec["max_abs_map_difference"] = float(max(abs(a - b) for a, b in zip(m, mo)))
+        assert rec["max_abs_map_difference"] <= 1e-6, "mAP of the HIP ranks differs from the oracle's: %r" % rec
 
 
 def roofline_of(res, args, world, with_traffic):
@@ -810,7 +824,9 @@ def main():
     if rank == 0 and default_shape and plain and not args.diagnostic:
         # the metric's other half: mAP (E / M / H) on planted rOxford5k- / +rParis6k-sized datasets, HIP ranks vs the oracle's
         try:
-            out["map"] = map_block(args, job.dev_index, with_oracle=not args.no_cpu_baseline)
+            out["map"] = map_block(args, job.dev_index)
+            if world == 1 and not args.no_cpu_baseline:
+                cpu_baseline_map(args, out["map"])
         except (RuntimeError, MemoryError) as e:
             out["map"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
