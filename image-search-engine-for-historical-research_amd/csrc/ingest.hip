@@ -17,6 +17,11 @@
 #ifndef MI_INGEST_PROBE
 #define MI_INGEST_PROBE 0      // scripts/ingestbench.hip: 1 = no rounding statistics, 2 = no f32 row store, 4 = no image store
 #endif
+// consecutive rows one workgroup of the persistent gallery ingest takes per turn (scripts/ingestbench.hip sweeps it)
+#ifndef MI_INGEST_RUN
+#define MI_INGEST_RUN 4
+#endif
+
 namespace mi {
 
 // 16-bit image element: fp16 (11-bit significand: 8x smaller rounding error, same MFMA rate) or bf16 (f32 range)
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
   // rows of a workgroup come in runs of RUN consecutive rows (run i of workgroup b starts at (i * gridDim.x + b) * RUN): one
   // row's piece of a slice block of the image is 64 bytes, and consecutive rows of a tile are neighbours in it, so a run
   // written by ONE workgroup fills whole 256-byte stretches in ONE XCD's L2 instead of leaving half lines in eight of them
-  constexpr int64_t RUN = INIT ? 1 : 4;
+  constexpr int64_t RUN = INIT ? 1 : MI_INGEST_RUN;
   auto row_of = [&](int64_t it) { return ((it / RUN) * (int64_t)gridDim.x + blockIdx.x) * RUN + it % RUN; };
   request(row_of(0));
   for (int64_t it = 0;; ++it) {
@@ -509,7 +514,8 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
       occ = 4;                                                                                                          \
     if (MI_INGEST_PROBE && getenv("MI_INGEST_WG_PER_CU")) occ = atoi(getenv("MI_INGEST_WG_PER_CU"));                    \
     if (MI_INGEST_PROBE) fprintf(stderr, "ingest: %d workgroups per CU\n", occ);                                        \
-    const unsigned grid = (unsigned)std::min<int64_t>((npad + 3) / 4, (int64_t)current_device_cus() * occ);             \
+    const unsigned grid = (unsigned)std::min<int64_t>((npad + MI_INGEST_RUN - 1) / MI_INGEST_RUN,                          \
+                                                      (int64_t)current_device_cus() * occ);                               \
     hipLaunchKernelGGL((ingest_query_kernel<T, false, PT>), dim3(grid), dim3(256), 0, stream, (const T*)src, n, d, rs,  \
                        cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, none, row_base);               \
   } while (0)
