@@ -49,6 +49,7 @@ struct Workspace {
   uint32_t* qflag = nullptr;
   float* lad_tc = nullptr;
   uint32_t *lad_pack = nullptr, *lad_cnt = nullptr;
+  uint32_t *lad_pack2 = nullptr, *lad_cnt2 = nullptr, *lad_lev = nullptr;   // second ladder level (option "ladder" = 2)
   uint32_t* cnt = nullptr;
   uint64_t* surv = nullptr;
   uint32_t* flags = nullptr;
@@ -91,6 +92,7 @@ struct P1Plan {
   bool sample_f32 = false;         // the bootstrap launch stores bare 4-byte scores
   bool thr_kernel = false;         // sample_threshold_kernel takes the thresholds (else select_maintain mode 0)
   int32_t lad_r = 0;               // ladder level (sample rank), 0 = off
+  int32_t lad_r2 = 0;              // second, tighter level (option "ladder" = 2), 0 = off
   bool zero_scores = false;        // the query ingest writes zeros for the K-split bootstrap to add onto
 };
 }  // namespace
@@ -247,6 +249,9 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(lad_tc, QB);
   A(lad_pack, QB);
   A(lad_cnt, QB);
+  A(lad_pack2, QB);
+  A(lad_cnt2, QB);
+  A(lad_lev, QB);
   A(cnt, (size_t)QB * CNT_STRIDE);
   A(surv, (size_t)QB * ws.cap);
   A(flags, 4);
@@ -305,6 +310,9 @@ static QueryState make_state(const Workspace& ws) {
   st.lad_tc = ws.lad_tc;
   st.lad_pack = ws.lad_pack;
   st.lad_cnt = ws.lad_cnt;
+  st.lad_pack2 = ws.lad_pack2;
+  st.lad_cnt2 = ws.lad_cnt2;
+  st.lad_lev = ws.lad_lev;
   st.cap = ws.cap;
   return st;
 }
@@ -433,6 +441,12 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
     int32_t lr = (int32_t)std::lround(std::sqrt(lambda * pl.samp_r));
     pl.lad_r = std::max<int32_t>(1, std::min<int32_t>(lr, pl.samp_r - 1));
+    // second rung (option "ladder" = 2; fp16 image only: the LAD2 instantiation): the same rule one level up -- rank
+    // sqrt(lambda * lad_r) < lad_r (2 at N = 1M, K = 100: validated after ~40 % of the rows)
+    if (g->ladder >= 2 && g->img_f16 && pl.lad_r > 1) {
+      const int32_t l2 = (int32_t)std::lround(std::sqrt(lambda * pl.lad_r));
+      pl.lad_r2 = std::max<int32_t>(1, std::min<int32_t>(l2, pl.lad_r - 1));
+    }
   }
   return pl;
 }
@@ -466,7 +480,7 @@ static int p1_pre(mi_gallery* g, Workspace& ws, const P1Plan& pl, const void* q_
     p1_score_launch(g, ws, st, p2, 0, pl.t0, true, nullptr, false, true, false, s);     // bootstrap on the sample image
     if (pl.thr_kernel)
       launch_sample_threshold(st, pl.nq, pl.k, pl.samp_r, pl.first_cnt, s, pl.lad_r, pl.sample_f32 ? 1 : 0,
-                              (pl.sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f);
+                              (pl.sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f, pl.lad_r2);
     else
       launch_select_maintain(st, pl.nq, pl.k, 0, ws.topvals, ws.L, ws.stats2, pl.samp_r, 1, 0, nullptr, s);
   }
@@ -510,6 +524,7 @@ static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, 
   a.cond = cond;
   a.bal = g->xcc_balance ? ws.bal : nullptr;
   a.lad_k = ladder_on ? pl.k : 0;
+  a.lad2 = (ladder_on && pl.lad_r2 > 0) ? 1 : 0;
   a.scores_only = (on_sample && first_chunk && pl.sample_f32) ? 1 : 0;
   a.ksplit = a.scores_only ? pl.boot_ksplit : 1;
   a.dbg = ws.dbg;
@@ -2401,7 +2416,10 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
   else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
-  else if (n == "ladder") g->ladder = value != 0;
+  else if (n == "ladder") {
+    REQUIRE(value == 0 || value == 1 || value == 2, "ladder: 0 (off), 1 (one level) or 2 (two levels)");
+    g->ladder = (int)value;
+  }
   else if (n == "boot_ksplit") g->boot_ksplit = value != 0;
   else if (n == "stream_tail") g->stream_tail = value != 0;
   else if (n == "stream_lookahead") g->stream_lookahead = value != 0;

@@ -56,6 +56,12 @@ __host__ __device__ __forceinline__ uint32_t bf16_down(float f) {
   return hi & 0xFFFFu;
 }
 
+// f32 -> upper 16 bits (bf16 layout), rounded toward +inf: a COUNT level may only get stricter by the packing
+__host__ __device__ __forceinline__ uint32_t bf16_up(float f) {
+  if (f != f) return 0x7F80u;                                  // NaN -> +inf (nothing is counted)
+  return (bf16_down(-f) ^ 0x8000u) & 0xFFFFu;
+}
+
 // survivor entry: (score bits << 32) | local row
 __device__ __forceinline__ uint64_t pack_entry(float s, uint32_t row) {
   return ((uint64_t)__float_as_uint(s) << 32) | row;
@@ -110,6 +116,10 @@ struct QueryState {       // all arrays sized for qpad queries
   float* lad_tc;          // count level t_c: a sample order statistic tighter than the speculative one (+inf = off)
   uint32_t* lad_pack;     // bf16(thr, rounded down) | bf16(t_c - margin, rounded down) << 16: the two thresholds a wave may apply
   uint32_t* lad_cnt;      // rows seen with approx >= t_c; once >= K, t_c - margin is a RIGOROUS threshold
+  // second ladder level (option "ladder" = 2, tile-kernel instantiation LAD2; nullptr = off): t_c2 >= t_c, a tighter sample rank
+  uint32_t* lad_pack2;    // bf16(t_c2 - margin, rounded down) << 16
+  uint32_t* lad_cnt2;     // rows seen with approx >= bf16_up(t_c2)
+  uint32_t* lad_lev;      // count levels of both: bf16_up(t_c) | bf16_up(t_c2) << 16
   uint32_t cap;
 };
 

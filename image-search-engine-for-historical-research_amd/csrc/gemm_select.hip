@@ -483,9 +483,12 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
 // DBG 16384: the query fragments are read from LDS once per launch (energy model of a query operand that bypasses LDS);
 // DBG 32768: every wave also loads its 4 KiB of query fragments per slice straight into (discarded) registers -- with
 // DBG 64 | 16384 the traffic of the "global -> VGPR query operand" structure without its pipeline (scripts/kbench.hip).
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0>
+// LAD2 (round 4): two ladder levels.  The query ring gives up its fourth slot (measured equal: profiles/r03d_ring_slots_ab.txt)
+// and the second level's per-wave words -- its packed threshold and its live counter -- live in that slot's 16 KiB.
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0, bool LAD2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
   constexpr bool ZC = (OPT & 1) != 0;
+  constexpr int BSL = LAD2 ? 3 : B_SLOTS;                    // slots of the query ring
   constexpr bool INTER = (OPT & 2) != 0 && !FIRST && !(DBG & (4 | 4096 | 8192));
   using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // rings | per-wave scratch | per-wave thresholds  (ONE LDS object)
@@ -529,12 +532,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
 
   auto run = [&](auto grp_tag) {
     constexpr int GRP = decltype(grp_tag)::value;              // wave group = gallery half; 0 streams A, 1 streams B
-    constexpr int MY_SLOTS = GRP == 0 ? A_SLOTS : B_SLOTS;
+    constexpr int MY_SLOTS = GRP == 0 ? A_SLOTS : BSL;
     constexpr bool dbg_nodma = (DBG & 1) || ((DBG & 32) && GRP == 0) || ((DBG & 64) && GRP == 1);
     // per-wave threshold words of its 64 queries: [0..63] threshold (f32) -- or, ladder on, the packed pair of thresholds --,
     // [64..127] ladder counters (refreshed by a 256-byte DMA per tile), [128..191] ladder count levels t_c
     float* thr_w = reinterpret_cast<float*>(smem + RING_BYTES + STAGE_BYTES) + w * THR_WORDS;
     const bool lad = !FIRST && !REPAIR && p.lad_k > 0 && p.st.lad_cnt != nullptr;
+    const bool lad2 = LAD2 && lad && p.st.lad_cnt2 != nullptr;
+    // second level, per wave: [0..63] bf16(t_c2 - margin) << 16, [64..127] its counter -- in the query ring's unused slot
+    uint32_t* thr_x = reinterpret_cast<uint32_t*>(smem + B_RING + 3 * SLICE_BYTES) + w * 128;
     const uint32_t* lad_cnt_src = p.st.lad_cnt;                 // + query of this lane, set with the thresholds
     uint32_t thr_qt = 0xFFFFFFFFu;
     auto load_thresholds = [&](uint32_t qt) {                   // plain loads: drains the DMA rings (query tile changes only)
@@ -542,7 +548,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       if (lad) {
         reinterpret_cast<uint32_t*>(thr_w)[lane] = p.st.lad_pack[q];
         reinterpret_cast<uint32_t*>(thr_w)[64 + lane] = p.st.lad_cnt[q];
-        thr_w[128 + lane] = p.st.lad_tc[q];
+        if (lad2) {                                   // count levels of both rungs as one word; the second rung's words
+          reinterpret_cast<uint32_t*>(thr_w)[128 + lane] = p.st.lad_lev[q];
+          thr_x[lane] = p.st.lad_pack2[q];
+          thr_x[64 + lane] = p.st.lad_cnt2[q];
+        } else {
+          thr_w[128 + lane] = p.st.lad_tc[q];
+        }
       } else {
         thr_w[lane] = p.st.thr[q];
       }
@@ -550,9 +562,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     };
     // ladder: this wave's 64 counters, straight into LDS (one 4-byte-per-lane DMA piece in the wave's vmcnt order)
     auto refresh_counts = [&](uint32_t qt) {
-      if (lad && qt == thr_qt)
+      if (lad && qt == thr_qt) {
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(lad_cnt_src + qt * TILE + wc * 64 + lane),
                                          (LDS_AS void*)(thr_w + 64), 4, 0, 0);
+        if (lad2)
+          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.st.lad_cnt2 + qt * TILE + wc * 64 + lane),
+                                           (LDS_AS void*)(thr_x + 64), 4, 0, 0);
+      }
     };
     auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
       const uint32_t v = j + i * nwg;
@@ -643,6 +659,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
           uint32_t cnt;
           asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cnt) : "v"(lds_addr(thr_w + 64 + nb * 16 + l15)) : "memory");
           thr4[nb] = __uint_as_float(cnt >= (uint32_t)p.lad_k ? (pk & 0xFFFF0000u) : (pk << 16));
+          if (LAD2 && lad2) {                         // the higher rung, once K rows above IT have been counted
+            uint32_t cnt2, pk2;
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(cnt2), "=&v"(pk2)
+                         : "v"(lds_addr(thr_x + 64 + nb * 16 + l15)), "v"(lds_addr(thr_x + nb * 16 + l15))
+                         : "memory");
+            if (cnt2 >= (uint32_t)p.lad_k) thr4[nb] = __uint_as_float(pk2 & 0xFFFF0000u);
+          }
         } else {
           thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
         }
@@ -863,7 +887,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
               if (!(DBG & 1024) && keep && pos < p.rec_cap)          // DBG 1024: no record stores (diagnostics)
                 reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(vv[it]), row, mt[it].y, 0u);
-              if (lad && keep && vv[it] >= __uint_as_float(mt[it].w)) atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
+              if (LAD2 && lad2) {                       // .w = bf16_up(t_c) | bf16_up(t_c2) << 16
+                if (keep && vv[it] >= __uint_as_float(mt[it].w << 16)) atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
+                if (keep && vv[it] >= __uint_as_float(mt[it].w & 0xFFFF0000u)) atomicAdd(&p.st.lad_cnt2[mt[it].y], 1u);
+              } else if (lad && keep && vv[it] >= __uint_as_float(mt[it].w)) {
+                atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
+              }
               if (DBG & 1024) asm volatile("" ::"v"(pos), "v"(row));
               my_cnt += (uint32_t)__popcll(km);
             }
@@ -887,7 +916,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     __builtin_amdgcn_s_barrier();
     if (GRP == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave group by one barrier
 
-    uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding the current slice
+    uint32_t a_rd = 0, b_rd = 0;                           // ring slots holding the current slice (query ring: BSL slots)
     unsigned long long clk0 = 0, rt0 = 0;
     frag_t bkeep[4] = {};                                  // DBG 16384: the query fragments of the launch's first slice
     // in-kernel clock of every launch (s_memtime / s_memrealtime around the loop, per wave): two scalar reads, and the
@@ -927,11 +956,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       const char* abase = smem + a_rd * SLICE_BYTES;
       const char* bbase = smem + b_rd * SLICE_BYTES;
       if (++a_rd == A_SLOTS) a_rd = 0;
-      if (++b_rd == B_SLOTS) b_rd = 0;
+      if (++b_rd == BSL) b_rd = 0;
       frag_reads(af, bfr, abase, bbase, first_ever);
       __builtin_amdgcn_sched_barrier(0);
       issue();
-      if (GRP == 1) vm_wait<(B_SLOTS - 2) * VM_PER_SLICE>();   // B(S+1) landed before the barrier that opens group 0's LOAD(S+1)
+      if (GRP == 1) vm_wait<(BSL - 2) * VM_PER_SLICE>();   // B(S+1) landed before the barrier that opens group 0's LOAD(S+1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads retired BEFORE the barrier: frees the slots (WAR)
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -1011,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
           const char* abase = smem + a_rd * SLICE_BYTES;
           const char* bbase = smem + b_rd * SLICE_BYTES;
           if (++a_rd == A_SLOTS) a_rd = 0;
-          if (++b_rd == B_SLOTS) b_rd = 0;
+          if (++b_rd == BSL) b_rd = 0;
           __builtin_amdgcn_sched_barrier(0);
           issue();
           __builtin_amdgcn_sched_barrier(0);
@@ -1235,17 +1264,17 @@ static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
 
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0>
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0, bool LAD2 = false>
 static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
-  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>);
+  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL, LAD2>);
   hipEvent_t e0, e1;
   take_launch_events(&e0, &e1);
   if (e0 && e1)
-    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>), dim3(persistent_grid()), dim3(512), lds,
-                          stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL, LAD2>), dim3(persistent_grid()), dim3(512),
+                          lds, stream, e0, e1, 0, a);
   else
-    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>), dim3(persistent_grid()), dim3(512), lds, stream,
-                       a);
+    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL, LAD2>), dim3(persistent_grid()), dim3(512), lds,
+                       stream, a);
 }
 
 void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
@@ -1261,6 +1290,7 @@ void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
     if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 3>(a, lds, stream)
                                 : launch_tile<true, 0, false, false, 3>(a, lds, stream);
     if (!a.img_f16) return launch_tile<false, 0, false, false, 3>(a, lds, stream);
+    if (a.lad2 && a.lad_k > 0 && a.debug == 0) return launch_tile<false, 0, true, false, 3, 0, 0, true>(a, lds, stream);   // two rungs
     switch (a.debug) {
       case 4:
         if (a.variant == 2) return launch_tile<false, 4, true, false, 0>(a, lds, stream);

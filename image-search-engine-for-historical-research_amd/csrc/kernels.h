@@ -42,6 +42,7 @@ struct ScoreArgs {
   const uint32_t* cond;   // non-null: the whole launch is skipped when *cond == 0 (repair pass)
   const XccBalance* bal = nullptr;   // non-null: weighted split of the gallery tiles over the XCD labels (tile kernel)
   int32_t lad_k = 0;                 // > 0: in-launch threshold ladder on (K of the search); tile kernel, filtered launch only
+  int32_t lad2 = 0;                  // 1: two ladder levels (QueryState::lad_*2; tile-kernel instantiation LAD2)
   int32_t scores_only = 0;           // bootstrap launch on the sample image (stream_select MODE 2): store the scores as 4-byte
                                      // floats at ((float*)(surv + q * cap))[sample row] instead of 8-byte (score, row) entries --
                                      // sample_threshold_kernel reads nothing but the scores, and the entries are dropped afterwards
@@ -96,7 +97,8 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 void set_tail_debug_phase(int phase);   // diagnostics only (scripts/tailbench.hip): selection kernels return after phase N; 0 = product
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f);   // f32_scores: see ScoreArgs::scores_only
+                             int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f,
+                             int32_t lad_r2 = 0);   // f32_scores: see ScoreArgs::scores_only; lad_r2: second ladder level
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows = nullptr, uint32_t* cand_cnt = nullptr,

@@ -174,6 +174,7 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
     st.lad_tc[q] = INFINITY;
     st.lad_pack[q] = 0x7F807F80u;         // (+inf, +inf)
     st.lad_cnt[q] = 0;
+    if (st.lad_cnt2) { st.lad_pack2[q] = 0x7F800000u; st.lad_cnt2[q] = 0; st.lad_lev[q] = 0x7F807F80u; }
   }
 }
 
@@ -401,10 +402,10 @@ constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD 
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
                                                                         int32_t lad_r, int32_t f32_scores, int dbg_phase,
-                                                                        float order_slack) {
+                                                                        float order_slack, int32_t lad_r2) {
   __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
   __shared__ __attribute__((aligned(16))) uint32_t hist[1024];   // the select's histograms; first 256 words: gather buffer
-  __shared__ uint32_t sh[8];
+  __shared__ uint32_t sh[9];
   const uint32_t q = blockIdx.x;
   const float margin_q = st.margin[q], thr_in = st.thr[q];    // requested up front (thread 0 needs them at the very end)
   const uint32_t n = min(st.cnt[q * CNT_STRIDE], (uint32_t)(SAMP_THREADS * SAMP_PER_THREAD));
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
   const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);   // wanted ranks, w1 <= w2 <= 256
   uint32_t* maxima = keys;                                  // 512 keys
   maxima[threadIdx.x] = kmax;
-  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
+  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = 0; }
   __syncthreads();
   const uint32_t t0 = block_kth_largest(maxima, SAMP_THREADS, w2, hist);
   __syncthreads();
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     }
   __syncthreads();
   const uint32_t m = sh[3];
-  uint32_t key1, key2, key3 = 0;
+  uint32_t key1, key2, key3 = 0, key4 = 0;
   if (m <= 256) {
     if (threadIdx.x < m) {
       const uint32_t me = hist[threadIdx.x];
@@ -444,11 +445,13 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
       if (gt < w1 && w1 <= ge) sh[4] = me;
       if (gt < w2 && w2 <= ge) sh[5] = me;
       if (lad_r > 0 && gt < (uint32_t)lad_r && (uint32_t)lad_r <= ge) sh[6] = me;
+      if (lad_r2 > 0 && gt < (uint32_t)lad_r2 && (uint32_t)lad_r2 <= ge) sh[8] = me;
     }
     __syncthreads();
     key1 = sh[4];
     key2 = sh[5];
     key3 = sh[6];
+    key4 = sh[8];
   } else {                                                  // a crowd of ties: plain selects over all keys
     __syncthreads();
 #pragma unroll
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     key1 = block_kth_largest(keys, n, w1, hist);
     key2 = block_kth_largest(keys, n, w2, hist);
     if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist);
+    if (lad_r2 > 0) key4 = block_kth_largest(keys, n, (uint32_t)lad_r2, hist);
   }
   if (threadIdx.x == 0) {
     // order_slack: the sample scores were summed in another order than the scoring launch sums (K-split bootstrap,
@@ -479,6 +483,15 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
       st.lad_tc[q] = tc;
       st.lad_pack[q] = bf16_down(excluded ? INFINITY : thr) | (bf16_down(on ? tc - margin : INFINITY) << 16);
       st.lad_cnt[q] = 0;
+      if (st.lad_cnt2) {
+        // second level: t_c2 = score(lad_r2), lad_r2 < lad_r, so t_c2 >= t_c; the count levels are rounded UP to bf16 (a
+        // count may only miss rows, never gain them) and travel as one word beside a hit's scores
+        const bool on2 = on && lad_r2 > 0;
+        const float tc2 = on2 ? key2f(key4) : INFINITY;
+        st.lad_pack2[q] = bf16_down(on2 ? tc2 - margin : INFINITY) << 16;
+        st.lad_cnt2[q] = 0;
+        st.lad_lev[q] = bf16_up(tc) | (bf16_up(tc2) << 16);
+      }
     }
   }
 }
@@ -490,19 +503,19 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
 }
 
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r, int32_t f32_scores, float order_slack) {
+                             int32_t lad_r, int32_t f32_scores, float order_slack, int32_t lad_r2) {
   if (first_cnt == SAMP_THREADS * 2u)
     hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack);
+                       g_tail_debug_phase, order_slack, lad_r2);
   else if (first_cnt == SAMP_THREADS * 4u)
     hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack);
+                       g_tail_debug_phase, order_slack, lad_r2);
   else if (first_cnt == SAMP_THREADS * 8u)
     hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack);
+                       g_tail_debug_phase, order_slack, lad_r2);
   else
     hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack);
+                       g_tail_debug_phase, order_slack, lad_r2);
 }
 
 // ------------------------------------------------------------------------------------------------

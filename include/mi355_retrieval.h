@@ -306,7 +306,8 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
  * be enqueued before phase 2 of batch i; sticky flags and statistics are one set for both),
  * "spec_max_ratio" (largest shard rows / sample rows for which the single-launch sample schedule is taken; default 160),
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
- * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel), "boot_ksplit" (batches of <= 512 queries: the bootstrap launch
+ * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel: 0 = off, 1 = one level (default), 2 = two levels -- built and measured
+ * 1.3 % slower), "boot_ksplit" (batches of <= 512 queries: the bootstrap launch
  * on the sample splits K over several workgroups that add their partial scores with float atomics; default 1.  The order of
  * those adds is not fixed, so the sample scores -- and with them the survivor / candidate statistics and which queries need a
  * repair -- may differ by an ulp from run to run; the answers do not: the threshold is speculative and verified), "xcc_balance" (XCD shares by measured

@@ -197,16 +197,19 @@ def test_ladder_thresholds_keep_the_answer_and_cut_the_survivors(lib):
     g = lib.Gallery.from_device_ptr(raw.data_ptr(), n, d)
     try:
         res = {}
-        for lad in (0, 1):
+        for lad in (0, 1, 2):                              # 2 = two levels (round 4, the LAD2 instantiation of the kernel)
             g.set_option("ladder", lad)
             g.status(reset=True)
             idx, sc = _search(g, q, k)
             st = g.status()
-            assert st["overflow_batches"] == 0
+            assert st["overflow_batches"] == 0 and st["spec_retries"] == 0
             res[lad] = (idx, sc, st["survivors"] / st["queries"], st["candidates"] / st["queries"])
-        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-        assert res[0][3] == res[1][3]                      # same candidate sets
+        g.set_option("ladder", 1)
+        for lad in (1, 2):
+            assert np.array_equal(res[0][0], res[lad][0]) and np.array_equal(res[0][1], res[lad][1]), lad
+            assert res[0][3] == res[lad][3], lad           # same candidate sets
         assert res[1][2] < 0.8 * res[0][2], (res[0][2], res[1][2])
+        assert res[2][2] < res[1][2], (res[1][2], res[2][2])   # the second rung cuts further
         assert res[1][0][900, 0] == 300000
         g.set_option("force_exact", 1)
         idx_e, sc_e = _search(g, q, k)
