@@ -837,7 +837,9 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     if (g->la.prepared) {
       const mi_gallery::Lookahead& la = g->la;
       pre_hit = (device_api || streaming) && la.pq == (const void*)src && la.pnq == b && la.pk == k && la.pdtype == q_dtype &&
-                la.prs == q_rs && la.pcs == q_cs && la.pnorm == q_norm && la.pset == set && !exact;
+                la.prs == q_rs && la.pcs == q_cs && la.pnorm == q_norm && la.pset == set && !exact &&
+                // (an option change may have rebuilt the active workspace and dropped the parked one with the prepared batch)
+                g->ws_alt.qcap >= QB && g->ws_alt.kcap >= k && g->ws_alt.cap == g->surv_cap && g->ws_alt.rcap == g->rescore_cap;
       g->la.prepared = false;
       if (pre_hit) {                              // its state is in the parked workspace: make that one the active one
         std::swap(g->ws, g->ws_alt);
@@ -1076,6 +1078,7 @@ int mi_gallery_append_device(mi_gallery* g, const float* rows_dev, int64_t m, vo
   REQUIRE(m >= 1, "nothing to append");
   REQUIRE(g->n + m <= g->cap, "gallery capacity exceeded");
   std::lock_guard<std::mutex> lock(g->mu);
+  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   HIPC(hipSetDevice(g->device));
   hipStream_t s = (hipStream_t)stream;
   // rows [n, n+m): normalise like the gallery, write f32 rows + 16-bit image + rounding norms at their final place
@@ -1098,6 +1101,7 @@ int mi_gallery_append(mi_gallery* g, const void* data, int64_t m, int dtype, int
   int rc = strided_extent(m, g->d, row_stride, col_stride, &elems);
   if (rc != MI_OK) return rc;
   std::lock_guard<std::mutex> lock(g->mu);
+  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   HIPC(hipSetDevice(g->device));
   hipStream_t s = g->stream;
   const size_t esz = dtype == MI_F32 ? 4 : 8;
@@ -2290,6 +2294,7 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
 int mi_gallery_norm_bounds(mi_gallery* g, float* bounds3, int raise) {
   REQUIRE(g && bounds3, "null");
   std::lock_guard<std::mutex> lock(g->mu);
+  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   HIPC(hipSetDevice(g->device));
   HIPC(hipStreamSynchronize(g->stream));
   float own[3] = {0, 0, 0};
@@ -2309,6 +2314,7 @@ int mi_gallery_set_image_dtype(mi_gallery* g, int f16) {
   REQUIRE(g, "null handle");
   f16 = f16 != 0;
   std::lock_guard<std::mutex> lock(g->mu);
+  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   if (g->img_f16 == f16 || g->n == 0) {
     g->img_f16 = f16;
     return MI_OK;
@@ -2379,6 +2385,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
 
 int mi_set_option(mi_gallery* g, const char* name, double value) {
   REQUIRE(g && name, "null");
+  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   const std::string n(name);
   if (g->pending.valid) {
     // a deferred tail (async_tail 3) is enqueued before ANY option changes: it must run with the buffers, caps and workspace
