@@ -579,14 +579,19 @@ static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s
     // repair pass for queries whose speculative threshold failed verification (1e-7 per query): conditional on the device
     // word *ws.repair, i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip.  Batches
     // of <= 128 queries -- the reference's own shapes, one query online and 70 per test set, where three empty launches
-    // are 1 % of the batch and a failure has probability <= 1e-5 -- do without WHEN THE CALLER IS A HOST ENTRY POINT: that
-    // one synchronises anyway, sees FLAG_SPEC_FAIL and answers the batch again by the rigorous schedule.  The asynchronous
-    // device and phase entry points keep the repair pass at every batch size (round 4: their callers -- sharded protocol,
-    // pipelined streams, alpha-QE re-search -- need not read the flags to get a complete answer).  Option "device_repair"
-    // overrides.
-    const bool repair_pass = g->device_repair < 0 ? (nq > STREAM_MAX_QUERIES || !caller_checks_flags) : g->device_repair != 0;
-    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, repair_pass ? 0 : 2, nullptr, s, fc_rows, fc_cnt,
-                           ws.rcap);
+    // are 1 % of the batch and a failure has probability <= 1e-5 -- do without.  A HOST entry point synchronises anyway, sees
+    // FLAG_SPEC_FAIL and answers the batch again by the rigorous schedule (mode 2).  The asynchronous device and phase entry
+    // points -- whose callers (sharded protocol, pipelined streams, alpha-QE re-search) need not read flags to get a
+    // complete answer -- take mode 3 below.  Option "device_repair" overrides.
+    // Round 4, second half: small batches on the asynchronous entry points launch no repair kernels either -- the workgroup
+    // of a failed query repairs it inside the maintain launch (repair mode 3, select.hip SCAN: a scan of the shard's stored
+    // rows by that one workgroup, ~0.1 s per 1 M rows, once per 10^7 queries).  "device_repair" = 1 still forces the launches.
+    const bool small = nq <= STREAM_MAX_QUERIES;
+    const bool repair_pass = g->device_repair < 0 ? !small : g->device_repair != 0;
+    const int rep_mode = repair_pass ? 0 : ((small && !caller_checks_flags && g->device_repair < 0) ? 3 : 2);
+    const RepairScan scan{g->gal_f32, ws.q_f32, g->dp, g->n};
+    launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, rep_mode, nullptr, s, fc_rows, fc_cnt, ws.rcap,
+                           rep_mode == 3 ? &scan : nullptr);
     if (repair_pass) {
       const uint32_t* cond = ws.repair;
       p1_score_launch(g, ws, st, pl, 0, ntiles, false, cond, false, false, false, s);

@@ -99,10 +99,18 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
                              int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f,
                              int32_t lad_r2 = 0);   // f32_scores: see ScoreArgs::scores_only; lad_r2: second ladder level
+// what the in-kernel repair of a failed query scans (repair == 3): the shard's stored f32 rows and the batch's f32 queries
+struct RepairScan {
+  const float* gal_f32 = nullptr;
+  const float* qry_f32 = nullptr;
+  int32_t dp = 0;
+  int64_t n = 0;
+};
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
                             hipStream_t stream, uint32_t* cand_rows = nullptr, uint32_t* cand_cnt = nullptr,
-                            uint32_t rcap = 0);   // cand_*: mode 1 also writes the candidate rows (single-shard search)
+                            uint32_t rcap = 0,   // cand_*: mode 1 also writes the candidate rows (single-shard search)
+                            const RepairScan* scan = nullptr);   // repair == 3: the workgroup of a failed query re-scans the shard
 void launch_select_candidates(QueryState st, int32_t nq, const float* L, uint32_t* cand_rows, uint32_t* cand_cnt,
                               uint32_t rcap, uint64_t* stats2, hipStream_t stream);
 void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,

@@ -208,7 +208,12 @@ constexpr int MAINT_PER_THREAD_MAX = 32;        // 512 * 32 = 16384 = largest su
 //   batches, api.hip), a failed query raises FLAG_SPEC_FAIL at once.  cond: skip the launch when *cond == 0.
 // PT = entries per thread kept in registers (PT * 512 >= survivor_cap): 24 instead of 32 at the default cap frees the
 // registers for a second workgroup per CU in MODE 1
-template <int MODE, int PT>
+//   repair == 3 (instantiation SCAN; small batches on the asynchronous entry points, round 4): no repair pass follows EITHER,
+//   and nobody may have to read a flag: the workgroup of a failed query repairs it itself -- it scans every stored f32 row of
+//   the shard against the query (one wave per row, float64 accumulation: scores at least as good as the image's, so the
+//   certificate's bounds hold a fortiori), keeps the rows at or above the looser threshold thr2 and runs the selection again
+//   on them.  ~0.1 s for a 1 M-row shard, once per 10^7 queries, instead of three empty launches behind every batch.
+template <int MODE, int PT, bool SCAN = false>
 __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QueryState st, int32_t k,
                                                                         float* __restrict__ topvals,
                                                                         float* __restrict__ l_local,
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
                                                                         const uint32_t* __restrict__ cond,
                                                                         uint32_t* __restrict__ cand_rows,
                                                                         uint32_t* __restrict__ cand_cnt, uint32_t rcap,
-                                                                        int dbg_phase) {
+                                                                        int dbg_phase, RepairScan rs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (cond && *cond == 0) return;
   const uint32_t q = blockIdx.x;
@@ -229,11 +234,13 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
   uint32_t* sh = hist + 1024;
   // the per-query words this workgroup needs later are requested up front: each is a global round trip of its own
   // otherwise, in the middle of the barrier chain
-  const uint32_t cnt_q = st.cnt[q * CNT_STRIDE];
+  uint32_t cnt_q = st.cnt[q * CNT_STRIDE];
   const float margin_q = st.margin[q];
-  const float used_thr = st.thr[q];
+  float used_thr = st.thr[q];
   const float thr2_q = st.thr2[q];
   const uint32_t lad_cnt_q = st.lad_cnt ? st.lad_cnt[q] : 0u;
+  int attempt = 0;                                   // SCAN: 1 = the selection runs again on the rows the scan kept
+restart:
   const uint32_t n = min(cnt_q, cap);
   if (MODE == 1 && cnt_q > cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
   uint64_t* gsurv = st.surv + (uint64_t)q * cap;
@@ -298,9 +305,53 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
     const float used = used_thr;
     // ladder validated: >= K rows with approx >= t_c were emitted, so L >= t_c and every row with approx >= t_c - margin
     // (the tightest threshold any wave applied) is among the survivors: nothing speculative is left to verify
-    const bool lad_ok = st.lad_cnt && repair != 1 && lad_cnt_q >= (uint32_t)k && n >= (uint32_t)k;
+    const bool lad_ok = st.lad_cnt && repair != 1 && attempt == 0 && lad_cnt_q >= (uint32_t)k && n >= (uint32_t)k;
     failed = !lad_ok && (used > -INFINITY) && !(n >= (uint32_t)k && L - margin_q >= used);
     if (failed) thr_new = thr2_q;
+  }
+  if (SCAN && MODE == 1 && failed && repair == 3 && attempt == 0 && rs.gal_f32) {
+    // in-kernel repair of this query: every stored row of the shard against it, rows with score >= thr2 become the survivors
+    __syncthreads();
+    if (threadIdx.x == 0) sh[6] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = MAINT_THREADS / 64;
+    const int nvec = rs.dp >> 2;
+    const float4* qv = reinterpret_cast<const float4*>(rs.qry_f32 + (uint64_t)q * rs.dp);
+    for (int64_t r0 = wv * 2; r0 < rs.n; r0 += 2 * nw) {
+      const int64_t r1 = r0 + 1 < rs.n ? r0 + 1 : r0;
+      const float4* g0 = reinterpret_cast<const float4*>(rs.gal_f32 + (uint64_t)r0 * rs.dp);
+      const float4* g1 = reinterpret_cast<const float4*>(rs.gal_f32 + (uint64_t)r1 * rs.dp);
+      double a0 = 0.0, a1 = 0.0;
+      for (int v = lane; v < nvec; v += 64) {
+        const float4 x = qv[v], y0 = g0[v], y1 = g1[v];
+        a0 += (double)x.x * (double)y0.x; a0 += (double)x.y * (double)y0.y;
+        a0 += (double)x.z * (double)y0.z; a0 += (double)x.w * (double)y0.w;
+        a1 += (double)x.x * (double)y1.x; a1 += (double)x.y * (double)y1.y;
+        a1 += (double)x.z * (double)y1.z; a1 += (double)x.w * (double)y1.w;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+      }
+      if (lane == 0) {
+        if ((float)a0 >= thr2_q) {
+          const uint32_t pos = atomicAdd(&sh[6], 1u);
+          if (pos < cap) gsurv[pos] = pack_entry((float)a0, (uint32_t)r0);
+        }
+        if (r1 != r0 && (float)a1 >= thr2_q) {
+          const uint32_t pos = atomicAdd(&sh[6], 1u);
+          if (pos < cap) gsurv[pos] = pack_entry((float)a1, (uint32_t)r1);
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    cnt_q = sh[6];
+    if (cnt_q > cap && threadIdx.x == 0) atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+    used_thr = thr2_q;
+    attempt = 1;
+    __syncthreads();
+    goto restart;
   }
   float* tv = topvals + (uint64_t)q * k;
 #pragma unroll
@@ -371,14 +422,21 @@ __global__ __launch_bounds__(MAINT_THREADS) void select_maintain_kernel(QuerySta
 
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
-                            hipStream_t stream, uint32_t* cand_rows, uint32_t* cand_cnt, uint32_t rcap) {
+                            hipStream_t stream, uint32_t* cand_rows, uint32_t* cand_cnt, uint32_t rcap, const RepairScan* scan) {
   const size_t lds = (size_t)std::min<uint32_t>(st.cap, MAINT_LDS_KEYS) * 4 + 16 + 1024 * 4 + 32;     // keys | hist[1024] | sh[8]
+  const RepairScan rs = scan ? *scan : RepairScan{};
   auto go = [&](auto kern) {
     ensure_dynamic_lds((const void*)kern);                     // survivor_cap = 16384 needs 66.6 KB
     hipLaunchKernelGGL(kern, dim3(nq), dim3(MAINT_THREADS), lds, stream, st, k, topvals, l_local, stats2, spec_r, spec,
-                       repair, cond, cand_rows, cand_cnt, rcap, g_tail_debug_phase);
+                       repair, cond, cand_rows, cand_cnt, rcap, g_tail_debug_phase, rs);
   };
   const uint32_t per_thread = (st.cap + MAINT_THREADS - 1) / MAINT_THREADS;
+  if (mode == 1 && repair == 3 && scan) {                      // in-kernel repair (small batches, asynchronous entry points)
+    if (per_thread <= 16) go(select_maintain_kernel<1, 16, true>);
+    else if (per_thread <= 24) go(select_maintain_kernel<1, 24, true>);
+    else go(select_maintain_kernel<1, MAINT_PER_THREAD_MAX, true>);
+    return;
+  }
   if (mode == 0) {
     if (per_thread <= 16) go(select_maintain_kernel<0, 16>);
     else if (per_thread <= 24) go(select_maintain_kernel<0, 24>);

@@ -317,9 +317,12 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
- * "device_repair" (-1 = default: the scoring launch is followed by a device-conditional repair pass for queries whose
- * speculative threshold failed verification -- except for batches of <= 128 queries through the HOST entry points, which
- * synchronise anyway, see the sticky flag and answer the batch again; 0 / 1 = never / always launch the repair pass), "small_tail" (1 = batches of <= 128 queries re-score and
+ * "device_repair" (-1 = default: the scoring launch of a batch of > 128 queries is followed by a device-conditional repair
+ * pass for queries whose speculative threshold failed verification; smaller batches launch none: through a HOST entry point
+ * the sticky flag makes the call answer the batch again, through the asynchronous device / phase entry points the workgroup
+ * of the failed query repairs it inside the maintain launch (a scan of the shard's rows, ~0.1 s per million, once per 10^7
+ * queries), so their answers are complete without anybody reading flags; 0 / 1 = never / always launch the repair pass),
+ * "small_tail" (1 = batches of <= 128 queries re-score and
  * order in one launch; measured slower, default 0),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
