@@ -130,6 +130,7 @@ struct mi_gallery {
   int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
   int boot_ksplit = 1;          // small batches: K-split bootstrap launch (kernels.h ScoreArgs::ksplit); 0 = one workgroup per tile
   int stream_tail = 1;          // host entry points with more than one batch of queries: deferred tail between their batches
+  int inkernel_repair_max = STREAM_MAX_QUERIES;   // batches up to this size repair a failed query inside the maintain launch
   int stream_lookahead = 0;     // ... and the pre part of batch i + 1 beside the scatter / maintain launches of batch i (no gain)
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
   // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 80
@@ -586,7 +587,7 @@ static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s
     // Round 4, second half: small batches on the asynchronous entry points launch no repair kernels either -- the workgroup
     // of a failed query repairs it inside the maintain launch (repair mode 3, select.hip SCAN: a scan of the shard's stored
     // rows by that one workgroup, ~0.1 s per 1 M rows, once per 10^7 queries).  "device_repair" = 1 still forces the launches.
-    const bool small = nq <= STREAM_MAX_QUERIES;
+    const bool small = nq <= g->inkernel_repair_max;
     const bool repair_pass = g->device_repair < 0 ? !small : g->device_repair != 0;
     const int rep_mode = repair_pass ? 0 : ((small && !caller_checks_flags && g->device_repair < 0) ? 3 : 2);
     const RepairScan scan{g->gal_f32, ws.q_f32, g->dp, g->n};
@@ -2381,6 +2382,7 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "boot_ksplit") *out_value = g->boot_ksplit;
   else if (n == "stream_tail") *out_value = g->stream_tail;
   else if (n == "stream_lookahead") *out_value = g->stream_lookahead;
+  else if (n == "inkernel_repair_max") *out_value = g->inkernel_repair_max;
   else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
@@ -2435,6 +2437,10 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "boot_ksplit") g->boot_ksplit = value != 0;
   else if (n == "stream_tail") g->stream_tail = value != 0;
   else if (n == "stream_lookahead") g->stream_lookahead = value != 0;
+  else if (n == "inkernel_repair_max") {
+    REQUIRE(value >= 0 && value <= QB, "inkernel_repair_max: 0 .. 1024 queries");
+    g->inkernel_repair_max = (int)value;
+  }
   else if (n == "async_tail") {
     REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
     g->async_tail = (int)value;

@@ -313,7 +313,9 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
  * repair -- may differ by an ulp from run to run; the answers do not: the threshold is speculative and verified), "xcc_balance" (XCD shares by measured
  * speed), "stream_tail" (default 1: a HOST entry point called with more than 1024 queries runs its internal batches with the
  * deferred tail of "async_tail" 3 and reads the sticky flags once at the end; 0 = one verified batch after the other),
- * "stream_lookahead" (default 0: such a call also announces every internal batch to its predecessor, see mi_knn_set_lookahead), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
+ * "inkernel_repair_max" (default 128: batches up to this many queries repair a failed speculative threshold inside the maintain
+ * launch on the asynchronous entry points; measured for 1024-query batches: 11 us SLOWER per batch than the three empty repair
+ * launches, the scanning instantiation of the kernel runs at a lower occupancy), "stream_lookahead" (default 0: such a call also announces every internal batch to its predecessor, see mi_knn_set_lookahead), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
