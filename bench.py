@@ -39,6 +39,13 @@ WORKLOADS = {
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 = dense f16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6300.0      # measured float4 copy, same guide
+PG_TIMEOUT_S = 90                # process-group timeout: a rank that never arrives fails the job after this, not after 10 min
+# seconds a block may take before rank 0 prints the line with {"error": "timeout"} for it and the job exits non-zero
+# (ISEHR_BENCH_DEADLINE_S overrides every one of them: tests)
+DEADLINES = {"headline": 420, "synchronous": 120, "cpu_baseline": 240, "row_shard_1xN": 150, "batch_replicas": 150,
+             "scale_10m": 300, "map": 120, "q1": 60, "q70": 60, "aqe_rparis_1m": 150, "qge_small": 120, "dropin": 240,
+             "online": 60, "shutdown": 60}
 
 
 def parse():
@@ -70,12 +77,6 @@ def parse():
                          "bootstrap of batch i+1 only.  Results of every batch are joined inside the timed region.  Default: "
                          "3 for the headline of a one-GPU run with batches of > 128 queries (the line then also carries a "
                          "`synchronous` block, and `roofline` is quoted on ITS undisturbed launches), else 0")
-    ap.add_argument("--lookahead", action="store_true",
-                    help="announce the next batch to every search (mi_knn_set_lookahead): its query ingest / bootstrap / "
-                         "thresholds then run on the handle's own stream beside the previous batch's scatter / maintain "
-                         "launches.  Built and measured in round 4: no gain (the empty repair launch of the previous batch "
-                         "needs a whole CU's LDS and waits for the bootstrap; cross-queue waits cost what the overlap "
-                         "saves) -- an option, off by default")
     ap.add_argument("--calibrate", type=int, default=16,
                     help="scoring launches of mi_gallery_calibrate after the ingest (the XCD shares converge within ~4; the rest "
                          "carries the chip through the 15-20 slow launches that follow the light-load ingest phase, "
@@ -104,6 +105,11 @@ def parse():
                          "synchronous and with pipelined collectives, per-stage timings).  auto: on for the default workload")
     ap.add_argument("--scale-10m-steps", type=int, default=10)
     ap.add_argument("--scale-10m-rows", type=int, default=10000000)
+    ap.add_argument("--extra-blocks", default="auto", choices=["auto", "off"],
+                    help="one GPU, default workload: the blocks that give every BASELINE config a number in the line -- `q70`, `q1` "
+                         "(HBM-bound small batches on the resident gallery), `aqe_rparis_1m` (configs[4]), `qge_small` (the "
+                         "N < 120 000 diffusion branch at rOxford5k size), `dropin` (matching_HIP on a host [D, N] array at "
+                         "BASELINE size: what the reference's entry points call)")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -198,13 +204,90 @@ def cpu_baseline(gallery, q_host, n_total, args):
             "sample": "oracle.knn_flat_ip_blas (numpy sgemm + argpartition, f32) on the first %d gallery rows x %d "
                       "queries, K=%d: %.2f s; scaled by rows" % (ns, full["queries"], args.topk, full["seconds"]),
             "points": points}
+    try:
+        import faiss  # noqa: F401
+        faiss_note = "importable on this box but not timed (the reference pins no version: requirements.txt:4 is commented out)"
+    except Exception as e:
+        faiss_note = "unavailable (%s: BASELINE.md section 3 B3 cannot run; B2 = sgemm + argpartition below is its stand-in)" \
+                     % type(e).__name__
     return {
         "value": qps_sample * ns / n_total, "unit": "queries/s", "cores": 1, "kind": "port", "blas": blas, "aqe": aqe,
+        # the strongest CPU exhaustive baseline beside the one-thread port of the reference's path
+        "value_blas": blas["value"], "cores_blas": blas_threads, "faiss": faiss_note,
         "sample": "oracle.matching_l2 (numpy, f32, single thread like the reference) on the first %d of %d gallery "
                   "rows x %d queries, K=%d: %.2f s; scaled by rows (cost is linear in N)" % (ns, n_total, nqs,
                                                                                             args.topk, dt),
         "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "blas_threads": blas_threads, "numpy": np.__version__,
     }
+
+
+class Emitter:
+    """Rank 0's JSON line and the deadlines of the blocks that fill it.
+
+    The line is written as soon as the headline is measured (`"complete": false`) and again, complete, at the end -- the driver
+    parses the LAST line, so a secondary block that hangs or dies can no longer cost the headline.  Every block runs under a
+    deadline: when it expires, rank 0 writes the line with `{"error": "timeout"}` for that block and EVERY rank leaves with
+    os._exit(3) from its own watchdog thread (the main thread may be inside a collective that will never complete; a launcher
+    sees a non-zero child and ends the others).  Nothing here re-executes a process that touched the GPU."""
+
+    def __init__(self, fd, rank):
+        import threading
+        self.fd, self.rank, self.out = fd, rank, None
+        self._threading = threading
+        self._timer = None
+        self._lock = threading.Lock()
+        self.exit_code = 0
+
+    def write(self, complete):
+        if self.rank != 0 or self.out is None:
+            return
+        with self._lock:
+            self.out["complete"] = bool(complete)
+            os.write(self.fd, (json.dumps(self.out) + "\n").encode())
+
+    def _expire(self, name, seconds):
+        sys.stderr.write("bench.py: block %r exceeded its deadline of %d s on rank %d\n" % (name, seconds, self.rank))
+        sys.stderr.flush()
+        if self.rank == 0:
+            if self.out is None:
+                self.out = {"metric": "queries/sec", "value": None, "unit": "queries/s"}
+            self.out[name if name != "headline" else "headline_error"] = {"error": "timeout", "deadline_s": seconds}
+            self.out["incomplete_because"] = "block %r hit its deadline" % name
+            self.write(False)
+        os._exit(3)
+
+    def deadline(self, name):
+        emitter = self
+        seconds = int(os.environ.get("ISEHR_BENCH_DEADLINE_S", DEADLINES.get(name, 120)))
+
+        class _Ctx:
+            def __enter__(self_):
+                t = emitter._threading.Timer(seconds, emitter._expire, (name, seconds))
+                t.daemon = True
+                emitter._timer = t
+                t.start()
+                return self_
+
+            def __exit__(self_, *exc):
+                emitter._timer.cancel()
+                return False
+        return _Ctx()
+
+    def block(self, name, fn, world, fatal_types=()):
+        """Runs fn() -> value under the block's deadline.  An exception becomes {"error": ...} in the line; with several ranks
+        it also ends the job (exit code 4 after the line is written: a rank that failed alone would leave the others in a
+        collective), with one rank the remaining blocks still run."""
+        try:
+            with self.deadline(name):
+                return fn()
+        except (RuntimeError, AssertionError, MemoryError, SystemExit, ValueError, OSError) as e:
+            sys.stderr.write("bench.py: block %r failed on rank %d: %s: %s\n" % (name, self.rank, type(e).__name__, e))
+            if self.out is not None:
+                self.out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            if world > 1:
+                self.write(False)
+                os._exit(4)
+            return None
 
 
 class Job:
@@ -221,23 +304,41 @@ class Job:
         # (RCCL refuses two ranks on one device); the real run is one rank per GPU over RCCL.
         self.backend = os.environ.get("ISEHR_DIST_BACKEND", "nccl")
         self.dev_index = 0 if os.environ.get("ISEHR_SHARE_GPU") == "1" else local_rank
+        from datetime import timedelta
         torch.cuda.set_device(self.dev_index)
+        pg_timeout = timedelta(seconds=int(os.environ.get("ISEHR_BENCH_PG_TIMEOUT_S", PG_TIMEOUT_S)))
         if self.world > 1:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index), timeout=pg_timeout)
             else:
-                dist.init_process_group(self.backend)
+                dist.init_process_group(self.backend, timeout=pg_timeout)
         if self.world == 1 and args.force_protocol:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29571")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", self.dev_index))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", self.dev_index),
+                                    timeout=pg_timeout)
         self.dev = torch.device("cuda", self.dev_index)
         self.stream = torch.cuda.current_stream().cuda_stream
         # what the communicator itself says (the answer to "did RCCL see N ranks")
         self.comm_ranks = dist.get_world_size() if dist.is_initialized() else 1
         self.comm_backend = dist.get_backend() if dist.is_initialized() else None
+        # ... and which device every rank really runs on: (host, torch.cuda.current_device(), PCI bus id) of all ranks
+        props = torch.cuda.get_device_properties(self.dev_index)
+        me = (os.uname().nodename, int(torch.cuda.current_device()),
+              str(getattr(props, "pci_bus_id", "")) + ":" + str(getattr(props, "pci_device_id", "")))
+        self.rank_devices = [me]
+        if self.world > 1:
+            got = [None] * self.world
+            dist.all_gather_object(got, me)
+            self.rank_devices = [tuple(x) for x in got]
+        self.devices_distinct = len(set(self.rank_devices)) == len(self.rank_devices)
+        if self.world > 1 and self.backend == "nccl" and os.environ.get("ISEHR_SHARE_GPU") != "1":
+            if self.comm_ranks != args.gpus or not self.devices_distinct:
+                sys.stderr.write("bench.py: %d ranks in the communicator for --gpus %d, devices %r\n"
+                                 % (self.comm_ranks, args.gpus, self.rank_devices))
+                sys.exit(2)
 
     def barrier(self):
         import torch
@@ -287,13 +388,26 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     _lib.synth_fill_device(raw.data_ptr(), args.seed, lo, hi - lo, d, stream)
     torch.cuda.synchronize()
     _lib.set_global_option("image_dtype", 1 if image_dtype == "f16" else 0)
+    alloc_s = None
+    ingest_kernel_s = None
     t0 = time.time()
-    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
-                                       row_offset=lo)
-    torch.cuda.synchronize()
+    if warm_ingest or (hi - lo) * d * 4 <= 16 << 30:
+        gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
+                                           row_offset=lo)
+        torch.cuda.synchronize()
+    else:
+        # large shards (the 10 M-row block: 82 GB of rows -> 123 GB of gallery): allocation and ingest timed apart.  The
+        # allocation is first-touch page-table work for ~123 GB (seconds, differs between boxes by a factor of ten); the
+        # ingest kernel is the same persistent kernel as above
+        gal = _lib.Gallery.empty(hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index, row_offset=lo)
+        torch.cuda.synchronize()
+        alloc_s = time.time() - t0
+        t1 = time.time()
+        gal.append_device(raw.data_ptr(), hi - lo, stream)
+        torch.cuda.synchronize()
+        ingest_kernel_s = time.time() - t1
     ingest_first_s = time.time() - t0
     ingest_s = ingest_first_s
-    ingest_kernel_s = None
     if warm_ingest:
         # the first ingest of a process also initialises the library (code objects, workspaces): the reference-style
         # per-call normalisation (matching_L2 normalises the gallery inside its timer, src/utils/nnsearch.py:688-705) is
@@ -341,12 +455,8 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
         gal.set_option("async_tail", async_tail)
     last = {}
 
-    # --lookahead: the next batch is announced to every search (mi_knn_set_lookahead: its query ingest / bootstrap / thresholds
-    # run beside this batch's scatter / maintain launches).  Single shard, plain search only
-    lookahead = world == 1 and not with_aqe and not sg._protocol and args.lookahead
-
-    def one_step(qb, nxt=None):
-        idx_, sc_ = sg.search(qb, k, join=not pipelined or with_aqe, next_q=nxt if lookahead else None)
+    def one_step(qb):
+        idx_, sc_ = sg.search(qb, k, join=not pipelined or with_aqe)
         last["q"] = qb
         if with_aqe:
             # ranks[K,Q] view of the [Q,K] result, like `ranks = match_idx.T` (src/test_rOP1m.py:157) -> QGE (N >= 120000)
@@ -358,7 +468,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     def run_eager(count):
         out_ = None
         for i in range(count):
-            out_ = one_step(pool[i % len(pool)], pool[(i + 1) % len(pool)] if i + 1 < count else None)
+            out_ = one_step(pool[i % len(pool)])
         return out_
 
     def run_stream(count):
@@ -438,7 +548,8 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     else:
         overflow = st["overflow_batches"] + st["spec_retries"]
 
-    # result sanity on the last batch (size-independent properties; the oracle cannot run at this size)
+    # result sanity on the last batch (size-independent properties here; the oracle itself checks the full size in tests/:
+    # test_gpu_full_size.py scores 8 queries against all rows in float64 on the host)
     worst = None
     dense_check = None
     if check:
@@ -488,8 +599,8 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
                job_steps=job_steps,
-               ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, worst=worst,
-               use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check, lookahead=lookahead,
+               ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, alloc_s=alloc_s, worst=worst,
+               use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check,
                protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
 
     if also_stream and sg._protocol and not use_stream and not with_aqe:
@@ -541,14 +652,13 @@ def synchronous_block(job, gal, args, steps):
     gal.set_option("async_tail", 0)
     gal.status(reset=True)
     out_ = None
-    la = args.lookahead
     for i in range(20):
-        out_ = sg.search(pool[i % 4], k, next_q=pool[(i + 1) % 4] if la else None)
+        out_ = sg.search(pool[i % 4], k)
     torch.cuda.synchronize()
     gal.profile(True)
     t0 = time.perf_counter()
     for i in range(steps):
-        out_ = sg.search(pool[i % 4], k, next_q=pool[(i + 1) % 4] if (la and i + 1 < steps) else None)
+        out_ = sg.search(pool[i % 4], k)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gal.profile(False)
@@ -556,6 +666,271 @@ def synchronous_block(job, gal, args, steps):
     st = gal.status(reset=True)
     same = bool(torch.equal(out_[0], ref[0]) and torch.equal(out_[1], ref[1]))
     return dict(st=st, nq=nq, elapsed=elapsed, steps=steps, launch_ms=lms, equals_pipelined_answer=same)
+
+
+
+def small_batch_block(job, gal, args, nq, steps):
+    """BASELINE.md section 4's small shapes on the gallery already resident: Q = 70 (the reference's own test sets,
+    src/test_rOP1m.py) and Q = 1 (one uploaded image, src/online.py:132-149), HBM-bound: the 16-bit image is streamed once per
+    batch (N * D * 2 bytes) by stream_select_kernel.  Synchronous calls, every step complete when it returns."""
+    import numpy as np
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    d, k, dev, stream = args.dim, args.topk, job.dev, job.stream
+    sg = ShardedGallery(gal)
+    pool = []
+    for i in range(4):
+        qb = torch.empty((nq, d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(qb.data_ptr(), args.seed + 11 + i, 0, nq, d, stream)
+        pool.append(qb)
+    gal.set_option("async_tail", 0)
+    for i in range(10):
+        sg.search(pool[i % 4], k)
+    torch.cuda.synchronize()
+    gal.status(reset=True)
+    gal.profile(True)
+    t0 = time.perf_counter()
+    out_ = None
+    for i in range(steps):
+        out_ = sg.search(pool[i % 4], k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gal.profile(False)
+    lms = [float(v) for v in gal.launch_ms()]
+    st = gal.status(reset=True)
+    m = min(nq, 16)
+    idx_h, sc_h = out_[0][:m].cpu().numpy(), out_[1][:m].cpu().numpy()
+    didx, dsc, _, _ = gal.dense64_search(pool[(steps - 1) % 4][:m].cpu().numpy(), k)
+    assert np.array_equal(idx_h, didx) and float(np.abs(sc_h - dsc).max()) <= 6e-8, "q%d block: dense f64 search disagrees" % nq
+    roof = roofline_of(dict(st=st, nq=nq, elapsed=elapsed, launch_ms=lms), args, 1, False)
+    roof["frac_of_achievable"] = roof["achieved"] / HBM_ACHIEVABLE_GBS if roof["achieved"] else None
+    roof["algorithmic_bytes_per_launch"] = st["gemm_bytes"] / max(1, st["gemm_launches"])
+    whole = (gal.n * d * 2.0 + nq * d * 2.0) * steps / elapsed / 1e9
+    return {"queries_per_step": nq, "steps": steps, "value": nq * steps / elapsed, "unit": "queries/s",
+            "ms_per_step": elapsed / steps * 1e3, "roofline": roof, "whole_step_GBps": whole,
+            "whole_step_frac_of_8TBps": whole / HBM_PEAK_GBS,
+            "flagged_batches": st["overflow_batches"] + st["spec_retries"], "inkernel_repairs": st["inkernel_repairs"],
+            "score_check": "%d queries x %d rows: dense float64 scores + exact top-%d equal the answer" % (m, gal.n, k)}
+
+
+def aqe_rparis_block(job, args):
+    """BASELINE configs[4]: rParis6k + 1M distractors (N = 1 007 323 x 2048), alpha-QE re-ranking as QGE's large-database branch
+    runs it (k = 3, w = 4.0, one iteration: src/utils/Reranking.py:273-283 -> feature_enhancement :195-208): one step = search
+    (K = 100) -> expansion of every query from its top-3 rows (float64 weighted sum, eps-normalised) -> re-search of the
+    expanded queries.  1024-query batches (the tile kernel) and 70 (the reference's query set)."""
+    import numpy as np
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    n, d, k, dev, stream = WORKLOADS["rparis6k+1m"][0], args.dim, args.topk, job.dev, job.stream
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), args.seed + 40, 0, n, d, stream)
+    torch.cuda.synchronize()
+    _lib.set_global_option("image_dtype", 1 if args.image_dtype == "f16" else 0)
+    gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d, norm_mode=_lib.NORM_L2, device=job.dev_index)
+    del raw
+    torch.cuda.empty_cache()
+    out = {"gallery_rows": n, "k_qe": 3, "w": 4.0, "topk": k, "image": args.image_dtype}
+    try:
+        sg = ShardedGallery(gal)
+        gal.calibrate(8, stream)
+        wts = np.array([(3 - j) / 3.0 for j in range(3)], dtype=np.float64) ** 4.0
+        for nq in (1024, 70):
+            pool = []
+            for i in range(2):
+                qb = torch.empty((nq, d), dtype=torch.float32, device=dev)
+                _lib.synth_fill_device(qb.data_ptr(), args.seed + 41 + i, 0, nq, d, stream)
+                pool.append(qb)
+
+            def step(qb):
+                idx1, _ = sg.search(qb, k)
+                return idx1, sg.aqe_search(idx1.t(), 3, 4.0, k)
+            for i in range(3):
+                step(pool[i % 2])
+            torch.cuda.synchronize()
+            gal.status(reset=True)
+            steps = 10
+            t0 = time.perf_counter()
+            for i in range(steps):
+                idx1, (idx2, sc2, qx) = step(pool[i % 2])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            st = gal.status(reset=True)
+            # checks: (i) the expansion of 4 queries recomputed in float64 from the stored rows, (ii) the re-search of 8 expanded
+            # queries against every row in float64 (dense path: no thresholds)
+            idx1_h, qx_h = idx1[:4].cpu().numpy(), qx[:8].cpu().numpy()
+            worst = 0.0
+            for qi in range(4):
+                rows = np.stack([gal.get_rows(int(r), 1)[0] for r in idx1_h[qi, :3]]).astype(np.float64)
+                e = (rows * wts[:, None]).sum(axis=0)
+                e /= (np.linalg.norm(e) + 1e-6)
+                worst = max(worst, float(np.abs(e - qx_h[qi]).max()))
+            assert worst < 1e-6, "alpha-QE expansion differs from the float64 recomputation: %g" % worst
+            didx, dsc, _, _ = gal.dense64_search(qx_h, k)
+            assert np.array_equal(idx2[:8].cpu().numpy(), didx), "alpha-QE re-search: dense f64 search disagrees"
+            assert float(np.abs(sc2[:8].cpu().numpy() - dsc).max()) <= 3e-6
+            out["q%d" % nq] = {"queries_per_step": nq, "steps": steps, "value": nq * steps / el, "unit": "queries/s",
+                               "ms_per_step": el / steps * 1e3,
+                               "flagged_batches": st["overflow_batches"] + st["spec_retries"],
+                               "score_check": "expansion of 4 queries vs float64: max |d| %.1e; re-search of 8 expanded queries "
+                                              "= dense float64 top-%d" % (worst, k)}
+    finally:
+        gal.close()
+        torch.cuda.empty_cache()
+    return out
+
+
+def qge_small_block(args, device):
+    """QGE's small-database branch (N < 120 000, src/utils/Reranking.py:212-264) at rOxford5k size (4993 x 2048, 70 queries,
+    planted dataset of map_block): alpha-QE k = 10, w = 4 -> offline truncated diffusion (kNN graph top-2000, mutual-200
+    affinity, Laplacian, 4993 CG solves; src/utils/diffusion.py:52-116) -> online combination with the expanded queries
+    (k_query = 3, truncation 2000) -> mAP.  The reference caches the offline stage in offline.jbl; here it is timed."""
+    import numpy as np
+    from isehr_amd import evaluate
+    from isehr_amd.diffusion import Diffusion
+    from isehr_amd.nnsearch import matching_HIP
+    from isehr_amd.reranking import feature_enhancement_hip
+    n = 4993
+    vecs, qv, gnd = _planted(args, n)
+    idx, _ = matching_HIP(args.topk, vecs.T, qv.T, device=device)
+    ranks = idx.T
+    t0 = time.time()
+    qx, ranks_aqe = feature_enhancement_hip(10, ranks, vecs, 4.0, 1000, None, False, device)
+    aqe_s = time.time() - t0
+    trunc, kd = 2000, 200
+    t0 = time.time()
+    dif = Diffusion(np.ascontiguousarray(vecs.T), None, device)
+    try:
+        build_s = time.time() - t0
+        t0 = time.time()
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            dif.get_offline_results(trunc, kd)
+        offline_s = time.time() - t0
+        dif.search_online(qx.T, 3, trunc)                         # warm
+        t0 = time.time()
+        reps = 5
+        for _ in range(reps):
+            ranks_dfs, scores = dif.search_online(qx.T, 3, trunc)
+        online_s = (time.time() - t0) / reps
+    finally:
+        dif.close()
+    assert ranks_dfs.shape == (trunc, 70) and (np.diff(scores, axis=1) <= 0).all(), "diffusion scores not sorted"
+    assert all(len(set(ranks_dfs[:, i])) == trunc for i in range(0, 70, 7)), "duplicate ids in a diffusion ranking"
+    m0 = evaluate.compute_map_revisited(ranks, gnd)
+    m1 = evaluate.compute_map_revisited(ranks_aqe[:args.topk], gnd)
+    m2 = evaluate.compute_map_revisited(ranks_dfs, gnd)
+    return {"gallery_rows": n, "queries": 70, "truncation": trunc, "k_gallery": kd, "k_query": 3,
+            "alpha_qe_s": round(aqe_s, 4), "gallery_prepare_s": round(build_s, 4), "offline_diffusion_s": round(offline_s, 3),
+            "online_s_per_70_queries": round(online_s, 5), "online_value": 70 / online_s, "unit": "queries/s",
+            "map": {"search": {"E": m0[0], "M": m0[1], "H": m0[2]}, "alpha_qe": {"E": m1[0], "M": m1[1], "H": m1[2]},
+                    "diffusion": {"E": m2[0], "M": m2[1], "H": m2[2]}},
+            "_ranks_aqe": ranks_aqe[:args.topk],
+            "score_check": "rankings sorted and duplicate-free; mAP of the alpha-QE ranks equals the oracle's "
+                           "feature_enhancement (cpu_baseline leg)"}
+
+
+def cpu_baseline_qge(args, rec):
+    """cpu_baseline leg: the oracle's feature_enhancement (k = 10, w = 4) on the planted rOxford5k-sized dataset; the mAP of
+    the HIP alpha-QE ranks must equal the mAP of the oracle's."""
+    import oracle
+    vecs, qv, gnd = _planted(args, 4993)
+    ref = oracle.matching_l2(args.topk, vecs.T, qv.T)
+    t0 = time.time()
+    _, ranks_o = oracle.feature_enhancement(10, ref.T, vecs, 4.0)
+    rec["alpha_qe_oracle_s"] = round(time.time() - t0, 3)
+    mo = oracle.compute_map_revisited(ranks_o[:args.topk], gnd)
+    got = rec.pop("_ranks_aqe")
+    mh = oracle.compute_map_revisited(got, gnd)
+    rec["max_abs_map_difference_alpha_qe"] = float(max(abs(a - b) for a, b in zip(mh, mo)))
+    assert rec["max_abs_map_difference_alpha_qe"] <= 1e-6, "alpha-QE mAP differs from the oracle's"
+
+
+def pinned_h2d_rate(torch, nbytes=1 << 30):
+    """GB/s of a pinned host -> device copy on this box (the roof of any call that takes a host gallery)."""
+    pinned = torch.empty(nbytes // 4, dtype=torch.float32, pin_memory=True)
+    pinned.fill_(1.0)
+    dev = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    del pinned, dev
+    return nbytes / best / 1e9
+
+
+def dropin_block(job, args):
+    """The call the reference's entry points make (src/test_rOP1m.py:136-139,155-159; src/offline.py:107-118; src/online.py:95-102,
+    132): `matching_<method>(K, vecs.T, qvecs.T[, dataset])` with `vecs` a HOST [D, N] array -- float32 at BASELINE size
+    (2048 x 1 005 994: 8.2 GB over PCIe, then the [D, N]-layout ingest kernel), and the float64 case of src/online.py:96 at
+    131 072 columns -- and the `time_per_query` it returns: stateless, stateful first call (build; the prepared-gallery file is
+    written behind the call), stateful cached, and from the file in a fresh cache."""
+    import shutil
+    import numpy as np
+    import torch
+    from isehr_amd import _lib, nnsearch
+    d, n, nq, k, stream = args.dim, WORKLOADS["roxford5k+1m"][0], 70, args.topk, job.stream
+    rate = pinned_h2d_rate(torch)
+    vecs = np.empty((d, n), dtype=np.float32)
+    blk = 131072
+    for r0 in range(0, n, blk):
+        m = min(blk, n - r0)
+        raw = torch.empty((m, d), dtype=torch.float32, device=job.dev)
+        _lib.synth_fill_device(raw.data_ptr(), args.seed, r0, m, d, stream)
+        vecs[:, r0:r0 + m] = raw.t().contiguous().cpu().numpy()
+    qraw = torch.empty((nq, d), dtype=torch.float32, device=job.dev)
+    _lib.synth_fill_device(qraw.data_ptr(), args.seed + 1, 0, nq, d, stream)
+    qvecs = np.ascontiguousarray(qraw.t().cpu().numpy())
+    del raw, qraw
+    torch.cuda.empty_cache()
+    _lib.set_global_option("image_dtype", 1 if args.image_dtype == "f16" else 0)
+    ds = "bench_dropin"
+    shutil.rmtree(os.path.join("outputs", ds), ignore_errors=True)
+    calls = {}
+
+    def call(name, **kw):
+        t0 = time.time()
+        idx, tpq = nnsearch.matching_HIP(k, vecs.T, qvecs.T, **kw)
+        calls[name] = {"time_per_query_s": tpq, "wall_s": time.time() - t0, "gallery": dict(nnsearch.last_timing)}
+        return idx
+    try:
+        i0 = call("stateless_first")
+        i1 = call("stateless")
+        i2 = call("dataset_first_call", dataset=ds, ifgenerate=True)
+        i3 = call("dataset_cached", dataset=ds)
+        t0 = time.time()
+        nnsearch.wait_for_saves()
+        save_wait = time.time() - t0
+        calls["dataset_first_call"]["file_written_behind_the_call"] = dict(nnsearch.last_timing.get("save") or {},
+                                                                         waited_s_after_the_calls=save_wait)
+        nnsearch.drop_cached_galleries()
+        i4 = call("dataset_from_file", dataset=ds)
+        nnsearch.drop_cached_galleries()
+        same = bool(all(np.array_equal(i0, x) for x in (i1, i2, i3, i4)))
+        v64 = vecs[:, :131072].astype(np.float64)
+        q64 = qvecs.astype(np.float64)
+        nnsearch.matching_HIP(k, v64.T, q64.T)
+        t0 = time.time()
+        i64, tpq64 = nnsearch.matching_HIP(k, v64.T, q64.T)
+        f64 = {"columns": 131072, "bytes": int(v64.nbytes), "time_per_query_s": tpq64, "wall_s": time.time() - t0,
+               "h2d_equivalent_GBps": v64.nbytes / (tpq64 * nq) / 1e9,
+               "equals_f32_answer_of_the_same_rows": bool(np.array_equal(
+                   i64, nnsearch.matching_HIP(k, vecs[:, :131072].T, qvecs.T)[0]))}
+    finally:
+        nnsearch.drop_cached_galleries()
+        shutil.rmtree(os.path.join("outputs", ds), ignore_errors=True)
+    st = calls["stateless"]
+    return {"layout": "host float32 [D, N] = [2048, %d], passed as vecs.T (row stride 1, column stride N)" % n,
+            "queries": nq, "topk": k, "bytes": int(vecs.nbytes), "pinned_h2d_GBps": rate,
+            "stateless_h2d_equivalent_GBps": vecs.nbytes / st["wall_s"] / 1e9,
+            "stateless_frac_of_pinned_h2d": vecs.nbytes / st["wall_s"] / 1e9 / rate,
+            "calls": calls, "same_answers": same, "float64_online_case": f64}
 
 
 MAP_DATASETS = (("roxford5k-sized (configs[0])", 4993), ("roxford5k+rparis6k-sized (configs[1])", 4993 + 6322))
@@ -646,6 +1021,44 @@ def roofline_of(res, args, world, with_traffic):
     return roof
 
 
+def selftest_main(args, json_fd):
+    """ISEHR_BENCH_SELFTEST=1 (tests/test_bench_cli_cpu.py, no GPU): the rank-process plumbing of main() -- process group with
+    its timeout, the early headline line, a secondary block under its deadline, the exit codes -- over gloo on the CPU, with
+    a stand-in workload (one all-reduce).  ISEHR_BENCH_TEST_HANG="<block>:<rank>" makes that rank sleep inside that block."""
+    from datetime import timedelta
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    emitter = Emitter(json_fd, rank)
+    with emitter.deadline("headline"):
+        if world > 1:
+            dist.init_process_group("gloo", timeout=timedelta(seconds=int(os.environ.get("ISEHR_BENCH_PG_TIMEOUT_S",
+                                                                                           PG_TIMEOUT_S))))
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+        out = {"metric": "queries/sec", "value": float(t.item()), "unit": "queries/s", "n_gpus": world, "selftest": True,
+               "config": {"rccl_ranks": dist.get_world_size() if world > 1 else 1}} if rank == 0 else None
+        emitter.out = out
+        emitter.write(False)
+    hang = os.environ.get("ISEHR_BENCH_TEST_HANG", "")
+
+    def blk():
+        if hang == "row_shard_1xN:%d" % rank:
+            time.sleep(3600)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            out["row_shard_1xN"] = {"value": 1.0}
+    emitter.block("row_shard_1xN", blk, world)
+    emitter.write(True)
+    if world > 1:
+        with emitter.deadline("shutdown"):
+            dist.barrier()
+            dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -664,11 +1077,15 @@ def main():
     # dmabuf IPC for RCCL / device-memory sharing between rank processes: the runtime reads this when it initialises, i.e.
     # before anything below touches the GPU (a launcher's environment normally carries it already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("ISEHR_BENCH_SELFTEST") == "1":
+        return selftest_main(args, json_fd)
     import torch  # noqa: F401
     import torch.distributed as dist
     import isehr_amd  # noqa: F401
 
-    job = Job(args)
+    emitter = Emitter(json_fd, int(os.environ.get("RANK", "0")))
+    with emitter.deadline("headline"):
+        job = Job(args)
     world, rank = job.world, job.rank
     n_total = args.rows or WORKLOADS[args.workload][0]
     d, k = args.dim, args.topk
@@ -680,76 +1097,94 @@ def main():
     auto_tail = args.async_tail is None
     async_tail = (3 if (world == 1 and args.queries > 128 and plain) else 0) if auto_tail else args.async_tail
     args.async_tail = async_tail
+    # the blocks beyond the headline that make the default one-GPU line cover every BASELINE config
+    extra_blocks = world == 1 and default_shape and plain and not args.diagnostic and args.extra_blocks != "off"
 
-    res = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, args.layout,
-                       with_aqe=args.with_aqe, async_tail=async_tail, pipeline=args.pipeline, options=args.option,
-                       check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True, graph=args.graph,
-                       also_stream=(world > 1 and plain), phases=(10 if world > 1 or args.force_protocol else 0))
-    gal = res.pop("gal")
-    q_last_pool = res.pop("q_last_pool")
-    out = None
+    with emitter.deadline("headline"):
+        res = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, args.layout,
+                           with_aqe=args.with_aqe, async_tail=async_tail, pipeline=args.pipeline, options=args.option,
+                           check=not args.diagnostic, warm_ingest=(n_total * d * 4 <= 16 << 30), keep=True, graph=args.graph,
+                           also_stream=(world > 1 and plain), phases=(10 if world > 1 or args.force_protocol else 0))
+        gal = res.pop("gal")
+        q_last_pool = res.pop("q_last_pool")
+        out = None
+        if rank == 0:
+            elapsed, st, nq, gq, gs = res["elapsed"], res["st"], res["nq"], res["gq"], res["gs"]
+            ms_step = elapsed / args.steps * 1e3
+            roof = roofline_of(res, args, world, with_traffic=default_shape and world == 1)
+            out = {
+                "metric": "queries/sec", "value": args.queries * args.steps / elapsed, "unit": "queries/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.image_dtype,
+                "data": "synthetic",
+                "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
+                           "gallery_rows": n_total, "dim": d, "queries_per_step": args.queries, "topk": k,
+                           "rccl_ranks": job.comm_ranks, "comm_backend": job.comm_backend,
+                           "parallelism": ("row-shard x%d" % world if gq == 1 else
+                                           "%d query groups (%d queries of every batch each, no exchange between groups) x %d "
+                                           "row shards per group" % (gq, nq, gs)) +
+                                          (" (two-phase protocol over RCCL forced on one rank)"
+                                           if args.force_protocol and world == 1 else ""),
+                           "alpha_qe": bool(args.with_aqe),
+                           "launch": "hipGraph replay of the per-batch launch sequence" if res["graph"] else "eager",
+                           "collectives": ("asynchronous, three batches in flight (search_stream)" if res["use_stream"] else
+                                           "synchronous per batch") if res["protocol"] else None,
+                           "value_mode": ("pipelined: deferred tail (async_tail 3), every result joined inside the timed region; "
+                                          "`synchronous` holds the same steps with the tail on the caller's stream, and "
+                                          "`roofline` is quoted on those undisturbed launches") if res["pipelined"] and auto_tail
+                                         else ("pipelined (async_tail %d)" % async_tail if res["pipelined"] else "synchronous"),
+                           "tail": ({1: "re-score + sort of batch i on the handle's own stream from the end of its phase 1: beside "
+                                        "the query ingest, bootstrap AND scoring launch of batch i+1",
+                                     2: "re-score + sort of batch i on the handle's own stream beside the query ingest + "
+                                        "bootstrap of batch i+1 only; its scoring launch waits for the tail",
+                                     3: "deferred: re-score + sort of batch i enqueued by the call of batch i+1 right before "
+                                        "its scoring launch, and runs beside that launch only"}[async_tail] +
+                                    "; every result joined inside the timed region") if res["pipelined"] else "same stream",
+                           "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
+                           "calibrate_launches": args.calibrate,
+                           # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
+                           # ingest_s = one normalisation + layout pass over the resident raw rows in a warm process (the second
+                           # ingest of this run; the first one, which also initialises the library, is ingest_first_s), and the
+                           # rate of ONE call that prepares the gallery and answers one batch
+                           "ingest_s": round(res["ingest_s"], 4), "ingest_first_s": round(res["ingest_first_s"], 3),
+                           "ingest_kernel_s": round(res["ingest_kernel_s"], 5) if res["ingest_kernel_s"] else None,
+                           "queries_per_s_incl_gallery_ingest_per_call_of_one_batch": nq / (ms_step * 1e-3 + res["ingest_s"]),
+                           "candidates_per_query": st["candidates"] / max(1, st["queries"]),
+                           "survivors_per_query": st["survivors"] / max(1, st["queries"]),
+                           "score_check": ("16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"
+                                           % (k, res["worst"], res["dense_check"])) if not args.diagnostic else None},
+                "roofline": roof,
+            }
+        emitter.out = out
+        # THE HEADLINE IS SAFE FROM HERE ON: the line goes out now and again, complete, at the end (the driver reads the last one)
+        if out is not None:
+            out["config"]["rank_devices"] = [list(x) for x in job.rank_devices]
+            out["config"]["rank_devices_distinct"] = job.devices_distinct
+            out["config"]["rccl_ranks_equal_n_gpus"] = job.comm_ranks == args.gpus
+            out["blocks_after_the_headline"] = "each under a deadline; {\"error\": \"timeout\"} + a non-zero exit if one hangs"
+        emitter.write(False)
+
+    selftest_hang = os.environ.get("ISEHR_BENCH_TEST_HANG", "")      # "<block>:<rank>": that rank sleeps in that block (tests)
+
+    def maybe_hang(name):
+        if selftest_hang == "%s:%d" % (name, rank):
+            time.sleep(3600)
+
     if rank == 0:
-        elapsed, st, nq, gq, gs = res["elapsed"], res["st"], res["nq"], res["gq"], res["gs"]
-        ms_step = elapsed / args.steps * 1e3
-        roof = roofline_of(res, args, world, with_traffic=default_shape and world == 1)
-        out = {
-            "metric": "queries/sec", "value": args.queries * args.steps / elapsed, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.image_dtype,
-            "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload][1] if not args.rows else "synthetic gallery",
-                       "gallery_rows": n_total, "dim": d, "queries_per_step": args.queries, "topk": k,
-                       "rccl_ranks": job.comm_ranks, "comm_backend": job.comm_backend,
-                       "parallelism": ("row-shard x%d" % world if gq == 1 else
-                                       "%d query groups (%d queries of every batch each, no exchange between groups) x %d "
-                                       "row shards per group" % (gq, nq, gs)) +
-                                      (" (two-phase protocol over RCCL forced on one rank)"
-                                       if args.force_protocol and world == 1 else ""),
-                       "alpha_qe": bool(args.with_aqe),
-                       "launch": "hipGraph replay of the per-batch launch sequence" if res["graph"] else "eager",
-                       "collectives": ("asynchronous, three batches in flight (search_stream)" if res["use_stream"] else
-                                       "synchronous per batch") if res["protocol"] else None,
-                       "value_mode": ("pipelined: deferred tail (async_tail 3), every result joined inside the timed region; "
-                                      "`synchronous` holds the same steps with the tail on the caller's stream, and "
-                                      "`roofline` is quoted on those undisturbed launches") if res["pipelined"] and auto_tail
-                                     else ("pipelined (async_tail %d)" % async_tail if res["pipelined"] else "synchronous"),
-                       "tail": ({1: "re-score + sort of batch i on the handle's own stream from the end of its phase 1: beside "
-                                    "the query ingest, bootstrap AND scoring launch of batch i+1",
-                                 2: "re-score + sort of batch i on the handle's own stream beside the query ingest + "
-                                    "bootstrap of batch i+1 only; its scoring launch waits for the tail",
-                                 3: "deferred: re-score + sort of batch i enqueued by the call of batch i+1 right before "
-                                    "its scoring launch, and runs beside that launch only"}[async_tail] +
-                                "; every result joined inside the timed region") if res["pipelined"] else "same stream",
-                       "exact": "%s MFMA filter + f64 re-score certificate" % args.image_dtype,
-                       "calibrate_launches": args.calibrate,
-                       "lookahead": ("the next batch is announced to every search: its query ingest, bootstrap and thresholds "
-                                     "run beside the previous batch's scatter / maintain launches (mi_knn_set_lookahead)")
-                                    if res["lookahead"] else None,
-                       # matching_L2's own timer spans the normalisation of the gallery too (src/utils/nnsearch.py:688-705):
-                       # ingest_s = one normalisation + layout pass over the resident raw rows in a warm process (the second
-                       # ingest of this run; the first one, which also initialises the library, is ingest_first_s), and the
-                       # rate of ONE call that prepares the gallery and answers one batch
-                       "ingest_s": round(res["ingest_s"], 4), "ingest_first_s": round(res["ingest_first_s"], 3),
-                       "ingest_kernel_s": round(res["ingest_kernel_s"], 5) if res["ingest_kernel_s"] else None,
-                       "queries_per_s_incl_gallery_ingest_per_call_of_one_batch": nq / (ms_step * 1e-3 + res["ingest_s"]),
-                       "candidates_per_query": st["candidates"] / max(1, st["queries"]),
-                       "survivors_per_query": st["survivors"] / max(1, st["queries"]),
-                       "score_check": ("16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"
-                                       % (k, res["worst"], res["dense_check"])) if not args.diagnostic else None},
-            "roofline": roof,
-        }
         if res.get("stream"):
             out["pipelined_collectives"] = res["stream"]
         if res.get("phases"):
             out["protocol_phases_ms_max_over_ranks"] = res["phases"]
-        if world == 1 and res["pipelined"] and auto_tail:
-            # the same steps with the tail on the caller's stream: the undisturbed scoring launch (roofline) and what the
-            # synchronous mode delivers on this box
+    if world == 1 and res["pipelined"] and auto_tail:
+        # the same steps with the tail on the caller's stream: the undisturbed scoring launch (roofline) and what the
+        # synchronous mode delivers on this box
+        def sync_block():
             sb = synchronous_block(job, gal, args, args.steps)
             roof_sync = roofline_of(sb, args, world, with_traffic=default_shape)
             roof_sync["measured_on"] = ("`synchronous` block: %d steps on the same gallery with the tail on the caller's "
                                         "stream (the launch runs undisturbed); the headline's launches, which share the "
                                         "device with the deferred tail, are under `pipelined`" % sb["steps"])
+            roof = out["roofline"]
             roof_sync["pipelined"] = {kk: roof[kk] for kk in ("achieved", "frac", "avg_launch_ms", "kernel_share_of_step",
                                                              "launches", "launch_ms_first5", "launch_ms_last5",
                                                              "in_kernel_clock_mhz", "frac_at_clock") if kk in roof}
@@ -760,82 +1195,122 @@ def main():
                                   "kernel_share_of_step": roof_sync["kernel_share_of_step"],
                                   "equals_pipelined_answer": sb["equals_pipelined_answer"],
                                   "flagged_batches": sb["st"]["overflow_batches"] + sb["st"]["spec_retries"]}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gal, q_last_pool.cpu().numpy(), n_total, args)
+            # like-for-like with the records of rounds 1-3, whose `value` was this mode
+            out["value_synchronous"] = out["synchronous"]["value"]
+        emitter.block("synchronous", sync_block, world)
+    elif rank == 0 and not res["pipelined"]:
+        out["value_synchronous"] = out["value"]
+    if extra_blocks:
+        for nq_small, name in ((70, "q70"), (1, "q1")):
+            r = emitter.block(name, lambda nq_small=nq_small: small_batch_block(job, gal, args, nq_small, 100), world)
+            if r is not None:
+                out[name] = r
+    if world == 1 and not args.no_cpu_baseline:
+        r = emitter.block("cpu_baseline", lambda: cpu_baseline(gal, q_last_pool.cpu().numpy(), n_total, args), world)
+        if r is not None:
+            out["cpu_baseline"] = r
+            out["vs_cpu_baseline"] = {"port_one_thread": out["value"] / r["value"],
+                                      "blas_full_width": out["value"] / r["value_blas"]}
     gal.close()
     del gal, q_last_pool
     torch.cuda.empty_cache()
+    emitter.write(False)
 
-    if world > 1 and plain and (args.multi_gpu_blocks == "on" or (args.multi_gpu_blocks == "auto" and default_shape)):
+    multi = world > 1 and plain and (args.multi_gpu_blocks == "on" or (args.multi_gpu_blocks == "auto" and default_shape))
+    if multi:
         # north_star's literal partition on the benchmarked gallery: row shards only (1 x N), every rank scores all queries
         # against its rows, two all-gathers per batch -- synchronous and with the pipelined collectives, plus what every
         # stage of the protocol costs (events behind every stage, maxima over the ranks)
-        r1 = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, "1x%d" % world, check=True,
-                          keep=False, also_stream=True, phases=10)
-        if rank == 0:
-            rf = roofline_of(r1, args, world, with_traffic=False)
-            out["row_shard_1xN"] = {
-                "parallelism": "row-shard x%d (two-phase protocol, RCCL all-gathers of the per-shard top-K)" % world,
-                "value": args.queries * r1["steps"] / r1["elapsed"], "unit": "queries/s", "steps": r1["steps"],
-                "ms_per_step": r1["elapsed"] / r1["steps"] * 1e3, "scoring_frac_of_mfma_peak": rf["frac"],
-                "scoring_share_of_step": rf["kernel_share_of_step"], "pipelined_collectives": r1.get("stream"),
-                "protocol_phases_ms_max_over_ranks": r1.get("phases"), "score_check": r1["dense_check"]}
+        def row_shards():
+            maybe_hang("row_shard_1xN")
+            r1 = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, "1x%d" % world,
+                              check=True, keep=False, also_stream=True, phases=10)
+            if rank == 0:
+                rf = roofline_of(r1, args, world, with_traffic=False)
+                out["row_shard_1xN"] = {
+                    "parallelism": "row-shard x%d (two-phase protocol, RCCL all-gathers of the per-shard top-K)" % world,
+                    "value": args.queries * r1["steps"] / r1["elapsed"], "unit": "queries/s", "steps": r1["steps"],
+                    "ms_per_step": r1["elapsed"] / r1["steps"] * 1e3, "scoring_frac_of_mfma_peak": rf["frac"],
+                    "scoring_share_of_step": rf["kernel_share_of_step"], "pipelined_collectives": r1.get("stream"),
+                    "protocol_phases_ms_max_over_ranks": r1.get("phases"), "score_check": r1["dense_check"]}
+        emitter.block("row_shard_1xN", row_shards, world)
+        emitter.write(False)
 
-    if world > 1 and plain and (args.multi_gpu_blocks == "on" or (args.multi_gpu_blocks == "auto" and default_shape)):
         # and the layout a deployment would pick for a gallery that fits one GPU (12 GB of 288): every rank holds ALL rows and
         # the job's batches are dealt to the ranks, each answered by the one-GPU pipeline (deferred tail), nothing exchanged
-        rr = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, "replicas", check=True,
-                          keep=False, async_tail=3 if args.queries > 128 else 0)
-        if rank == 0:
-            out["batch_replicas"] = {
-                "parallelism": "%d replicas of the whole gallery; batch i of the job is answered by rank i mod %d with the "
-                               "one-GPU pipeline; no collective on the search path" % (world, world),
-                "value": args.queries * rr["job_steps"] / rr["elapsed"], "unit": "queries/s", "steps": rr["job_steps"],
-                "steps_of_rank_0": rr["steps"], "ms_per_step": rr["elapsed"] / rr["job_steps"] * 1e3,
-                "score_check": rr["dense_check"]}
+        def replicas():
+            maybe_hang("batch_replicas")
+            rr = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, "replicas", check=True,
+                              keep=False, async_tail=3 if args.queries > 128 else 0)
+            if rank == 0:
+                out["batch_replicas"] = {
+                    "parallelism": "%d replicas of the whole gallery; batch i of the job is answered by rank i mod %d with the "
+                                   "one-GPU pipeline; no collective on the search path" % (world, world),
+                    "value": args.queries * rr["job_steps"] / rr["elapsed"], "unit": "queries/s", "steps": rr["job_steps"],
+                    "steps_of_rank_0": rr["steps"], "ms_per_step": rr["elapsed"] / rr["job_steps"] * 1e3,
+                    "score_check": rr["dense_check"]}
+        emitter.block("batch_replicas", replicas, world)
+        emitter.write(False)
 
     if scale_10m:
         # BASELINE configs[3]: 10 M x 2048 rows, bf16 image, 1024-query batches, row-sharded over the job's ranks
         # (1 x N: every rank scores all queries against its rows; the two all-gathers of the protocol per batch)
-        r10 = None
-        try:
+        def ten_million():
+            maybe_hang("scale_10m")
             r10 = run_workload(job, args.scale_10m_rows, 1024, "bf16", args.scale_10m_steps, 2, "1x%d" % world,
                                check=True, keep=False, also_stream=world > 1, phases=(5 if world > 1 else 0))
-        except (RuntimeError, AssertionError, MemoryError, SystemExit) as e:
-            # the secondary block must never cost the headline line (one rank: report and go on; several ranks: a rank that
-            # fails alone would leave the others in a collective, so there the error ends the job)
-            if world > 1:
-                raise
-            out["scale_10m"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        if rank == 0 and r10 is not None:
-            roof10 = roofline_of(r10, args, world, with_traffic=False)
-            out["scale_10m"] = {
-                "gallery_rows": r10["n_total"], "rows_per_rank": r10["hi"] - r10["lo"], "image": "bf16",
-                "queries_per_step": 1024, "steps": r10["steps"], "ms_per_step": r10["elapsed"] / r10["steps"] * 1e3,
-                "value": 1024 * r10["steps"] / r10["elapsed"], "unit": "queries/s", "n_gpus": world,
-                "rccl_ranks": job.comm_ranks, "parallelism": "row-shard x%d" % world,
-                "ingest_s": round(r10["ingest_first_s"], 3),
-                "scoring_frac_of_mfma_peak": roof10["frac"], "scoring_share_of_step": roof10["kernel_share_of_step"],
-                "scoring_launches_per_step": r10["st"]["gemm_launches"] / max(1, r10["steps"]),
-                "pipelined_collectives": r10.get("stream"), "protocol_phases_ms_max_over_ranks": r10.get("phases"),
-                "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"
-                               % (k, r10["worst"], r10["dense_check"])}
+            if rank == 0:
+                roof10 = roofline_of(r10, args, world, with_traffic=False)
+                out["scale_10m"] = {
+                    "gallery_rows": r10["n_total"], "rows_per_rank": r10["hi"] - r10["lo"], "image": "bf16",
+                    "queries_per_step": 1024, "steps": r10["steps"], "ms_per_step": r10["elapsed"] / r10["steps"] * 1e3,
+                    "value": 1024 * r10["steps"] / r10["elapsed"], "unit": "queries/s", "n_gpus": world,
+                    "rccl_ranks": job.comm_ranks, "parallelism": "row-shard x%d" % world,
+                    "ingest_s": round(r10["ingest_first_s"], 3),
+                    "ingest_s_is": "first-touch allocation of the gallery's buffers (~123 GB on one GPU: page-table work, "
+                                   "`alloc_s`) + the ingest kernel over the resident rows (`ingest_kernel_s`)"
+                                   if r10.get("alloc_s") is not None else "allocation + ingest kernel of this rank's shard",
+                    "alloc_s": round(r10["alloc_s"], 3) if r10.get("alloc_s") is not None else None,
+                    "ingest_kernel_s": round(r10["ingest_kernel_s"], 4) if r10.get("ingest_kernel_s") is not None else None,
+                    "scoring_frac_of_mfma_peak": roof10["frac"], "scoring_share_of_step": roof10["kernel_share_of_step"],
+                    "scoring_launches_per_step": r10["st"]["gemm_launches"] / max(1, r10["steps"]),
+                    "pipelined_collectives": r10.get("stream"), "protocol_phases_ms_max_over_ranks": r10.get("phases"),
+                    "score_check": "16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"
+                                   % (k, r10["worst"], r10["dense_check"])}
+        emitter.block("scale_10m", ten_million, world)
+        torch.cuda.empty_cache()
+        emitter.write(False)
 
     if rank == 0 and default_shape and plain and not args.diagnostic:
         # the metric's other half: mAP (E / M / H) on planted rOxford5k- / +rParis6k-sized datasets, HIP ranks vs the oracle's
-        try:
+        def map_blk():
             out["map"] = map_block(args, job.dev_index)
             if world == 1 and not args.no_cpu_baseline:
                 cpu_baseline_map(args, out["map"])
-        except (RuntimeError, MemoryError) as e:
-            out["map"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        emitter.block("map", map_blk, 1)
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if extra_blocks:
+        r = emitter.block("aqe_rparis_1m", lambda: aqe_rparis_block(job, args), world)
+        if r is not None:
+            out["aqe_rparis_1m"] = r
+
+        def qge_blk():
+            rec = qge_small_block(args, job.dev_index)
+            if not args.no_cpu_baseline:
+                cpu_baseline_qge(args, rec)
+            rec.pop("_ranks_aqe", None)
+            out["qge_small"] = rec
+        emitter.block("qge_small", qge_blk, world)
+        emitter.write(False)
+        r = emitter.block("dropin", lambda: dropin_block(job, args), world)
+        if r is not None:
+            out["dropin"] = r
+
+    emitter.write(True)
     if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        with emitter.deadline("shutdown"):
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

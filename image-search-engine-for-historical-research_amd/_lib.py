@@ -26,7 +26,7 @@ class SearchStats(C.Structure):
     _fields_ = [("searches", C.c_int64), ("queries", C.c_int64), ("overflow_batches", C.c_int64),
                 ("survivors", C.c_int64), ("candidates", C.c_int64), ("gemm_ms", C.c_double),
                 ("gemm_launches", C.c_int64), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
-                ("kernel_clock_mhz", C.c_double), ("spec_retries", C.c_int64)]
+                ("kernel_clock_mhz", C.c_double), ("spec_retries", C.c_int64), ("inkernel_repairs", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -97,7 +97,6 @@ SIGNATURES = {
     "mi_whiten_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_double, C.c_int, C.c_void_p]),
     "mi_gallery_calibrate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
-    "mi_knn_set_lookahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
     "mi_profile_launch_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -432,11 +431,6 @@ class Gallery:
     def search_device(self, q_ptr, nq, k, idx_ptr, score_ptr=None, score64_ptr=None, stream=None):
         check(load().mi_knn_search_device(self._h, C.c_void_p(q_ptr), nq, k, C.c_void_p(idx_ptr),
                                           C.c_void_p(score_ptr), C.c_void_p(score64_ptr), C.c_void_p(stream)))
-
-    def set_lookahead(self, q_next_ptr, nq_next):
-        """Announces the batch of the NEXT search_device call (mi_knn_set_lookahead): its query ingest / bootstrap / thresholds
-        then run beside the scatter / maintain launches of the call that follows this announcement.  None withdraws."""
-        check(load().mi_knn_set_lookahead(self._h, C.c_void_p(q_next_ptr), nq_next if q_next_ptr else 0))
 
     def phase1_device(self, q_ptr, nq, k, approx_ptr, stream=None):
         check(load().mi_knn_phase1_device(self._h, C.c_void_p(q_ptr), nq, k, C.c_void_p(approx_ptr),

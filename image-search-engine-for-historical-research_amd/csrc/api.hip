@@ -49,7 +49,6 @@ struct Workspace {
   uint32_t* qflag = nullptr;
   float* lad_tc = nullptr;
   uint32_t *lad_pack = nullptr, *lad_cnt = nullptr;
-  uint32_t *lad_pack2 = nullptr, *lad_cnt2 = nullptr, *lad_lev = nullptr;   // second ladder level (option "ladder" = 2)
   uint32_t* cnt = nullptr;
   uint64_t* surv = nullptr;
   uint32_t* flags = nullptr;
@@ -92,7 +91,6 @@ struct P1Plan {
   bool sample_f32 = false;         // the bootstrap launch stores bare 4-byte scores
   bool thr_kernel = false;         // sample_threshold_kernel takes the thresholds (else select_maintain mode 0)
   int32_t lad_r = 0;               // ladder level (sample rank), 0 = off
-  int32_t lad_r2 = 0;              // second, tighter level (option "ladder" = 2), 0 = off
   bool zero_scores = false;        // the query ingest writes zeros for the K-split bootstrap to add onto
 };
 }  // namespace
@@ -119,19 +117,14 @@ struct mi_gallery {
   Workspace ws_alt;
   int ws_slot = 0;
   // options
-  int chunk0_tiles = 0 /* 0 = default, bootstrap_tiles() */, chunk_growth = 8, exact_fallback = 1, force_exact = 0, debug = 0,
+  int chunk0_tiles = 0 /* 0 = default, bootstrap_tiles() */, chunk_growth = 8, exact_fallback = 1, force_exact = 0,
       speculative = 1, rescore_grid_x = 0, spec_max_ratio = 160;
-  int small_tail = 0;           // 1: batches of <= 128 queries re-score and order in ONE launch (select.hip rescore_emit_kernel;
-                                // built, measured slower -- 39 vs 19.5 + 9 us at 70 queries -- and left off)
   int device_repair = -1;       // -1 = by batch size (off for <= 128 queries), 0 / 1 = never / always launch the conditional repair pass
   int small_batch_kernel = 1;   // batches of <= 128 queries are scored by stream_select.hip (HBM-bound kernel)
-  int kernel_variant = 0;       // structure of the tile kernel (gemm_select.hip), for A/B inside one process
   int xcc_balance = 1;          // split the gallery tiles over the XCDs by their measured speed (common.h XccBalance)
-  int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*)
+  int ladder = 1;               // in-launch threshold ladder of the tile kernel (common.h QueryState::lad_*): 0 = off, 1 = on
   int boot_ksplit = 1;          // small batches: K-split bootstrap launch (kernels.h ScoreArgs::ksplit); 0 = one workgroup per tile
   int stream_tail = 1;          // host entry points with more than one batch of queries: deferred tail between their batches
-  int inkernel_repair_max = STREAM_MAX_QUERIES;   // batches up to this size repair a failed query inside the maintain launch
-  int stream_lookahead = 0;     // ... and the pre part of batch i + 1 beside the scatter / maintain launches of batch i (no gain)
   // asynchronous tail (option "async_tail", device entry point mi_knn_search_device only): the exact re-score + emit of a
   // batch run on tail_stream behind an event, beside the scoring launch of the NEXT batch (the tile kernel leaves 80
   // VGPRs per SIMD lane and no LDS: exactly one 70-register re-score wave per SIMD fits next to its two); results are
@@ -155,27 +148,6 @@ struct mi_gallery {
     double* out_score64 = nullptr;
   } pending;
   hipEvent_t ev_pre = nullptr;                // recorded on the caller's stream right before the scoring launch
-  // Lookahead (mi_knn_set_lookahead, and the internal batches of a multi-batch host call): the PRE part of the next batch --
-  // query ingest, bootstrap launch on the sample, thresholds -- is enqueued on pre_stream right behind the scoring launch of
-  // the current batch and runs in the PARKED workspace beside the current batch's scatter / maintain launches: two chains of
-  // small latency-bound launches share the chip instead of following each other.  The next search call finds its batch
-  // prepared, switches the workspaces and goes straight to its scoring launch.
-  struct Lookahead {
-    bool armed = false;                       // a next batch was announced
-    const void* q = nullptr;
-    int32_t nq = 0;
-    int dtype = MI_F32, norm = 0;
-    int64_t rs = 0, cs = 1;
-    int32_t k_cur = 0;                        // k of the search call in progress (the next batch uses the same)
-    bool prepared = false;                    // its pre part is enqueued (in ws_alt, on pre_stream; ev_ready behind it)
-    const void* pq = nullptr;
-    int32_t pnq = 0, pk = 0;
-    int pdtype = MI_F32, pnorm = 0, pset = 0;
-    int64_t prs = 0, pcs = 1;
-    P1Plan plan;
-  } la;
-  hipStream_t pre_stream = nullptr;
-  hipEvent_t ev_scored = nullptr, ev_ready = nullptr;
   int qnorm_override = -1;  // device entry points: normalise queries with this mi_norm instead of the gallery's (-1 = off)
   uint32_t surv_cap = 12288, rescore_cap = 2048;
   // stats
@@ -250,9 +222,6 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(lad_tc, QB);
   A(lad_pack, QB);
   A(lad_cnt, QB);
-  A(lad_pack2, QB);
-  A(lad_cnt2, QB);
-  A(lad_lev, QB);
   A(cnt, (size_t)QB * CNT_STRIDE);
   A(surv, (size_t)QB * ws.cap);
   A(flags, 4);
@@ -262,7 +231,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   A(cand_rows, (size_t)QB * ws.rcap);
   A(cand_cnt, QB);
   A(cand_score, (size_t)QB * ws.rcap);
-  A(stats2, 2 * (size_t)QB);     // per query: (survivors, candidates) accumulators -- one writer each, no atomics
+  A(stats2, 3 * (size_t)QB);     // per query: (survivors, candidates) accumulators, then [2 QB ..) in-kernel repairs -- one writer each, no atomics
   ws.rec_cap = 4096;          // records per wave segment and launch (K = 1000 at 1M rows needs ~1800)
   ws.nseg = gemm_select_grid() * 8;
   A(rec, (size_t)ws.nseg * ws.rec_cap);
@@ -280,7 +249,7 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
 #undef A
   HIPC(hipMemset(ws.flags, 0, 16));
   HIPC(hipMemset(ws.repair, 0, 16));
-  HIPC(hipMemset(ws.stats2, 0, 2 * (size_t)QB * 8));
+  HIPC(hipMemset(ws.stats2, 0, 3 * (size_t)QB * 8));
   HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
   HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
   HIPC(hipMemset(ws.cand_cnt_set[1], 0, (size_t)QB * 4));
@@ -311,9 +280,6 @@ static QueryState make_state(const Workspace& ws) {
   st.lad_tc = ws.lad_tc;
   st.lad_pack = ws.lad_pack;
   st.lad_cnt = ws.lad_cnt;
-  st.lad_pack2 = ws.lad_pack2;
-  st.lad_cnt2 = ws.lad_cnt2;
-  st.lad_lev = ws.lad_lev;
   st.cap = ws.cap;
   return st;
 }
@@ -389,11 +355,10 @@ static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
 }
 
 // ---- phase 1 for one batch (nq <= QB): query ingest, chunked scoring + threshold maintenance ----------
-// Split in three since round 4: a PLAN (pure arithmetic: which schedule, which sample rank), the PRE part -- everything that
-// depends on the queries but not on a finished scoring launch: query ingest, bootstrap launch on the sample image, thresholds --
-// and the MAIN part (scoring launches, scatter, maintain, repair).  The pre part of batch i + 1 can run on the handle's own
-// stream in the OTHER workspace while the main part of batch i finishes (mi_knn_set_lookahead): both are latency-bound
-// chains of small launches that leave most of the chip idle.
+// In three parts: a PLAN (pure arithmetic: which schedule, which sample rank), the PRE part -- everything that depends on the
+// queries but not on a finished scoring launch: query ingest, bootstrap launch on the sample image, thresholds -- and the MAIN
+// part (scoring launches, scatter, maintain, repair).  (Round 4 ran the pre part of batch i + 1 on a stream of its own beside
+// the main part of batch i -- "lookahead": measured at no gain, profiles/r04*_lookahead*; removed in round 5.)
 static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring);
 
 
@@ -425,7 +390,7 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
   pl.thr_kernel = pl.samp_r > 0 && sample_threshold_applies(pl.first_cnt, k, pl.samp_r);
   // small batches on the sample schedule: the bootstrap launch splits K over several workgroups per (sample tile, query
   // group) and adds its partial scores onto zeros that the query ingest writes (ScoreArgs::ksplit)
-  if (pl.samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && g->debug == 0 && pl.thr_kernel && g->dp <= 4096) {
+  if (pl.samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && pl.thr_kernel && g->dp <= 4096) {
     const int64_t wgs = t0 * ((nq + 63) / 64);                       // bootstrap workgroups of a batch of <= 512 queries
     if (nq <= 512)
       while (pl.boot_ksplit < 8 && wgs * pl.boot_ksplit * 2 <= 256 && (g->dp / SLICE_K) % (pl.boot_ksplit * 2) == 0)
@@ -433,7 +398,7 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
   }
   // sample-based schedule with the dedicated threshold kernel: the bootstrap launch (stream_select MODE 2) stores bare
   // 4-byte scores, all that kernel reads (half the bytes written and read back; ScoreArgs::scores_only)
-  pl.sample_f32 = pl.thr_kernel && g->small_batch_kernel && g->debug == 0;
+  pl.sample_f32 = pl.thr_kernel && g->small_batch_kernel;
   // in-launch ladder: a tighter sample order statistic (rank j < r) becomes a rigorous threshold once K rows above it have
   // been counted during the launch.  In units of N / n_s rows: score(j) has expected rank j in the shard and is validated
   // after the fraction lambda / j of the rows (lambda = K n_s / N), so the survivors are ~ (lambda / j) r + (1 - lambda / j) j,
@@ -442,12 +407,6 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
     int32_t lr = (int32_t)std::lround(std::sqrt(lambda * pl.samp_r));
     pl.lad_r = std::max<int32_t>(1, std::min<int32_t>(lr, pl.samp_r - 1));
-    // second rung (option "ladder" = 2; fp16 image only: the LAD2 instantiation): the same rule one level up -- rank
-    // sqrt(lambda * lad_r) < lad_r (2 at N = 1M, K = 100: validated after ~40 % of the rows)
-    if (g->ladder >= 2 && g->img_f16 && pl.lad_r > 1) {
-      const int32_t l2 = (int32_t)std::lround(std::sqrt(lambda * pl.lad_r));
-      pl.lad_r2 = std::max<int32_t>(1, std::min<int32_t>(l2, pl.lad_r - 1));
-    }
   }
   return pl;
 }
@@ -455,7 +414,7 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
 // one scoring launch (+ the scatter of its records) of a phase-1 schedule
 static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, const P1Plan& pl, int64_t tile_from, int64_t ntile,
                             bool first_chunk, const uint32_t* cond, bool profile_it, bool on_sample, bool ladder_on,
-                            hipStream_t s, bool* lookahead_after_launch = nullptr);
+                            hipStream_t s);
 
 // PRE part.  With pl.samp_r > 0: query ingest + per-query state, bootstrap launch on the sample image, thresholds (+ ladder
 // levels).  Otherwise (chunk schedules): the query ingest alone.
@@ -481,7 +440,7 @@ static int p1_pre(mi_gallery* g, Workspace& ws, const P1Plan& pl, const void* q_
     p1_score_launch(g, ws, st, p2, 0, pl.t0, true, nullptr, false, true, false, s);     // bootstrap on the sample image
     if (pl.thr_kernel)
       launch_sample_threshold(st, pl.nq, pl.k, pl.samp_r, pl.first_cnt, s, pl.lad_r, pl.sample_f32 ? 1 : 0,
-                              (pl.sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f, pl.lad_r2);
+                              (pl.sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f);
     else
       launch_select_maintain(st, pl.nq, pl.k, 0, ws.topvals, ws.L, ws.stats2, pl.samp_r, 1, 0, nullptr, s);
   }
@@ -491,7 +450,7 @@ static int p1_pre(mi_gallery* g, Workspace& ws, const P1Plan& pl, const void* q_
 
 static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, const P1Plan& pl, int64_t tile_from, int64_t ntile,
                             bool first_chunk, const uint32_t* cond, bool profile_it, bool on_sample, bool ladder_on,
-                            hipStream_t s, bool* lookahead_after_launch) {
+                            hipStream_t s) {
   const int64_t rows0 = tile_from * TILE, rows1 = std::min<int64_t>(g->n, (tile_from + ntile) * TILE);
   if (pl.exact) {
     ExactArgs a;
@@ -516,16 +475,13 @@ static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, 
   a.nqt = pl.qpad / TILE;
   a.n = on_sample ? ntile * TILE : g->n;
   a.nq = pl.nq;
-  a.debug = g->debug;
   a.small_batch_kernel = g->small_batch_kernel;
-  a.variant = g->kernel_variant;
   a.rec = ws.rec;
   a.rec_cnt = ws.rec_cnt;
   a.rec_cap = ws.rec_cap;
   a.cond = cond;
   a.bal = g->xcc_balance ? ws.bal : nullptr;
   a.lad_k = ladder_on ? pl.k : 0;
-  a.lad2 = (ladder_on && pl.lad_r2 > 0) ? 1 : 0;
   a.scores_only = (on_sample && first_chunk && pl.sample_f32) ? 1 : 0;
   a.ksplit = a.scores_only ? pl.boot_ksplit : 1;
   a.dbg = ws.dbg;
@@ -540,14 +496,11 @@ static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, 
     g->stats.gemm_flops += 2.0 * pl.nq * rows * g->d;
     g->stats.gemm_bytes += rows * g->d * 2.0 + (double)pl.nq * g->d * 2.0;
   }
-  if (lookahead_after_launch) *lookahead_after_launch = true;    // the caller enqueues the next batch's pre part HERE
   if (!first_chunk)
     launch_scatter_records(ws.rec, ws.rec_cnt, ws.rec_cap, ws.nseg, st, cond, s,
                            (g->xcc_balance && !on_sample && !stream_select_applies(a)) ? ws.bal : nullptr, ws.dbg,
                            (uint32_t)ntile, pl.nq);
 }
-
-static int enqueue_lookahead(mi_gallery* g, hipStream_t s);
 
 // MAIN part: the filtered scoring launch(es) with their scatter / maintain launches, the conditional repair pass.
 // fuse_cand: the final maintain launch also writes the candidate lists (single-shard search: its L is the global one).
@@ -570,13 +523,8 @@ static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s
       const int rc = flush_pending_tail(g, s, /*beside_scoring=*/true);
       if (rc != MI_OK) return rc;
     }
-    // every tile, one launch; the pre part of an announced NEXT batch is enqueued right behind it (before this batch's
-    // scatter / maintain launches, with which it then shares the chip)
+    // every tile, one launch
     p1_score_launch(g, ws, st, pl, 0, ntiles, false, nullptr, true, false, pl.lad_r > 0 && pl.thr_kernel, s);
-    if (g->la.armed) {
-      const int rc = enqueue_lookahead(g, s);
-      if (rc != MI_OK) return rc;
-    }
     // repair pass for queries whose speculative threshold failed verification (1e-7 per query): conditional on the device
     // word *ws.repair, i.e. three early-exit launches in the (overwhelmingly) common case, and no host round trip.  Batches
     // of <= 128 queries -- the reference's own shapes, one query online and 70 per test set, where three empty launches
@@ -587,10 +535,10 @@ static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s
     // Round 4, second half: small batches on the asynchronous entry points launch no repair kernels either -- the workgroup
     // of a failed query repairs it inside the maintain launch (repair mode 3, select.hip SCAN: a scan of the shard's stored
     // rows by that one workgroup, ~0.1 s per 1 M rows, once per 10^7 queries).  "device_repair" = 1 still forces the launches.
-    const bool small = nq <= g->inkernel_repair_max;
+    const bool small = nq <= STREAM_MAX_QUERIES;     // (in-kernel repair up to 1024 queries: measured slower, profiles/r04q_*)
     const bool repair_pass = g->device_repair < 0 ? !small : g->device_repair != 0;
     const int rep_mode = repair_pass ? 0 : ((small && !caller_checks_flags && g->device_repair < 0) ? 3 : 2);
-    const RepairScan scan{g->gal_f32, ws.q_f32, g->dp, g->n};
+    const RepairScan scan{g->gal_f32, ws.q_f32, g->dp, g->n, ws.stats2 + 2 * (size_t)QB};
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, rep_mode, nullptr, s, fc_rows, fc_cnt, ws.rcap,
                            rep_mode == 3 ? &scan : nullptr);
     if (repair_pass) {
@@ -655,13 +603,11 @@ static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s
 
 static int phase1_batch(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                         int32_t nq, int32_t k, bool exact, hipStream_t s, bool fuse_cand = false,
-                        bool caller_checks_flags = false, bool pre_done = false) {
+                        bool caller_checks_flags = false) {
   Workspace& ws = g->ws;
-  const P1Plan pl = pre_done ? g->la.plan : plan_phase1(g, ws, nq, k, exact);
-  if (!pre_done) {
-    const int rc = p1_pre(g, ws, pl, q_src, q_dtype, q_rs, q_cs, q_norm, s);
-    if (rc != MI_OK) return rc;
-  }
+  const P1Plan pl = plan_phase1(g, ws, nq, k, exact);
+  const int rc = p1_pre(g, ws, pl, q_src, q_dtype, q_rs, q_cs, q_norm, s);
+  if (rc != MI_OK) return rc;
   return p1_main(g, ws, pl, s, fuse_cand, caller_checks_flags);
 }
 
@@ -673,12 +619,6 @@ static int phase2_batch(mi_gallery* g, int32_t nq, int32_t k, const float* L_dev
   QueryState st = make_state(ws);
   if (!have_cand) launch_select_candidates(st, nq, L_dev, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.stats2, s);
   const uint32_t last_row = (uint32_t)std::max<int64_t>(0, g->n - 1);
-  if (!resident && nq <= STREAM_MAX_QUERIES && g->small_tail) {      // option, off: re-score and final order in one launch
-    launch_rescore_emit(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, last_row, k,
-                        g->row_offset, out_idx, out_score, out_score64, s);
-    HIPC(hipGetLastError());
-    return MI_OK;
-  }
   if (resident) launch_rescore_resident(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
                                         last_row);
   else launch_rescore(g->gal_f32, ws.q_f32, g->dp, nq, ws.cand_rows, ws.cand_cnt, ws.rcap, ws.cand_score, s,
@@ -697,7 +637,7 @@ static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring)
   if (!g->pending.valid) return MI_OK;
   const mi_gallery::PendingTail p = g->pending;
   g->pending.valid = false;
-  Workspace& ws = (p.slot == g->ws_slot) ? g->ws : g->ws_alt;     // the workspace the batch ran in (lookahead alternates them)
+  Workspace& ws = (p.slot == g->ws_slot) ? g->ws : g->ws_alt;     // the workspace the batch ran in (option "workspace_slot")
   float* q_keep = ws.q_f32;
   uint32_t* rows_keep = ws.cand_rows;
   uint32_t* cnt_keep = ws.cand_cnt;
@@ -728,50 +668,6 @@ static int flush_pending_tail(mi_gallery* g, hipStream_t s, bool beside_scoring)
   return rc;
 }
 
-// The pre part of the announced next batch, enqueued on the handle's pre_stream behind the scoring launch that `s` has just
-// received; it runs in the parked workspace.  Skipped (the next call then does its own pre part) when that batch would not
-// take the single-launch sample schedule or the parked workspace does not exist yet.
-static int enqueue_lookahead(mi_gallery* g, hipStream_t s) {
-  mi_gallery::Lookahead& la = g->la;
-  la.armed = false;
-  la.prepared = false;
-  const int32_t k = la.k_cur;
-  Workspace& alt = g->ws_alt;
-  if (la.nq < 1 || la.nq > QB || alt.qcap < QB || alt.kcap < k || alt.cap != g->surv_cap || alt.rcap != g->rescore_cap)
-    return MI_OK;
-  const P1Plan pl = plan_phase1(g, alt, la.nq, k, false);
-  if (!(pl.samp_r > 0 && pl.thr_kernel)) return MI_OK;
-  if (!g->pre_stream) {
-    HIPC(hipStreamCreateWithFlags(&g->pre_stream, hipStreamNonBlocking));
-    HIPC(hipEventCreateWithFlags(&g->ev_scored, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming));
-  }
-  HIPC(hipEventRecord(g->ev_scored, s));                          // behind the scoring launch of the current batch
-  HIPC(hipStreamWaitEvent(g->pre_stream, g->ev_scored, 0));
-  // the buffer set the next batch will use (the asynchronous modes alternate two; this batch toggled already): whoever
-  // read it last -- the tail of the batch before this one -- must be done with it
-  const int nset = g->async_tail != 0 ? g->tail_set : 0;
-  if (g->tail_stream && g->ev_tail_valid[nset]) HIPC(hipStreamWaitEvent(g->pre_stream, g->ev_tail[nset], 0));
-  alt.q_f32 = alt.q_f32_set[nset];
-  alt.cand_rows = alt.cand_rows_set[nset];
-  alt.cand_cnt = alt.cand_cnt_set[nset];
-  alt.cand_score = alt.cand_score_set[nset];
-  const int rc = p1_pre(g, alt, pl, la.q, la.dtype, la.rs, la.cs, la.norm, g->pre_stream);
-  if (rc != MI_OK) return rc;
-  HIPC(hipEventRecord(g->ev_ready, g->pre_stream));
-  la.prepared = true;
-  la.pq = la.q;
-  la.pnq = la.nq;
-  la.pk = k;
-  la.pdtype = la.dtype;
-  la.prs = la.rs;
-  la.pcs = la.cs;
-  la.pnorm = la.norm;
-  la.pset = nset;
-  la.plan = pl;
-  return MI_OK;
-}
-
 // a batch whose sticky flags were raised: a buffer overflow (or fp16 range) and a failed speculative threshold are counted apart
 static void count_flagged_batch(mi_gallery* g, uint32_t flags) {
   if (flags & ~(uint32_t)FLAG_SPEC_FAIL) g->stats.overflow_batches += 1;
@@ -788,23 +684,10 @@ static int check_k(const mi_gallery* g, int32_t k) {
   return MI_OK;
 }
 
-// makes sure the PARKED workspace exists with the active one's capacities (lookahead runs the next batch's pre part there)
-static int ensure_parked_workspace(mi_gallery* g, int32_t k) {
-  Workspace& alt = g->ws_alt;
-  if (alt.qcap >= QB && alt.kcap >= k && alt.cap == g->surv_cap && alt.rcap == g->rescore_cap) return MI_OK;
-  std::swap(g->ws, g->ws_alt);
-  g->ws_slot ^= 1;
-  const int rc = ws_ensure(g, k);
-  std::swap(g->ws, g->ws_alt);
-  g->ws_slot ^= 1;
-  return rc;
-}
-
 // full search of up to any nq on device inputs (strided, any dtype), outputs on device
-// device_api: called by mi_knn_search_device (a batch prepared by a lookahead may be waiting for exactly this call)
 static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t q_rs, int64_t q_cs, int q_norm,
                          int64_t nq, int32_t k, int64_t* out_idx, float* out_score, double* out_score64, bool exact,
-                         hipStream_t s, bool allow_async = false, bool caller_checks_flags = false, bool device_api = false) {
+                         hipStream_t s, bool allow_async = false, bool caller_checks_flags = false) {
   int rc = check_k(g, k);
   if (rc != MI_OK) return rc;
   const bool async = g->async_tail != 0 && allow_async;
@@ -815,12 +698,6 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     if ((rc = flush_pending_tail(g, s, false)) != MI_OK) return rc;
     HIPC(hipStreamWaitEvent(s, g->ev_tail[set], 0));
   }
-  // a batch prepared by a lookahead belongs to a device-API call (or to the next internal batch of a streaming call) for
-  // exactly those queries; anything else drops it and the announcement (the work of its pre part is lost, nothing else)
-  // internal batches of a multi-batch call announce their successors when option "stream_lookahead" is on (default off:
-  // measured, no gain -- DESIGN 5.5)
-  const bool streaming = g->stream_lookahead && nq > QB && async && g->async_tail == 3 && !exact;
-  if (!device_api && !streaming) g->la.armed = g->la.prepared = false;
   if ((rc = ws_ensure(g, k)) != MI_OK) return rc;
   const size_t esz = q_dtype == MI_F32 ? 4 : 8;
   if (async && !g->tail_stream) {
@@ -838,31 +715,6 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     hipStream_t tail = s;
     int set = 0;
     if (async) set = g->tail_set;
-    // is this batch waiting in the parked workspace, prepared by the previous call / the previous internal batch?
-    bool pre_hit = false;
-    if (g->la.prepared) {
-      const mi_gallery::Lookahead& la = g->la;
-      pre_hit = (device_api || streaming) && la.pq == (const void*)src && la.pnq == b && la.pk == k && la.pdtype == q_dtype &&
-                la.prs == q_rs && la.pcs == q_cs && la.pnorm == q_norm && la.pset == set && !exact &&
-                // (an option change may have rebuilt the active workspace and dropped the parked one with the prepared batch)
-                g->ws_alt.qcap >= QB && g->ws_alt.kcap >= k && g->ws_alt.cap == g->surv_cap && g->ws_alt.rcap == g->rescore_cap;
-      g->la.prepared = false;
-      if (pre_hit) {                              // its state is in the parked workspace: make that one the active one
-        std::swap(g->ws, g->ws_alt);
-        g->ws_slot ^= 1;
-      }
-    }
-    if (streaming && q0 + QB < nq) {              // announce the next internal batch
-      g->la.armed = true;
-      g->la.q = src + (size_t)QB * q_rs * esz;
-      g->la.nq = (int32_t)std::min<int64_t>(QB, nq - q0 - QB);
-      g->la.dtype = q_dtype;
-      g->la.rs = q_rs;
-      g->la.cs = q_cs;
-      g->la.norm = q_norm;
-    }
-    g->la.k_cur = k;
-    if (g->la.armed && (rc = ensure_parked_workspace(g, k)) != MI_OK) return rc;
     if (async) {
       g->tail_set ^= 1;
       tail = g->tail_stream;
@@ -875,9 +727,7 @@ static int search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t 
     ws.cand_rows = ws.cand_rows_set[set];
     ws.cand_cnt = ws.cand_cnt_set[set];
     ws.cand_score = ws.cand_score_set[set];
-    if (pre_hit) HIPC(hipStreamWaitEvent(s, g->ev_ready, 0));      // its thresholds are there
-    rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true, caller_checks_flags, pre_hit);
-    g->la.armed = false;                          // an announcement is for the call it was made before, whatever became of it
+    rc = phase1_batch(g, src, q_dtype, q_rs, q_cs, q_norm, b, k, exact, s, /*fuse_cand=*/true, caller_checks_flags);
     if (rc != MI_OK) return rc;
     if (async && g->async_tail == 3) {
       // deferred: a schedule without the single filtered launch (chunked, f32-scored) has not picked the previous tail up
@@ -955,12 +805,6 @@ int mi_gallery_destroy(mi_gallery* g) {
   }
   if (g->ev_pre) (void)hipEventDestroy(g->ev_pre);
   if (g->tail_stream) (void)hipStreamDestroy(g->tail_stream);
-  if (g->pre_stream) {
-    (void)hipStreamSynchronize(g->pre_stream);
-    (void)hipStreamDestroy(g->pre_stream);
-    (void)hipEventDestroy(g->ev_scored);
-    (void)hipEventDestroy(g->ev_ready);
-  }
   ws_free(g->ws);
   ws_free(g->ws_alt);
   for (auto& e : g->ev_pool) {
@@ -1084,7 +928,6 @@ int mi_gallery_append_device(mi_gallery* g, const float* rows_dev, int64_t m, vo
   REQUIRE(m >= 1, "nothing to append");
   REQUIRE(g->n + m <= g->cap, "gallery capacity exceeded");
   std::lock_guard<std::mutex> lock(g->mu);
-  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   HIPC(hipSetDevice(g->device));
   hipStream_t s = (hipStream_t)stream;
   // rows [n, n+m): normalise like the gallery, write f32 rows + 16-bit image + rounding norms at their final place
@@ -1107,7 +950,6 @@ int mi_gallery_append(mi_gallery* g, const void* data, int64_t m, int dtype, int
   int rc = strided_extent(m, g->d, row_stride, col_stride, &elems);
   if (rc != MI_OK) return rc;
   std::lock_guard<std::mutex> lock(g->mu);
-  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   HIPC(hipSetDevice(g->device));
   hipStream_t s = g->stream;
   const size_t esz = dtype == MI_F32 ? 4 : 8;
@@ -1482,20 +1324,7 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   HIPC(hipSetDevice(g->device));
   return search_device(g, q_dev, MI_F32, g->d, 1, g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode, nq, k,
                        out_idx_dev, out_score_dev, out_score64_dev, g->force_exact != 0, (hipStream_t)stream,
-                       /*allow_async=*/true, /*caller_checks_flags=*/false, /*device_api=*/true);
-}
-
-int mi_knn_set_lookahead(mi_gallery* g, const float* q_next_dev, int64_t nq_next) {
-  REQUIRE(g, "null handle");
-  REQUIRE(q_next_dev == nullptr || (nq_next >= 1 && nq_next <= QB), "lookahead: one batch of at most 1024 queries");
-  g->la.armed = q_next_dev != nullptr;
-  g->la.q = q_next_dev;
-  g->la.nq = (int32_t)nq_next;
-  g->la.dtype = MI_F32;
-  g->la.rs = g->d;
-  g->la.cs = 1;
-  g->la.norm = g->qnorm_override >= 0 ? g->qnorm_override : g->norm_mode;
-  return MI_OK;
+                       /*allow_async=*/true, /*caller_checks_flags=*/false);
 }
 
 int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream) {
@@ -1514,7 +1343,6 @@ int mi_gallery_calibrate(mi_gallery* g, int32_t launches, void* stream) {
   if (g->pending.valid && (rc = flush_pending_tail(g, (hipStream_t)stream, false)) != MI_OK) return rc;
   for (int i = 0; i < 2; ++i)
     if (g->ev_tail_valid[i]) HIPC(hipStreamWaitEvent((hipStream_t)stream, g->ev_tail[i], 0));
-  g->la.armed = g->la.prepared = false;
   // queries = the first stored rows of the gallery itself (resident, already in the gallery's own normalisation): what the
   // launches score is irrelevant, every workgroup's loop time is what block 0 of the scatter kernel turns into shares
   for (int32_t i = 0; i < launches; ++i)
@@ -1537,7 +1365,6 @@ int mi_knn_phase1_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
   REQUIRE(nq >= 1 && nq <= QB, "phase API handles one batch of at most 1024 queries");
   HIPC(hipSetDevice(g->device));
   REQUIRE(k >= 1, "k must be >= 1");
-  g->la.armed = g->la.prepared = false;          // the phase API manages the workspace slots itself
   // a shard may hold fewer than k rows: clamp the local k, pad the tail with -inf
   const int32_t kl = (int32_t)std::min<int64_t>(k, g->n);
   int rc = check_k(g, kl);
@@ -1704,6 +1531,9 @@ int dense_search_device(mi_gallery* g, const void* q_src, int q_dtype, int64_t r
   REQUIRE(k <= 4096, "dense top-k supports k <= 4096");
   int rc = ws_ensure(g, std::min<int32_t>(k, 1024));
   if (rc != MI_OK) return rc;
+  // these launches overwrite the workspace's query buffers: a deferred / running asynchronous tail of an earlier device-API
+  // batch (async_tail 1..3) must be done with them first
+  if ((rc = join_tails(g, s)) != MI_OK) return rc;
   Workspace& ws = g->ws;
   int64_t qb = std::min<int64_t>(QB, std::max<int64_t>(64, ((int64_t)1 << 28) / g->n / 64 * 64));
   TmpAlloc tmp;
@@ -1744,6 +1574,9 @@ static int dense64_search_device(mi_gallery* g, const void* q_src, int q_dtype, 
   REQUIRE(k >= 1 && (int64_t)k <= g->n && k <= 4096, "dense top-k supports k <= min(N, 4096)");
   int rc = ws_ensure(g, std::min<int32_t>(k, 1024));
   if (rc != MI_OK) return rc;
+  // these launches overwrite the workspace's query buffers: a deferred / running asynchronous tail of an earlier device-API
+  // batch (async_tail 1..3) must be done with them first
+  if ((rc = join_tails(g, s)) != MI_OK) return rc;
   Workspace& ws = g->ws;
   const int64_t qb = std::min<int64_t>(QB, std::max<int64_t>(16, ((int64_t)1 << 28) / g->n));
   TmpAlloc tmp;
@@ -1838,6 +1671,7 @@ static int rank_all_impl(mi_gallery* g, const void* q, int64_t nq, int dtype, in
   int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
   if (rc != MI_OK) return rc;
   if ((rc = ws_ensure(g, 1)) != MI_OK) return rc;
+  if ((rc = join_tails(g, g->stream)) != MI_OK) return rc;     // (an asynchronous tail still reads the query buffers)
   Workspace& ws = g->ws;
   hipStream_t s = g->stream;
   const size_t esz = dtype == MI_F32 ? 4 : 8;
@@ -1910,6 +1744,7 @@ int mi_rank_positions(mi_gallery* g, const void* q, int64_t nq, int dtype, int64
   int rc = strided_extent(nq, g->d, row_stride, col_stride, &elems);
   if (rc != MI_OK) return rc;
   if ((rc = ws_ensure(g, 1)) != MI_OK) return rc;
+  if ((rc = join_tails(g, g->stream)) != MI_OK) return rc;     // (an asynchronous tail still reads the query buffers)
   Workspace& ws = g->ws;
   hipStream_t s = g->stream;
   const size_t esz = dtype == MI_F32 ? 4 : 8;
@@ -2251,11 +2086,12 @@ int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset) {
   if (sw.qcap) {
     // per-query accumulators (the kernels add to the words of their own query: no atomics on one address from 1024
     // workgroups, which cost the final maintain launch 15 us per batch); summed here
-    std::vector<uint64_t> s2(2 * (size_t)QB);
+    std::vector<uint64_t> s2(3 * (size_t)QB);
     HIPC(hipMemcpy(s2.data(), sw.stats2, s2.size() * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < (size_t)QB; ++i) {
       g->stats.survivors += (int64_t)s2[2 * i];
       g->stats.candidates += (int64_t)s2[2 * i + 1];
+      g->stats.inkernel_repairs += (int64_t)s2[2 * (size_t)QB + i];
     }
     HIPC(hipMemset(sw.stats2, 0, s2.size() * 8));
     uint32_t flags = 0;
@@ -2300,7 +2136,6 @@ int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* o
 int mi_gallery_norm_bounds(mi_gallery* g, float* bounds3, int raise) {
   REQUIRE(g && bounds3, "null");
   std::lock_guard<std::mutex> lock(g->mu);
-  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   HIPC(hipSetDevice(g->device));
   HIPC(hipStreamSynchronize(g->stream));
   float own[3] = {0, 0, 0};
@@ -2320,7 +2155,6 @@ int mi_gallery_set_image_dtype(mi_gallery* g, int f16) {
   REQUIRE(g, "null handle");
   f16 = f16 != 0;
   std::lock_guard<std::mutex> lock(g->mu);
-  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   if (g->img_f16 == f16 || g->n == 0) {
     g->img_f16 = f16;
     return MI_OK;
@@ -2371,18 +2205,13 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
   else if (n == "rescore_cap") *out_value = g->rescore_cap;
   else if (n == "exact_fallback") *out_value = g->exact_fallback;
   else if (n == "force_exact") *out_value = g->force_exact;
-  else if (n == "debug") *out_value = g->debug;
   else if (n == "speculative") *out_value = g->speculative;
   else if (n == "device_repair") *out_value = g->device_repair;
-  else if (n == "small_tail") *out_value = g->small_tail;
   else if (n == "small_batch_kernel") *out_value = g->small_batch_kernel;
-  else if (n == "kernel_variant") *out_value = g->kernel_variant;
   else if (n == "xcc_balance") *out_value = g->xcc_balance;
   else if (n == "ladder") *out_value = g->ladder;
   else if (n == "boot_ksplit") *out_value = g->boot_ksplit;
   else if (n == "stream_tail") *out_value = g->stream_tail;
-  else if (n == "stream_lookahead") *out_value = g->stream_lookahead;
-  else if (n == "inkernel_repair_max") *out_value = g->inkernel_repair_max;
   else if (n == "async_tail") *out_value = g->async_tail;
   else if (n == "query_norm_override") *out_value = g->qnorm_override;
   else if (n == "image_dtype") *out_value = g->img_f16;
@@ -2392,7 +2221,6 @@ int mi_get_option(const mi_gallery* g, const char* name, double* out_value) {
 
 int mi_set_option(mi_gallery* g, const char* name, double value) {
   REQUIRE(g && name, "null");
-  g->la.armed = g->la.prepared = false;   // whatever a lookahead prepared was prepared for the gallery / options as they WERE
   const std::string n(name);
   if (g->pending.valid) {
     // a deferred tail (async_tail 3) is enqueued before ANY option changes: it must run with the buffers, caps and workspace
@@ -2405,7 +2233,6 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
   else if (n == "spec_max_ratio") { REQUIRE(value >= 1 && value <= 4096, "spec_max_ratio in [1, 4096]"); g->spec_max_ratio = (int)value; }
   else if (n == "workspace_slot") {
     REQUIRE(value == 0 || value == 1, "workspace_slot: 0 or 1");
-    g->la.armed = g->la.prepared = false;
     if ((int)value != g->ws_slot) {
       std::swap(g->ws, g->ws_alt);
       g->ws_slot = (int)value;
@@ -2423,24 +2250,16 @@ int mi_set_option(mi_gallery* g, const char* name, double value) {
     g->rescore_cap = v;
   } else if (n == "exact_fallback") g->exact_fallback = value != 0;
   else if (n == "force_exact") g->force_exact = value != 0;
-  else if (n == "debug") g->debug = (int)value;
   else if (n == "speculative") g->speculative = value != 0;
   else if (n == "device_repair") g->device_repair = value < 0 ? -1 : (value != 0);
-  else if (n == "small_tail") g->small_tail = value != 0;
   else if (n == "small_batch_kernel") g->small_batch_kernel = value != 0;
-  else if (n == "kernel_variant") g->kernel_variant = (int)value;
   else if (n == "xcc_balance") g->xcc_balance = value != 0;
   else if (n == "ladder") {
-    REQUIRE(value == 0 || value == 1 || value == 2, "ladder: 0 (off), 1 (one level) or 2 (two levels)");
+    REQUIRE(value == 0 || value == 1, "ladder: 0 (off) or 1 (on)");
     g->ladder = (int)value;
   }
   else if (n == "boot_ksplit") g->boot_ksplit = value != 0;
   else if (n == "stream_tail") g->stream_tail = value != 0;
-  else if (n == "stream_lookahead") g->stream_lookahead = value != 0;
-  else if (n == "inkernel_repair_max") {
-    REQUIRE(value >= 0 && value <= QB, "inkernel_repair_max: 0 .. 1024 queries");
-    g->inkernel_repair_max = (int)value;
-  }
   else if (n == "async_tail") {
     REQUIRE(value == 0 || value == 1 || value == 2 || value == 3, "async_tail: 0, 1, 2 or 3");
     g->async_tail = (int)value;

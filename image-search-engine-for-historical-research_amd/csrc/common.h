@@ -116,10 +116,6 @@ struct QueryState {       // all arrays sized for qpad queries
   float* lad_tc;          // count level t_c: a sample order statistic tighter than the speculative one (+inf = off)
   uint32_t* lad_pack;     // bf16(thr, rounded down) | bf16(t_c - margin, rounded down) << 16: the two thresholds a wave may apply
   uint32_t* lad_cnt;      // rows seen with approx >= t_c; once >= K, t_c - margin is a RIGOROUS threshold
-  // second ladder level (option "ladder" = 2, tile-kernel instantiation LAD2; nullptr = off): t_c2 >= t_c, a tighter sample rank
-  uint32_t* lad_pack2;    // bf16(t_c2 - margin, rounded down) << 16
-  uint32_t* lad_cnt2;     // rows seen with approx >= bf16_up(t_c2)
-  uint32_t* lad_lev;      // count levels of both: bf16_up(t_c) | bf16_up(t_c2) << 16
   uint32_t cap;
 };
 

@@ -483,12 +483,11 @@ __global__ __launch_bounds__(512, 2) void gemm_select_kernel(ScoreArgs p) {
 // DBG 16384: the query fragments are read from LDS once per launch (energy model of a query operand that bypasses LDS);
 // DBG 32768: every wave also loads its 4 KiB of query fragments per slice straight into (discarded) registers -- with
 // DBG 64 | 16384 the traffic of the "global -> VGPR query operand" structure without its pipeline (scripts/kbench.hip).
-// LAD2 (round 4): two ladder levels.  The query ring gives up its fourth slot (measured equal: profiles/r03d_ring_slots_ab.txt)
-// and the second level's per-wave words -- its packed threshold and its live counter -- live in that slot's 16 KiB.
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0, bool LAD2 = false>
+// (A second ladder level -- round 4, "LAD2" -- was built and measured at +1.3 %: profiles/r04k_ladder2_ab.txt; removed in round 5.)
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
   constexpr bool ZC = (OPT & 1) != 0;
-  constexpr int BSL = LAD2 ? 3 : B_SLOTS;                    // slots of the query ring
+  constexpr int BSL = B_SLOTS;                               // slots of the query ring
   constexpr bool INTER = (OPT & 2) != 0 && !FIRST && !(DBG & (4 | 4096 | 8192));
   using frag_t = typename std::conditional<F16, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // rings | per-wave scratch | per-wave thresholds  (ONE LDS object)
@@ -538,9 +537,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     // [64..127] ladder counters (refreshed by a 256-byte DMA per tile), [128..191] ladder count levels t_c
     float* thr_w = reinterpret_cast<float*>(smem + RING_BYTES + STAGE_BYTES) + w * THR_WORDS;
     const bool lad = !FIRST && !REPAIR && p.lad_k > 0 && p.st.lad_cnt != nullptr;
-    const bool lad2 = LAD2 && lad && p.st.lad_cnt2 != nullptr;
-    // second level, per wave: [0..63] bf16(t_c2 - margin) << 16, [64..127] its counter -- in the query ring's unused slot
-    uint32_t* thr_x = reinterpret_cast<uint32_t*>(smem + B_RING + 3 * SLICE_BYTES) + w * 128;
     const uint32_t* lad_cnt_src = p.st.lad_cnt;                 // + query of this lane, set with the thresholds
     uint32_t thr_qt = 0xFFFFFFFFu;
     auto load_thresholds = [&](uint32_t qt) {                   // plain loads: drains the DMA rings (query tile changes only)
@@ -548,13 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
       if (lad) {
         reinterpret_cast<uint32_t*>(thr_w)[lane] = p.st.lad_pack[q];
         reinterpret_cast<uint32_t*>(thr_w)[64 + lane] = p.st.lad_cnt[q];
-        if (lad2) {                                   // count levels of both rungs as one word; the second rung's words
-          reinterpret_cast<uint32_t*>(thr_w)[128 + lane] = p.st.lad_lev[q];
-          thr_x[lane] = p.st.lad_pack2[q];
-          thr_x[64 + lane] = p.st.lad_cnt2[q];
-        } else {
-          thr_w[128 + lane] = p.st.lad_tc[q];
-        }
+        thr_w[128 + lane] = p.st.lad_tc[q];
       } else {
         thr_w[lane] = p.st.thr[q];
       }
@@ -562,13 +552,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
     };
     // ladder: this wave's 64 counters, straight into LDS (one 4-byte-per-lane DMA piece in the wave's vmcnt order)
     auto refresh_counts = [&](uint32_t qt) {
-      if (lad && qt == thr_qt) {
+      if (lad && qt == thr_qt)
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(lad_cnt_src + qt * TILE + wc * 64 + lane),
                                          (LDS_AS void*)(thr_w + 64), 4, 0, 0);
-        if (lad2)
-          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(p.st.lad_cnt2 + qt * TILE + wc * 64 + lane),
-                                           (LDS_AS void*)(thr_x + 64), 4, 0, 0);
-      }
     };
     auto tile_of = [&](uint32_t i, uint32_t& gt, uint32_t& qt) {
       const uint32_t v = j + i * nwg;
@@ -659,14 +645,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
           uint32_t cnt;
           asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cnt) : "v"(lds_addr(thr_w + 64 + nb * 16 + l15)) : "memory");
           thr4[nb] = __uint_as_float(cnt >= (uint32_t)p.lad_k ? (pk & 0xFFFF0000u) : (pk << 16));
-          if (LAD2 && lad2) {                         // the higher rung, once K rows above IT have been counted
-            uint32_t cnt2, pk2;
-            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(cnt2), "=&v"(pk2)
-                         : "v"(lds_addr(thr_x + 64 + nb * 16 + l15)), "v"(lds_addr(thr_x + nb * 16 + l15))
-                         : "memory");
-            if (cnt2 >= (uint32_t)p.lad_k) thr4[nb] = __uint_as_float(pk2 & 0xFFFF0000u);
-          }
         } else {
           thr4[nb] = thr_w[nb * 16 + l15];      // +inf for padded queries
         }
@@ -887,12 +865,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(ScoreArgs p) {
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
               if (!(DBG & 1024) && keep && pos < p.rec_cap)          // DBG 1024: no record stores (diagnostics)
                 reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(vv[it]), row, mt[it].y, 0u);
-              if (LAD2 && lad2) {                       // .w = bf16_up(t_c) | bf16_up(t_c2) << 16
-                if (keep && vv[it] >= __uint_as_float(mt[it].w << 16)) atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
-                if (keep && vv[it] >= __uint_as_float(mt[it].w & 0xFFFF0000u)) atomicAdd(&p.st.lad_cnt2[mt[it].y], 1u);
-              } else if (lad && keep && vv[it] >= __uint_as_float(mt[it].w)) {
-                atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
-              }
+              if (lad && keep && vv[it] >= __uint_as_float(mt[it].w)) atomicAdd(&p.st.lad_cnt[mt[it].y], 1u);
               if (DBG & 1024) asm volatile("" ::"v"(pos), "v"(row));
               my_cnt += (uint32_t)__popcll(km);
             }
@@ -1252,6 +1225,12 @@ void init_xcc_balance_host(XccBalance* h) {
   h->launches = 0;
 }
 
+// The product build holds SIX instantiations of the tile kernel -- {bootstrap, filtered launch, conditional repair launch} x
+// {fp16, bf16 image}, structure 2, snake order -- and nothing else.  Every diagnostic (DBG != 0: stages switched off, stamps),
+// A/B (ORDER, OPT, POL, the paired-XCD walk) and structure-1 instantiation is compiled under -DMI_KBENCH only, i.e. into
+// scripts/kbench.hip's own program (scripts/kbench_build.sh), whose records are under profiles/ (r04a_kbench*, r04c_kbench_rotated,
+// r04m_kbench*): several of them return wrong answers by design and none is reachable from the C ABI.
+#ifdef MI_KBENCH
 template <bool FIRST, int DBG, bool F16, bool REPAIR = false>
 static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   ensure_dynamic_lds((const void*)gemm_select_kernel<FIRST, DBG, F16, REPAIR>);
@@ -1263,96 +1242,108 @@ static void launch_variant(const ScoreArgs& a, size_t lds, hipStream_t stream) {
   else
     hipLaunchKernelGGL((gemm_select_kernel<FIRST, DBG, F16, REPAIR>), dim3(persistent_grid()), dim3(512), lds, stream, a);
 }
+#endif
 
-template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0, bool LAD2 = false>
+template <bool FIRST, int DBG, bool F16, bool REPAIR, int ORDER, int OPT = 0, int POL = 0>
 static void launch_tile(const ScoreArgs& a, size_t lds, hipStream_t stream) {
-  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL, LAD2>);
+  ensure_dynamic_lds((const void*)gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>);
   hipEvent_t e0, e1;
   take_launch_events(&e0, &e1);
   if (e0 && e1)
-    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL, LAD2>), dim3(persistent_grid()), dim3(512),
+    hipExtLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>), dim3(persistent_grid()), dim3(512),
                           lds, stream, e0, e1, 0, a);
   else
-    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL, LAD2>), dim3(persistent_grid()), dim3(512), lds,
+    hipLaunchKernelGGL((gemm_tile_kernel<FIRST, DBG, F16, REPAIR, ORDER, OPT, POL>), dim3(persistent_grid()), dim3(512), lds,
                        stream, a);
 }
 
-void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
-  ScoreArgs a = a_in;
+#ifdef MI_KBENCH
+// scripts/kbench.hip only: a.debug / a.variant select a diagnostic or A/B instantiation; false = none matches (product kernel)
+static bool launch_kbench_variant(ScoreArgs& a, bool first, size_t lds, hipStream_t stream) {
   if (a.variant == 20 || a.variant == 21) a.walk = 1;           // paired-XCD walk (A/B), 21: with nt gallery pieces
-  if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
-  const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * THR_WORDS * 4;      // 162,816 B of the 163,840
-  if (a.variant != 1) {                                          // structure 2 (default); variant 1 = structure 1 (A/B)
-    // MFMA issue order: 3 = query-block-major snake (default: every MFMA shares an operand with its predecessor; bit-identical
-    // results, +0.8 % over plain query-block-major and +4 % over gallery-block-major by the clock the chip holds)
-    if (a.cond) return a.img_f16 ? launch_tile<false, 0, true, true, 3>(a, lds, stream)
-                                 : launch_tile<false, 0, false, true, 3>(a, lds, stream);
-    if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 3>(a, lds, stream)
-                                : launch_tile<true, 0, false, false, 3>(a, lds, stream);
-    if (!a.img_f16) return launch_tile<false, 0, false, false, 3>(a, lds, stream);
-    if (a.lad2 && a.lad_k > 0 && a.debug == 0) return launch_tile<false, 0, true, false, 3, 0, 0, true>(a, lds, stream);   // two rungs
+  if (a.variant != 1) {
+    if (a.cond || first || !a.img_f16) return false;
     switch (a.debug) {
       case 4:
-        if (a.variant == 2) return launch_tile<false, 4, true, false, 0>(a, lds, stream);
-        if (a.variant == 3) return launch_tile<false, 4, true, false, 2>(a, lds, stream);
-        if (a.variant == 4) return launch_tile<false, 4, true, false, 1>(a, lds, stream);
-        return launch_tile<false, 4, true, false, 3>(a, lds, stream);
-      case 5: return launch_tile<false, 5, true, false, 3>(a, lds, stream);
-      case 512: return launch_tile<false, 512, true, false, 3>(a, lds, stream);
-      case 1024: return launch_tile<false, 1024, true, false, 3>(a, lds, stream);
+        if (a.variant == 2) return launch_tile<false, 4, true, false, 0>(a, lds, stream), true;
+        if (a.variant == 3) return launch_tile<false, 4, true, false, 2>(a, lds, stream), true;
+        if (a.variant == 4) return launch_tile<false, 4, true, false, 1>(a, lds, stream), true;
+        return launch_tile<false, 4, true, false, 3>(a, lds, stream), true;
+      case 5: return launch_tile<false, 5, true, false, 3>(a, lds, stream), true;
+      case 512: return launch_tile<false, 512, true, false, 3>(a, lds, stream), true;
+      case 1024: return launch_tile<false, 1024, true, false, 3>(a, lds, stream), true;
       case 2048:
-        if (a.variant == 6) return launch_tile<false, 2048, true, false, 3, 3>(a, lds, stream);
-        return launch_tile<false, 2048, true, false, 3>(a, lds, stream);
-      case 8192: return launch_tile<false, 8192, true, false, 3>(a, lds, stream);
-      case 8192 + 2048: return launch_tile<false, 8192 + 2048, true, false, 3>(a, lds, stream);
-      case 4096: return launch_tile<false, 4096, true, false, 3>(a, lds, stream);
-      case 4096 + 2048: return launch_tile<false, 4096 + 2048, true, false, 3>(a, lds, stream);
-      case 4096 + 1024: return launch_tile<false, 4096 + 1024, true, false, 3>(a, lds, stream);
-      case 5 + 128: return launch_tile<false, 5 + 128, true, false, 3>(a, lds, stream);
+        if (a.variant == 6) return launch_tile<false, 2048, true, false, 3, 3>(a, lds, stream), true;
+        return launch_tile<false, 2048, true, false, 3>(a, lds, stream), true;
+      case 8192: return launch_tile<false, 8192, true, false, 3>(a, lds, stream), true;
+      case 8192 + 2048: return launch_tile<false, 8192 + 2048, true, false, 3>(a, lds, stream), true;
+      case 4096: return launch_tile<false, 4096, true, false, 3>(a, lds, stream), true;
+      case 4096 + 2048: return launch_tile<false, 4096 + 2048, true, false, 3>(a, lds, stream), true;
+      case 4096 + 1024: return launch_tile<false, 4096 + 1024, true, false, 3>(a, lds, stream), true;
+      case 5 + 128: return launch_tile<false, 5 + 128, true, false, 3>(a, lds, stream), true;
       // round 4: which operand's DMA costs what (gallery pieces / query pieces skipped), and the price list of a query
       // operand that bypasses LDS (query fragments read once; + the fragment-shaped loads into discarded registers)
-      case 4 + 32: return launch_tile<false, 4 + 32, true, false, 3>(a, lds, stream);
-      case 4 + 64: return launch_tile<false, 4 + 64, true, false, 3>(a, lds, stream);
-      case 4 + 64 + 16384: return launch_tile<false, 4 + 64 + 16384, true, false, 3>(a, lds, stream);
-      case 4 + 64 + 16384 + 32768: return launch_tile<false, 4 + 64 + 16384 + 32768, true, false, 3>(a, lds, stream);
+      case 4 + 32: return launch_tile<false, 4 + 32, true, false, 3>(a, lds, stream), true;
+      case 4 + 64: return launch_tile<false, 4 + 64, true, false, 3>(a, lds, stream), true;
+      case 4 + 64 + 16384: return launch_tile<false, 4 + 64 + 16384, true, false, 3>(a, lds, stream), true;
+      case 4 + 64 + 16384 + 32768: return launch_tile<false, 4 + 64 + 16384 + 32768, true, false, 3>(a, lds, stream), true;
       default:
-        // round 4: cache policy of the DMA pieces (10 .. 15; gallery aux | query aux << 8) and the paired-XCD walk (20, 21)
-        if (a.variant == 10 || a.variant == 21) return launch_tile<false, 0, true, false, 3, 0, 2>(a, lds, stream);          // gallery nt
-        if (a.variant == 11) return launch_tile<false, 0, true, false, 3, 0, 16>(a, lds, stream);         // gallery sc1
-        if (a.variant == 12) return launch_tile<false, 0, true, false, 3, 0, 17>(a, lds, stream);         // gallery sc0 sc1
-        if (a.variant == 13) return launch_tile<false, 0, true, false, 3, 0, 2 | (2 << 8)>(a, lds, stream);   // both nt
-        if (a.variant == 14) return launch_tile<false, 0, true, false, 3, 0, 2 << 8>(a, lds, stream);     // query nt (control)
-        if (a.variant == 15) return launch_tile<false, 0, true, false, 3, 0, 18>(a, lds, stream);         // gallery nt sc1
-        if (a.variant == 16) return launch_tile<false, 0, true, false, 3, 0, 1>(a, lds, stream);          // gallery sc0
-        if (a.variant == 17) return launch_tile<false, 0, true, false, 3, 1, 1>(a, lds, stream);          // zero-C + gallery sc0
-        if (a.variant == 18) return launch_tile<false, 0, true, false, 3, 1, 17>(a, lds, stream);         // zero-C + gallery sc0 sc1
-        if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream);
-        if (a.variant == 4) return launch_tile<false, 0, true, false, 1>(a, lds, stream);
-        if (a.variant == 5) return launch_tile<false, 0, true, false, 3, 1>(a, lds, stream);   // zero-C first slice
-        if (a.variant == 6) return launch_tile<false, 0, true, false, 3, 3>(a, lds, stream);   // + decide inside the last slice
-        if (a.variant == 7) return launch_tile<false, 0, true, false, 3, 2>(a, lds, stream);   // decide inside the last slice only
-        return launch_tile<false, 0, true, false, 3>(a, lds, stream);
+        // round 4: cache policy of the DMA pieces (10 .. 18; gallery aux | query aux << 8) and the paired-XCD walk (20, 21)
+        if (a.variant == 10 || a.variant == 21) return launch_tile<false, 0, true, false, 3, 0, 2>(a, lds, stream), true;   // gallery nt
+        if (a.variant == 11) return launch_tile<false, 0, true, false, 3, 0, 16>(a, lds, stream), true;         // gallery sc1
+        if (a.variant == 12) return launch_tile<false, 0, true, false, 3, 0, 17>(a, lds, stream), true;         // gallery sc0 sc1
+        if (a.variant == 13) return launch_tile<false, 0, true, false, 3, 0, 2 | (2 << 8)>(a, lds, stream), true;   // both nt
+        if (a.variant == 14) return launch_tile<false, 0, true, false, 3, 0, 2 << 8>(a, lds, stream), true;     // query nt (control)
+        if (a.variant == 15) return launch_tile<false, 0, true, false, 3, 0, 18>(a, lds, stream), true;         // gallery nt sc1
+        if (a.variant == 16) return launch_tile<false, 0, true, false, 3, 0, 1>(a, lds, stream), true;          // gallery sc0
+        if (a.variant == 17) return launch_tile<false, 0, true, false, 3, 1, 1>(a, lds, stream), true;          // zero-C + gallery sc0
+        if (a.variant == 18) return launch_tile<false, 0, true, false, 3, 1, 17>(a, lds, stream), true;         // zero-C + gallery sc0 sc1
+        if (a.variant == 2) return launch_tile<false, 0, true, false, 0>(a, lds, stream), true;
+        if (a.variant == 4) return launch_tile<false, 0, true, false, 1>(a, lds, stream), true;
+        if (a.variant == 5) return launch_tile<false, 0, true, false, 3, 1>(a, lds, stream), true;   // zero-C first slice
+        if (a.variant == 6) return launch_tile<false, 0, true, false, 3, 3>(a, lds, stream), true;   // + decide inside the last slice
+        if (a.variant == 7) return launch_tile<false, 0, true, false, 3, 2>(a, lds, stream), true;   // decide inside the last slice only
+        return false;
     }
   }
-  if (a.cond) return a.img_f16 ? launch_variant<false, 0, true, true>(a, lds, stream)
-                               : launch_variant<false, 0, false, true>(a, lds, stream);
+  // structure 1 (variant 1)
+  if (a.cond) return (a.img_f16 ? launch_variant<false, 0, true, true>(a, lds, stream)
+                                : launch_variant<false, 0, false, true>(a, lds, stream)), true;
   if (a.img_f16) {
-    if (first) return launch_variant<true, 0, true>(a, lds, stream);
+    if (first) return launch_variant<true, 0, true>(a, lds, stream), true;
     switch (a.debug) {
-      case 4: return launch_variant<false, 4, true>(a, lds, stream);
-      case 5: return launch_variant<false, 5, true>(a, lds, stream);
-      case 8: case 24: return launch_variant<false, 8, true>(a, lds, stream);
-      case 4 + 32: return launch_variant<false, 4 + 32, true>(a, lds, stream);
-      case 4 + 64: return launch_variant<false, 4 + 64, true>(a, lds, stream);
-      case 4 + 128: return launch_variant<false, 4 + 128, true>(a, lds, stream);
-      case 5 + 128: return launch_variant<false, 5 + 128, true>(a, lds, stream);
-      case 5 + 128 + 256: return launch_variant<false, 5 + 128 + 256, true>(a, lds, stream);
-      case 5 + 256: return launch_variant<false, 5 + 256, true>(a, lds, stream);
-      default: return launch_variant<false, 0, true>(a, lds, stream);
+      case 4: return launch_variant<false, 4, true>(a, lds, stream), true;
+      case 5: return launch_variant<false, 5, true>(a, lds, stream), true;
+      case 8: case 24: return launch_variant<false, 8, true>(a, lds, stream), true;
+      case 4 + 32: return launch_variant<false, 4 + 32, true>(a, lds, stream), true;
+      case 4 + 64: return launch_variant<false, 4 + 64, true>(a, lds, stream), true;
+      case 4 + 128: return launch_variant<false, 4 + 128, true>(a, lds, stream), true;
+      case 5 + 128: return launch_variant<false, 5 + 128, true>(a, lds, stream), true;
+      case 5 + 128 + 256: return launch_variant<false, 5 + 128 + 256, true>(a, lds, stream), true;
+      case 5 + 256: return launch_variant<false, 5 + 256, true>(a, lds, stream), true;
+      default: return launch_variant<false, 0, true>(a, lds, stream), true;
     }
   }
-  if (first) return launch_variant<true, 0, false>(a, lds, stream);
-  return launch_variant<false, 0, false>(a, lds, stream);
+  if (first) return launch_variant<true, 0, false>(a, lds, stream), true;
+  return launch_variant<false, 0, false>(a, lds, stream), true;
+}
+#endif
+
+void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
+  ScoreArgs a = a_in;
+  if (stream_select_applies(a) || (first && stream_bootstrap_applies(a))) return launch_stream_select(a, first, stream);
+  const size_t lds = (size_t)RING_BYTES + STAGE_BYTES + 8 * THR_WORDS * 4;      // 162,816 B of the 163,840
+#ifdef MI_KBENCH
+  if (launch_kbench_variant(a, first, lds, stream)) return;
+#endif
+  // structure 2, MFMA issue order 3 = query-block-major snake (every MFMA shares an operand with its predecessor; bit-identical
+  // results, +0.8 % over plain query-block-major and +4 % over gallery-block-major by the clock the chip holds)
+  if (a.cond) return a.img_f16 ? launch_tile<false, 0, true, true, 3>(a, lds, stream)
+                               : launch_tile<false, 0, false, true, 3>(a, lds, stream);
+  if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 3>(a, lds, stream)
+                              : launch_tile<true, 0, false, false, 3>(a, lds, stream);
+  return a.img_f16 ? launch_tile<false, 0, true, false, 3>(a, lds, stream)
+                   : launch_tile<false, 0, false, false, 3>(a, lds, stream);
 }
 
 }  // namespace mi

@@ -445,7 +445,6 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
       st.lad_tc[q] = INFINITY;
       st.lad_pack[q] = 0x7F807F80u;
       st.lad_cnt[q] = 0;
-      if (st.lad_cnt2) { st.lad_pack2[q] = 0x7F800000u; st.lad_cnt2[q] = 0; st.lad_lev[q] = 0x7F807F80u; }
     }
   }
   }   // rows of this workgroup

@@ -31,9 +31,9 @@ struct ScoreArgs {
   int32_t nqt;            // query tiles (qpad / 256)
   int64_t n;              // valid gallery rows in the shard
   int32_t nq;             // valid queries
-  int32_t debug;          // diagnostics only: bit0 skip DMA, bit1 skip MFMA, bit2 skip filter (results invalid)
+  int32_t debug = 0;      // scripts/kbench.hip (-DMI_KBENCH builds) only: diagnostic instantiation; the product passes 0
   int32_t small_batch_kernel;   // 1: launches with <= STREAM_MAX_QUERIES queries go to stream_select.hip
-  int32_t variant = 0;          // tile-kernel structure (option "kernel_variant"; A/B of builds inside one process)
+  int32_t variant = 0;          // scripts/kbench.hip (-DMI_KBENCH builds) only: A/B instantiation; the product passes 0
   int32_t walk = 0;             // tile kernel: 0 = every XCD label walks all query tiles of its gallery range; 1 = labels 2y, 2y + 1
                                 // share a range and take half of the query tiles each (A/B, gemm_select.hip)
   SurvRec* rec;           // [grid * 8 waves][rec_cap] wave-private survivor records of this launch
@@ -42,7 +42,6 @@ struct ScoreArgs {
   const uint32_t* cond;   // non-null: the whole launch is skipped when *cond == 0 (repair pass)
   const XccBalance* bal = nullptr;   // non-null: weighted split of the gallery tiles over the XCD labels (tile kernel)
   int32_t lad_k = 0;                 // > 0: in-launch threshold ladder on (K of the search); tile kernel, filtered launch only
-  int32_t lad2 = 0;                  // 1: two ladder levels (QueryState::lad_*2; tile-kernel instantiation LAD2)
   int32_t scores_only = 0;           // bootstrap launch on the sample image (stream_select MODE 2): store the scores as 4-byte
                                      // floats at ((float*)(surv + q * cap))[sample row] instead of 8-byte (score, row) entries --
                                      // sample_threshold_kernel reads nothing but the scores, and the entries are dropped afterwards
@@ -97,14 +96,14 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 void set_tail_debug_phase(int phase);   // diagnostics only (scripts/tailbench.hip): selection kernels return after phase N; 0 = product
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f,
-                             int32_t lad_r2 = 0);   // f32_scores: see ScoreArgs::scores_only; lad_r2: second ladder level
+                             int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f);   // f32_scores: see ScoreArgs::scores_only
 // what the in-kernel repair of a failed query scans (repair == 3): the shard's stored f32 rows and the batch's f32 queries
 struct RepairScan {
   const float* gal_f32 = nullptr;
   const float* qry_f32 = nullptr;
   int32_t dp = 0;
   int64_t n = 0;
+  uint64_t* repairs = nullptr;   // per query: in-kernel repairs so far (one writer per word; summed by mi_search_status)
 };
 void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, float* topvals, float* l_local,
                             uint64_t* stats2, int32_t spec_r, int32_t spec, int32_t repair, const uint32_t* cond,
@@ -119,10 +118,6 @@ void launch_rescore(const float* gal_f32, const float* qry_f32, int32_t dp, int3
 void launch_rescore_resident(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
                              const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, hipStream_t stream,
                              uint32_t last_row);
-// batches of <= STREAM_MAX_QUERIES queries: launch_rescore + launch_emit in one launch (one workgroup per query)
-void launch_rescore_emit(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                         const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, uint32_t last_row, int32_t k,
-                         int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64, hipStream_t stream);
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
                  int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score,
                  double* out_score64, hipStream_t stream);

@@ -174,7 +174,6 @@ __global__ void init_query_state_kernel(const RowStat* __restrict__ qstat, const
     st.lad_tc[q] = INFINITY;
     st.lad_pack[q] = 0x7F807F80u;         // (+inf, +inf)
     st.lad_cnt[q] = 0;
-    if (st.lad_cnt2) { st.lad_pack2[q] = 0x7F800000u; st.lad_cnt2[q] = 0; st.lad_lev[q] = 0x7F807F80u; }
   }
 }
 
@@ -312,7 +311,10 @@ restart:
   if (SCAN && MODE == 1 && failed && repair == 3 && attempt == 0 && rs.gal_f32) {
     // in-kernel repair of this query: every stored row of the shard against it, rows with score >= thr2 become the survivors
     __syncthreads();
-    if (threadIdx.x == 0) sh[6] = 0;
+    if (threadIdx.x == 0) {
+      sh[6] = 0;
+      if (rs.repairs) rs.repairs[q] += 1;           // the one trace of a repair: a sub-millisecond call that took 0.1 .. 1 s
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = MAINT_THREADS / 64;
     const int nvec = rs.dp >> 2;
@@ -460,10 +462,10 @@ constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD 
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
                                                                         int32_t lad_r, int32_t f32_scores, int dbg_phase,
-                                                                        float order_slack, int32_t lad_r2) {
+                                                                        float order_slack) {
   __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
   __shared__ __attribute__((aligned(16))) uint32_t hist[1024];   // the select's histograms; first 256 words: gather buffer
-  __shared__ uint32_t sh[9];
+  __shared__ uint32_t sh[8];
   const uint32_t q = blockIdx.x;
   const float margin_q = st.margin[q], thr_in = st.thr[q];    // requested up front (thread 0 needs them at the very end)
   const uint32_t n = min(st.cnt[q * CNT_STRIDE], (uint32_t)(SAMP_THREADS * SAMP_PER_THREAD));
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
   const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);   // wanted ranks, w1 <= w2 <= 256
   uint32_t* maxima = keys;                                  // 512 keys
   maxima[threadIdx.x] = kmax;
-  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = 0; }
+  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
   __syncthreads();
   const uint32_t t0 = block_kth_largest(maxima, SAMP_THREADS, w2, hist);
   __syncthreads();
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     }
   __syncthreads();
   const uint32_t m = sh[3];
-  uint32_t key1, key2, key3 = 0, key4 = 0;
+  uint32_t key1, key2, key3 = 0;
   if (m <= 256) {
     if (threadIdx.x < m) {
       const uint32_t me = hist[threadIdx.x];
@@ -503,13 +505,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
       if (gt < w1 && w1 <= ge) sh[4] = me;
       if (gt < w2 && w2 <= ge) sh[5] = me;
       if (lad_r > 0 && gt < (uint32_t)lad_r && (uint32_t)lad_r <= ge) sh[6] = me;
-      if (lad_r2 > 0 && gt < (uint32_t)lad_r2 && (uint32_t)lad_r2 <= ge) sh[8] = me;
     }
     __syncthreads();
     key1 = sh[4];
     key2 = sh[5];
     key3 = sh[6];
-    key4 = sh[8];
   } else {                                                  // a crowd of ties: plain selects over all keys
     __syncthreads();
 #pragma unroll
@@ -518,7 +518,6 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     key1 = block_kth_largest(keys, n, w1, hist);
     key2 = block_kth_largest(keys, n, w2, hist);
     if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist);
-    if (lad_r2 > 0) key4 = block_kth_largest(keys, n, (uint32_t)lad_r2, hist);
   }
   if (threadIdx.x == 0) {
     // order_slack: the sample scores were summed in another order than the scoring launch sums (K-split bootstrap,
@@ -541,15 +540,6 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
       st.lad_tc[q] = tc;
       st.lad_pack[q] = bf16_down(excluded ? INFINITY : thr) | (bf16_down(on ? tc - margin : INFINITY) << 16);
       st.lad_cnt[q] = 0;
-      if (st.lad_cnt2) {
-        // second level: t_c2 = score(lad_r2), lad_r2 < lad_r, so t_c2 >= t_c; the count levels are rounded UP to bf16 (a
-        // count may only miss rows, never gain them) and travel as one word beside a hit's scores
-        const bool on2 = on && lad_r2 > 0;
-        const float tc2 = on2 ? key2f(key4) : INFINITY;
-        st.lad_pack2[q] = bf16_down(on2 ? tc2 - margin : INFINITY) << 16;
-        st.lad_cnt2[q] = 0;
-        st.lad_lev[q] = bf16_up(tc) | (bf16_up(tc2) << 16);
-      }
     }
   }
 }
@@ -561,19 +551,19 @@ bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
 }
 
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
-                             int32_t lad_r, int32_t f32_scores, float order_slack, int32_t lad_r2) {
+                             int32_t lad_r, int32_t f32_scores, float order_slack) {
   if (first_cnt == SAMP_THREADS * 2u)
     hipLaunchKernelGGL(sample_threshold_kernel<2>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack, lad_r2);
+                       g_tail_debug_phase, order_slack);
   else if (first_cnt == SAMP_THREADS * 4u)
     hipLaunchKernelGGL(sample_threshold_kernel<4>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack, lad_r2);
+                       g_tail_debug_phase, order_slack);
   else if (first_cnt == SAMP_THREADS * 8u)
     hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack, lad_r2);
+                       g_tail_debug_phase, order_slack);
   else
     hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
-                       g_tail_debug_phase, order_slack, lad_r2);
+                       g_tail_debug_phase, order_slack);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -902,151 +892,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
   }
 }
 
-// Batches of <= 128 queries (the reference's own shapes: one query online, 70 per test set): exact re-score AND final order
-// in ONE launch, one 1024-thread workgroup per query -- its 16 waves gather the query's ~127 candidate rows two at a time
-// (rescore_kernel's arithmetic, bit for bit), the scores go to the candidate list in global memory like before and, for the
-// first 512 candidates, straight into the LDS tile as integer keys; then the same workgroup counts every candidate's
-// place (emit_kernel's order, bit for bit; eight threads per candidate at <= 128 candidates).  It saves a launch boundary
-// and the count / score round trips of emit -- and LOSES: 39 us against 19.5 + 9.0 us for the two launches at 70 queries, and
-// a single query goes from 0.693 to 0.712 ms (same box, alternating builds), because one workgroup per query gathers its
-// 1 MB of candidate rows at a fraction of the rate 64 two-row workgroups per query do.  Kept behind option "small_tail"
-// (default 0) with a parity test; the default path is rescore_kernel + emit_kernel for every batch size.
-constexpr int RE_THREADS = 1024;
-__global__ __launch_bounds__(RE_THREADS) void rescore_emit_kernel(const float* __restrict__ gal, const float* __restrict__ qry,
-                                                                  int32_t dp, const uint32_t* __restrict__ cand_rows,
-                                                                  const uint32_t* __restrict__ cand_cnt, uint32_t rcap,
-                                                                  double* __restrict__ cand_score, uint32_t last_row, int32_t k,
-                                                                  int64_t row_offset, int64_t* __restrict__ out_idx,
-                                                                  float* __restrict__ out_score, double* __restrict__ out_score64) {
-  __shared__ __attribute__((aligned(16))) uint64_t tk[EMIT_TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t ti[EMIT_TILE];
-  __shared__ uint32_t partial[RE_THREADS];
-  const uint32_t q = blockIdx.x;
-  const uint32_t nc = min(cand_cnt[q], rcap);
-  const uint32_t* rows = cand_rows + (uint64_t)q * rcap;
-  double* outs = cand_score + (uint64_t)q * rcap;
-  // slots no candidate claims (fewer than k candidates): padding
-  for (uint32_t i = nc + threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
-    out_idx[(uint64_t)q * k + i] = -1;
-    if (out_score) out_score[(uint64_t)q * k + i] = -INFINITY;
-    if (out_score64) out_score64[(uint64_t)q * k + i] = -INFINITY;
-  }
-  // ---- exact scores (rescore_kernel's loop: f32 inputs, exact f64 products, f64 accumulation, lanes stride the columns)
-  {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const float4* qv = reinterpret_cast<const float4*>(qry + (uint64_t)q * dp);
-    const int nvec = dp >> 2;
-    for (uint32_t c = (uint32_t)w * 2u; c < nc; c += 2u * (uint32_t)nw) {
-      const bool two = (c + 1 < nc);
-      const uint32_t r0 = min(rows[c], last_row), r1 = min(rows[two ? c + 1 : c], last_row);
-      const float4* g0 = reinterpret_cast<const float4*>(gal + (uint64_t)r0 * dp);
-      const float4* g1 = reinterpret_cast<const float4*>(gal + (uint64_t)r1 * dp);
-      double a0 = 0.0, a1 = 0.0;
-      int v = lane;
-      for (; v + 192 < nvec; v += 256) {
-        float4 x[4], y0[4], y1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          x[u] = qv[v + 64 * u];
-          y0[u] = nt_load4(g0 + v + 64 * u);
-          y1[u] = nt_load4(g1 + v + 64 * u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a0 += (double)x[u].x * (double)y0[u].x; a0 += (double)x[u].y * (double)y0[u].y;
-          a0 += (double)x[u].z * (double)y0[u].z; a0 += (double)x[u].w * (double)y0[u].w;
-          a1 += (double)x[u].x * (double)y1[u].x; a1 += (double)x[u].y * (double)y1[u].y;
-          a1 += (double)x[u].z * (double)y1[u].z; a1 += (double)x[u].w * (double)y1[u].w;
-        }
-      }
-      for (; v < nvec; v += 64) {
-        const float4 x = qv[v];
-        const float4 y0 = g0[v];
-        const float4 y1 = g1[v];
-        a0 += (double)x.x * (double)y0.x; a0 += (double)x.y * (double)y0.y;
-        a0 += (double)x.z * (double)y0.z; a0 += (double)x.w * (double)y0.w;
-        a1 += (double)x.x * (double)y1.x; a1 += (double)x.y * (double)y1.y;
-        a1 += (double)x.z * (double)y1.z; a1 += (double)x.w * (double)y1.w;
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        a0 += __shfl_xor(a0, o);
-        a1 += __shfl_xor(a1, o);
-      }
-      if (lane == 0) {
-        outs[c] = a0;
-        if (c < EMIT_TILE) { tk[c] = emit_key(a0); ti[c] = rows[c]; }
-        if (two) {
-          outs[c + 1] = a1;
-          if (c + 1 < EMIT_TILE) { tk[c + 1] = emit_key(a1); ti[c + 1] = rows[c + 1]; }
-        }
-      }
-    }
-  }
-  {                                                           // padding of the first tile to a multiple of four
-    const uint32_t tn = min(EMIT_TILE, nc), tn4 = (tn + 3u) & ~3u;
-    if (threadIdx.x >= tn && threadIdx.x < tn4) { tk[threadIdx.x] = 0ull; ti[threadIdx.x] = 0xFFFFFFFFu; }
-  }
-  __syncthreads();       // scores: in LDS (first tile) and, through this workgroup-scope release / acquire, in global memory
-  // ---- places (emit_kernel's counting, `parts` threads per candidate)
-  const uint32_t T = blockDim.x;
-  const uint32_t parts = nc <= T / 8u ? 8u : nc <= T / 4u ? 4u : nc <= T / 2u ? 2u : 1u;
-  const uint32_t per = T / parts;
-  const uint32_t local = threadIdx.x & (per - 1u), part = threadIdx.x / per;
-  for (uint32_t i0 = 0; i0 < nc; i0 += per) {
-    const uint32_t i = i0 + local;
-    const bool mine = i < nc;
-    uint64_t ka = 0ull;
-    uint32_t ia = 0u;
-    if (mine) {
-      if (nc <= EMIT_TILE) { ka = tk[i]; ia = ti[i]; }        // one tile: staged by the re-score phase and never replaced
-      else { ka = emit_key(outs[i]); ia = rows[i]; }
-    }
-    uint32_t place = 0;
-    for (uint32_t t0 = 0; t0 < nc; t0 += EMIT_TILE) {
-      const uint32_t tn = min(EMIT_TILE, nc - t0), tn4 = (tn + 3u) & ~3u;
-      if (nc > EMIT_TILE) {                                   // more than one tile (degenerate data): (re)stage this one
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < tn4; e += blockDim.x) {
-          tk[e] = e < tn ? emit_key(outs[t0 + e]) : 0ull;
-          ti[e] = e < tn ? rows[t0 + e] : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-      }
-      if (mine) {
-        const uint32_t groups = tn4 >> 2, g0 = groups * part / parts, g1 = groups * (part + 1u) / parts;
-#pragma unroll 2
-        for (uint32_t e = g0 * 4u; e < g1 * 4u; e += 4) {
-          const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(tk + e), k23 = *reinterpret_cast<const ulonglong2*>(tk + e + 2);
-          const uint4 id4 = *reinterpret_cast<const uint4*>(ti + e);
-          const uint64_t kb[4] = {k01.x, k01.y, k23.x, k23.y};
-          const uint32_t ib[4] = {id4.x, id4.y, id4.z, id4.w};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) place += ((kb[u] > ka) || (kb[u] == ka && ib[u] < ia)) ? 1u : 0u;   // "b comes before a"
-        }
-      }
-    }
-    if (parts > 1u) {                                         // (block-uniform) combine the shares of a candidate
-      __syncthreads();
-      partial[threadIdx.x] = place;
-      __syncthreads();
-      if (mine && part == 0u)
-        for (uint32_t pp = 1; pp < parts; ++pp) place += partial[pp * per + local];
-    }
-    if (mine && part == 0u && place < (uint32_t)k) {
-      const double a = outs[i];
-      out_idx[(uint64_t)q * k + place] = row_offset + (int64_t)ia;
-      if (out_score) out_score[(uint64_t)q * k + place] = (float)a;
-      if (out_score64) out_score64[(uint64_t)q * k + place] = a;
-    }
-  }
-}
-
-void launch_rescore_emit(const float* gal_f32, const float* qry_f32, int32_t dp, int32_t nq, const uint32_t* cand_rows,
-                         const uint32_t* cand_cnt, uint32_t rcap, double* cand_score, uint32_t last_row, int32_t k,
-                         int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64, hipStream_t stream) {
-  hipLaunchKernelGGL(rescore_emit_kernel, dim3(nq), dim3(RE_THREADS), 0, stream, gal_f32, qry_f32, dp, cand_rows, cand_cnt,
-                     rcap, cand_score, last_row, k, row_offset, out_idx, out_score, out_score64);
-}
+// (A one-launch re-score + order kernel for batches of <= 128 queries was built in round 3 and measured slower -- 39 us against
+// 19.5 + 9.0 us at 70 queries, profiles/r03*: one workgroup per query gathers its candidate rows at a fraction of the rate of 64
+// two-row workgroups -- and removed in round 5.)
 
 void launch_emit(const uint32_t* cand_rows, const uint32_t* cand_cnt, const double* cand_score, uint32_t rcap,
                  int32_t nq, int32_t k, int64_t row_offset, int64_t* out_idx, float* out_score, double* out_score64,

@@ -26,6 +26,8 @@ TOPK_PATH_MAX_K = 2048      # beyond this the full-length ranking path is used
 
 _cache = {}
 _cache_lock = threading.Lock()
+_savers = {}                # cache key -> thread writing that gallery's file behind the call that built it
+last_timing = {}            # what the last get_gallery() did: {"source": built | cached | file, "build_s", "save": ...}
 
 
 def _gallery_path(dataset, norm_mode=NORM_L2):
@@ -35,36 +37,84 @@ def _gallery_path(dataset, norm_mode=NORM_L2):
     return os.path.join("outputs", dataset.replace("/", "_"), "mi355_gallery_%s.bin" % suffix)
 
 
+def _save_behind(key, g, path):
+    """The prepared-gallery file (12 GB at the 1M-row size: ~1.2 s of D2H + page-cache writes) is written by a thread of its
+    own AFTER the gallery is usable: the caller's timer (matching_<method> times everything it does, src/utils/nnsearch.py:688-705)
+    no longer spans it.  mi_gallery_save only reads the handle's immutable buffers on a stream of its own, so searches run
+    beside it.  Written to a temporary name and renamed: a reader never sees half a file."""
+    def work():
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        t0 = time.time()
+        try:
+            g.save(tmp)
+            os.replace(tmp, path)
+            last_timing["save"] = {"seconds": time.time() - t0, "path": path, "behind_the_call": True}
+        except Exception as e:            # the file is a cache: failing to write it must not fail a search that succeeded
+            last_timing["save"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+    th = threading.Thread(target=work, name="mi355-gallery-save", daemon=False)
+    _savers[key] = th
+    th.start()
+
+
+def wait_for_saves():
+    """Blocks until every write-behind gallery file is complete (a process that exits joins them anyway)."""
+    for key in list(_savers):
+        th = _savers.pop(key, None)
+        if th is not None:
+            th.join()
+
+
+def _join_saver(key):
+    th = _savers.pop(key, None)
+    if th is not None:
+        th.join()
+
+
 def get_gallery(train, dataset=None, ifgenerate=False, norm_mode=NORM_L2, device=0):
     """Device-resident prepared gallery for `train` [N,D].
 
     dataset=None: a fresh (uncached) gallery.  Otherwise the gallery is cached in-process under
-    `dataset`, persisted to outputs/<dataset>/mi355_gallery.bin, and rebuilt iff `ifgenerate`
-    (or when its shape no longer matches `train`, which the reference leaves to the user:
+    `dataset`, persisted to outputs/<dataset>/mi355_gallery_<norm>.bin (written behind the call, _save_behind), and rebuilt
+    iff `ifgenerate` (or when its shape no longer matches `train`, which the reference leaves to the user:
     README "delete the cache when the database changes")."""
+    last_timing.clear()
     if dataset is None:
-        return _build_gallery(train, norm_mode, device)
+        t0 = time.time()
+        g = _build_gallery(train, norm_mode, device)
+        last_timing.update(source="built", build_s=time.time() - t0)
+        return g
     key = (dataset, norm_mode, device)
     with _cache_lock:
         g = _cache.get(key)
         shape = _train_shape(train)
         if g is not None and not ifgenerate and (g.n, g.d) == shape:
+            last_timing.update(source="cached")
             return g
+        _join_saver(key)                  # the handle about to be closed / the file about to be replaced may still be written
         if g is not None:
             g.close()
             _cache.pop(key, None)
         path = _gallery_path(dataset, norm_mode)
+        t0 = time.time()
         if not ifgenerate and os.path.exists(path):
             g = Gallery.load(path, device=device)
             if (g.n, g.d) != shape or g.norm_mode != norm_mode:
                 g.close()
                 g = None
+            else:
+                last_timing.update(source="file", load_s=time.time() - t0)
         else:
             g = None
         if g is None:
+            t0 = time.time()
             g = _build_gallery(train, norm_mode, device)
+            last_timing.update(source="built", build_s=time.time() - t0)
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            g.save(path)
+            _save_behind(key, g, path)
         _cache[key] = g
         return g
 
@@ -90,6 +140,7 @@ def _build_gallery(train, norm_mode, device):
 
 def drop_cached_galleries():
     with _cache_lock:
+        wait_for_saves()
         for g in _cache.values():
             g.close()
         _cache.clear()

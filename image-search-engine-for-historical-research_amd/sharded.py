@@ -113,7 +113,7 @@ class ShardedGallery:
                 osc=torch.empty((nq, k), dtype=torch.float32, device=device))
         return self._buf[key]
 
-    def search(self, q, k, query_norm_none=False, verify=False, join=True, next_q=None):
+    def search(self, q, k, query_norm_none=False, verify=False, join=True):
         """q: [Q, D] float32 cuda tensor (same on every rank), Q <= 1024.
         Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.  They are this object's
         buffers for (Q, k): the next search of the same shape overwrites them (clone what must outlive it).
@@ -127,12 +127,7 @@ class ShardedGallery:
 
         join: only matters when the shard's handle runs in the asynchronous-tail mode (`set_option("async_tail", 1)`,
         single shard): join=False leaves the exact re-score + sort of this batch running on the handle's own stream
-        beside the scoring launch of the next search; the returned tensors are complete after `self.g.join(stream)`.
-
-        next_q: the batch the NEXT search call will be made with (same k; single shard only): its query ingest, bootstrap and
-        thresholds are enqueued behind this call's scoring launch and run beside this call's scatter / maintain launches
-        (`mi_knn_set_lookahead`).  Purely a throughput hint: a next call with other queries is answered all the same."""
-        self._next_q = next_q if (next_q is not None and not self._protocol and not verify) else None
+        beside the scoring launch of the next search; the returned tensors are complete after `self.g.join(stream)`."""
         if query_norm_none:
             self.g.set_option("query_norm_override", _lib.NORM_NONE)
         self._join = join or verify
@@ -247,10 +242,6 @@ class ShardedGallery:
         b = self._buffers(nq, k, q.device)
         stream = torch.cuda.current_stream().cuda_stream
         if not self._protocol:
-            nxt = getattr(self, "_next_q", None)
-            if nxt is not None:
-                self.g.set_lookahead(nxt.data_ptr(), nxt.shape[0])
-                self._next_q = None
             self.g.search_device(q.data_ptr(), nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), None, stream)
             if self._join:
                 self.g.join(stream)

@@ -108,19 +108,6 @@ int mi_knn_search_device(mi_gallery* g, const float* q_dev, int64_t nq, int32_t 
  * its scoring launch (or by mi_search_join, or by any call that cannot carry it on): the re-score gather then shares the
  * device with the power-bound scoring launch only.  The output buffers of a call must stay valid until the join. */
 int mi_search_join(mi_gallery* g, void* stream);
-/* Lookahead for streams of mi_knn_search_device calls (round 4).  Everything a batch does BEFORE its scoring launch -- query
- * ingest, the bootstrap launch on the threshold sample, the thresholds -- depends on its queries only, and so does not have to
- * wait for the previous batch's scatter / maintain (/ re-score) launches; both are chains of small latency-bound launches
- * that leave most of the chip idle.  mi_knn_set_lookahead(handle, q_next, nq_next) announces the batch of the NEXT
- * mi_knn_search_device call (device rows [nq_next][d] f32, valid on the stream of the search call that follows, nq_next <= 1024,
- * same k): that search call enqueues the announced batch's pre part on the handle's own stream right behind its scoring
- * launch, in the handle's second workspace, and the next search call -- same pointer, count and k -- goes straight to its scoring
- * launch.  One-shot; a next call that does not match simply does its own pre part.  Answers are unchanged, bit for bit.
- * A host call with more than 1024 queries does this between its internal batches with option "stream_lookahead".  q_next = NULL
- * withdraws.  Measured on MI355X (profiles/r04e_lookahead_*): the overlap happens and buys nothing -- the empty repair launch
- * of the current batch needs a whole CU's LDS and waits for the announced batch's bootstrap launch, and the waits between
- * hardware queues cost what the overlap saves; bench.py uses it only with --lookahead. */
-int mi_knn_set_lookahead(mi_gallery* g, const float* q_next_dev, int64_t nq_next);
 
 /* Sharded search = phase 1 on every shard, all-gather of approx top-k values, phase 2, all-gather of
  * exact (score64, idx), merge.  New functionality (the reference is single-process).
@@ -295,40 +282,43 @@ typedef struct mi_search_stats {
                                * MFMA load, so this is what the dense peak scales with */
   int64_t spec_retries;       /* batches whose speculative threshold failed its verification (and, where a device repair pass ran,
                                * that too): answered again by the rigorous chunk schedule.  Not an overflow */
+  int64_t inkernel_repairs;   /* queries of batches of <= 128 queries on the asynchronous (device / phase) entry points whose
+                               * speculative threshold failed and that were repaired INSIDE the maintain launch: the query's workgroup
+                               * rescans the whole shard (~0.1 s per 1 M rows x 2048, over 1 s on a 10 M-row shard; expected once per
+                               * ~10^7 queries).  The answer is complete; this counter is the only trace of why that call was slow */
 } mi_search_stats;
 int mi_profile_enable(mi_gallery* g, int on);      /* times the scoring launches with HIP events (dispatch timestamps) */
 int mi_search_status(mi_gallery* g, mi_search_stats* out, int reset); /* synchronises the handle's work */
 /* The durations (ms, launch order) of the timed scoring launches since the last mi_search_status(reset = 1): what gemm_ms is
  * the sum of.  Waits for the launches enqueued so far; writes min(count, cap) values, *out_count = launches logged. */
 int mi_profile_launch_ms(mi_gallery* g, float* out_host, int64_t cap, int64_t* out_count);
-/* Tunables: "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
+/* Tunables (19 names; everything that was an A/B switch of a measured-and-rejected variant -- "debug", "kernel_variant",
+ * "small_tail", "stream_lookahead", "inkernel_repair_max", "ladder" = 2 -- left the product in round 5: MI_ERR_INVALID):
+ * "chunk0_tiles" (rows / 256 of the bootstrap chunk and of the threshold sample; 0 = default 32), "chunk_growth",
  * "workspace_slot" (0 | 1: which of the handle's two per-batch workspaces the phase API uses -- phase 1 of batch i + 1 may
  * be enqueued before phase 2 of batch i; sticky flags and statistics are one set for both),
  * "spec_max_ratio" (largest shard rows / sample rows for which the single-launch sample schedule is taken; default 160),
  * "survivor_cap", "rescore_cap", "exact_fallback" (0 = report MI_ERR_OVERFLOW instead of falling back to the f32 scorer and
- * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel: 0 = off, 1 = one level (default), 2 = two levels -- built and measured
- * 1.3 % slower), "boot_ksplit" (batches of <= 512 queries: the bootstrap launch
+ * then the dense f64 path), "ladder" (in-launch threshold ladder of the tile kernel: 0 = off, 1 = on (default)),
+ * "boot_ksplit" (batches of <= 512 queries: the bootstrap launch
  * on the sample splits K over several workgroups that add their partial scores with float atomics; default 1.  The order of
  * those adds is not fixed, so the sample scores -- and with them the survivor / candidate statistics and which queries need a
  * repair -- may differ by an ulp from run to run; the answers do not: the threshold is speculative and verified), "xcc_balance" (XCD shares by measured
  * speed), "stream_tail" (default 1: a HOST entry point called with more than 1024 queries runs its internal batches with the
  * deferred tail of "async_tail" 3 and reads the sticky flags once at the end; 0 = one verified batch after the other),
- * "inkernel_repair_max" (default 128: batches up to this many queries repair a failed speculative threshold inside the maintain
- * launch on the asynchronous entry points; measured for 1024-query batches: 11 us SLOWER per batch than the three empty repair
- * launches, the scanning instantiation of the kernel runs at a lower occupancy), "stream_lookahead" (default 0: such a call also announces every internal batch to its predecessor, see mi_knn_set_lookahead), "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
+ * "async_tail" (1 | 2 | 3: re-score + sort on the handle's own stream beside the next batch's scoring launch | beside its
  * query ingest and bootstrap only | deferred: enqueued by the next call right before its scoring launch; see mi_search_join), "rescore_grid_x" (workgroups of 2
  * candidates per query in the re-score launch; 0 = 64; a shard of a G-way gallery sets ~96 / G),
  * "force_exact" (score with the f32 kernel instead of the 16-bit MFMA), "speculative" (0 = rigorous chunk schedule only),
  * "device_repair" (-1 = default: the scoring launch of a batch of > 128 queries is followed by a device-conditional repair
  * pass for queries whose speculative threshold failed verification; smaller batches launch none: through a HOST entry point
  * the sticky flag makes the call answer the batch again, through the asynchronous device / phase entry points the workgroup
- * of the failed query repairs it inside the maintain launch (a scan of the shard's rows, ~0.1 s per million, once per 10^7
- * queries), so their answers are complete without anybody reading flags; 0 / 1 = never / always launch the repair pass),
- * "small_tail" (1 = batches of <= 128 queries re-score and
- * order in one launch; measured slower, default 0),
+ * of the failed query repairs it inside the maintain launch (a scan of the shard's rows, ~0.1 s per million -- over a second
+ * on a 10 M-row shard --, once per 10^7 queries; counted in mi_search_stats.inkernel_repairs), so their answers are complete
+ * without anybody reading flags; 0 / 1 = never / always launch the repair pass),
  * "small_batch_kernel" (0 = batches of <= 128 queries use the 256 x 256-tile kernel too),
  * "query_norm_override" (-1 | mi_norm: how the _device entry points normalise their queries; MI_NORM_NONE for the
- * already normalised expanded queries of alpha-QE), "kernel_variant" (structure of the tile kernel, A/B only).
+ * already normalised expanded queries of alpha-QE).
  * mi_get_option also answers "image_dtype" (1 = fp16, 0 = bf16; read-only, see mi_gallery_set_image_dtype) and
  * "sample_rows" (rows of the threshold sample in effect). */
 int mi_set_option(mi_gallery* g, const char* name, double value);

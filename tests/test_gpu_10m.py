@@ -1,11 +1,13 @@
 """GPU: BASELINE.json configs[3]'s gallery on ONE GPU -- 10,000,000 x 2048 rows with a bf16 image (the chunk schedule of
-the tile kernel over 39,063 gallery tiles; 82 GB of stored f32 rows + 41 GB of image) -- through size-independent
+the tile kernel over 39,063 gallery tiles; 82 GB of stored f32 rows + 41 GB of image) -- against the oracle itself for 4
+queries (every one of the 10 M stored rows scored in float64 on the host, tests/_fullsize.py) and through size-independent
 properties: equality with the f32-scored path, float64 re-computation of returned scores, planted neighbours at both
 ends and on both sides of every chunk seam.  Rows are generated on the device."""
 import numpy as np
 import pytest
 
 from isehr_amd.synth import synth_rows
+from _fullsize import assert_oracle_parity, host_f64_scores_and_topk
 
 pytestmark = pytest.mark.gpu
 N, D, K = 10_000_000, 2048, 100
@@ -98,6 +100,18 @@ def test_10m_full_batch_tile_kernel_equals_the_f32_scored_path(huge):
     _check_scores_f64(g, q, idx, sc, range(0, 1024, 128))
     idx2, sc2 = _search(g, q, 1024)                                   # idempotent
     assert np.array_equal(idx, idx2) and np.array_equal(sc, sc2)
+
+
+def test_10m_against_the_oracle_itself(huge):
+    """4 queries x 10 000 000 rows in float64 on the host (64 k-row chunks of get_rows(), oracle.exact_scores_f64 /
+    exact_topk_f64 / merge_topk), the answers inside the 1024-query batch (bf16 image, chunk schedule) judged by
+    oracle.check_topk_parity at 1e-6.  Queries 2 and 4 are planted on the far side of the chunk seams."""
+    g, q = huge
+    pick = np.array([2, 4, 6, 700])
+    scores, top_i, top_s = host_f64_scores_and_topk(g, q.cpu().numpy()[pick], K, workers=12)
+    assert [int(top_i[j, 0]) for j in range(3)] == [PLANTS[2], PLANTS[4], PLANTS[6]]
+    idx, sc = _search(g, q, 1024)
+    assert_oracle_parity(idx[pick], sc[pick], scores, top_i, top_s, K)
 
 
 def test_10m_answers_equal_the_dense_float64_search(huge):

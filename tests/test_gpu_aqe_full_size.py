@@ -1,9 +1,12 @@
 """GPU: BASELINE.json configs[4] at its own size -- rParis6k + 1M distractors, N = 1,007,323 x 2048, alpha-QE (k = 3,
-w = 4, N >= 120 000 branch of QGE: src/utils/Reranking.py:195-208, 273-283) then re-search, K = 100 -- through
-size-independent properties: the expanded queries against a float64 re-computation from the stored rows, the re-search
-against the f32-scored path, the returned scores against float64."""
+w = 4, N >= 120 000 branch of QGE: src/utils/Reranking.py:195-208, 273-283) then re-search, K = 100 -- against the
+oracle itself for 8 queries (every stored row scored in float64 on the host) and through size-independent properties: the
+expanded queries against a float64 re-computation from the stored rows, the re-search against the f32-scored path, the
+returned scores against float64."""
 import numpy as np
 import pytest
+
+from _fullsize import assert_oracle_parity, host_f64_scores_and_topk
 
 pytestmark = pytest.mark.gpu
 N, D, K, NQ = 1007323, 2048, 100, 70          # 70 queries: rParis6k's query set
@@ -51,6 +54,12 @@ def test_aqe_at_rparis_plus_1m():
         for qi in range(0, NQ, 7):
             rows = np.stack([g.get_rows(int(r), 1)[0] for r in aidx[qi]]).astype(np.float64)
             assert np.abs(rows @ qx32[qi] - asc[qi]).max() < 3e-7
+        # the oracle itself at this size: the expanded queries of 8 queries (used as they are: no second normalisation, like
+        # `scores = np.dot(vecs.T, qvecs_qe)`, src/utils/Reranking.py:206) against all 1 007 323 stored rows in float64 on the
+        # host; the re-search's answer must be that ranking's top-100
+        pick = np.arange(0, NQ, 9)
+        scores, top_i, top_s = host_f64_scores_and_topk(g, qx32[pick], K, normalize_queries=False)
+        assert_oracle_parity(aidx[pick], asc[pick], scores, top_i, top_s, K)
         # re-search vs the f32-scored path
         g.set_option("force_exact", 1)
         try:

@@ -20,14 +20,20 @@ def _bench(args, env_extra=None, timeout=600):
                        timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines                                     # stdout carries the one JSON line only
-    return json.loads(lines[0])
+    # stdout carries the JSON line and nothing else: once as soon as the headline is measured (complete: false) and once more,
+    # complete, at the end -- possibly refreshed in between; the driver parses the LAST line
+    recs = [json.loads(ln) for ln in lines]
+    assert len(recs) >= 2 and recs[0]["complete"] is False and recs[-1]["complete"] is True, lines
+    assert all(rc["value"] == recs[0]["value"] for rc in recs)         # the headline never changes once it is out
+    return recs[-1]
 
 
 def test_bare_gpus_2_runs_two_ranks():
     out = _bench(["--gpus", "2", "--rows", "200000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
                  {"ISEHR_DIST_BACKEND": "gloo", "ISEHR_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["comm_backend"] == "gloo"
+    assert out["config"]["rccl_ranks_equal_n_gpus"] is True and len(out["config"]["rank_devices"]) == 2
+    assert out["config"]["rank_devices_distinct"] is False             # (rehearsal: both ranks share the box's one GPU)
     assert out["config"]["gallery_rows"] == 200000 and out["steps"] == 4 and out["value"] > 0
     assert "scale_10m" not in out                                     # --rows override: the secondary block is off
 
@@ -56,6 +62,8 @@ def test_one_gpu_line_has_the_contract_fields():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["cpu_model"]
     pts = {(p["queries"], p["threads"] == 1) for p in cb["blas"]["points"]}
     assert {(1024, True), (70, True), (1, True)} <= pts and any(q == 70 and not one for q, one in pts)
+    assert cb["value_blas"] == cb["blas"]["value"] and "faiss" in cb and out["vs_cpu_baseline"]["blas_full_width"] > 1
+    assert out["value_synchronous"] == out["synchronous"]["value"]
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["launches"] == 5
 
@@ -66,7 +74,7 @@ def test_default_shape_line_carries_the_secondary_blocks():
     and on whose undisturbed launches `roofline` is quoted --, `scale_10m` (here on a smaller row count) and `map`: mAP
     (E / M / H) of the HIP ranks on the planted rOxford5k- / +rParis6k-sized datasets."""
     out = _bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--scale-10m", "on", "--scale-10m-rows", "400000",
-                  "--scale-10m-steps", "2"])
+                  "--scale-10m-steps", "2", "--extra-blocks", "off"])
     assert out["config"]["gallery_rows"] == 1005994 and out["config"]["tail"].startswith("deferred")
     assert out["config"]["value_mode"].startswith("pipelined") and "mi_knn_dense64_search" in out["config"]["score_check"]
     d = out["synchronous"]
@@ -82,6 +90,37 @@ def test_default_shape_line_carries_the_secondary_blocks():
     assert [b["gallery_rows"] for b in m] == [4993, 11315]
     for b in m:
         assert 0 < b["map"]["H"] <= b["map"]["M"] <= 1 and 0 < b["map"]["E"] <= 1 and b["time_per_query_s"] > 0
+
+
+def test_default_line_gives_every_baseline_config_a_number():
+    """the default one-GPU line also carries `q70` and `q1` (HBM-bound small batches on the resident
+    gallery, fraction of 8 TB/s), `aqe_rparis_1m` (configs[4]: alpha-QE at 1 007 323 rows, 1024 and 70 queries), `qge_small`
+    (the diffusion branch at rOxford5k size) and `dropin`: matching_HIP(K, vecs.T, qvecs.T[, dataset]) on a HOST [2048, 1 005 994]
+    float32 array -- the call src/test_rOP1m.py:155-159 makes -- stateless, stateful first / cached / from the file, with the
+    prepared-gallery file written BEHIND the first call, and the float64 case of src/online.py:96."""
+    out = _bench(["--steps", "10", "--warmup", "2", "--scale-10m", "off", "--cpu-sample-rows", "8192"], timeout=900)
+    for name in ("q70", "q1"):
+        b = out[name]
+        assert b["roofline"]["bound"] == "hbm" and 0.3 < b["roofline"]["frac"] < 1 and b["flagged_batches"] == 0
+        assert b["value"] > 0 and b["roofline"]["kernel"] == "stream_select_kernel"
+    a = out["aqe_rparis_1m"]
+    assert a["gallery_rows"] == 1007323 and a["q1024"]["value"] > 0 and a["q70"]["value"] > 0
+    assert a["q1024"]["flagged_batches"] == 0 and "dense float64" in a["q70"]["score_check"]
+    g = out["qge_small"]
+    assert g["gallery_rows"] == 4993 and g["offline_diffusion_s"] > 0 and g["online_value"] > 0
+    assert g["max_abs_map_difference_alpha_qe"] <= 1e-6 and "_ranks_aqe" not in g
+    assert 0 < g["map"]["diffusion"]["M"] <= 1
+    d = out["dropin"]
+    assert d["same_answers"] is True and d["bytes"] == 2048 * 1005994 * 4 and d["pinned_h2d_GBps"] > 5
+    c = d["calls"]
+    assert c["dataset_first_call"]["gallery"]["source"] == "built" and c["dataset_cached"]["gallery"]["source"] == "cached"
+    assert c["dataset_from_file"]["gallery"]["source"] == "file"
+    assert c["dataset_first_call"]["file_written_behind_the_call"]["behind_the_call"] is True
+    # the 12 GB file no longer sits in the caller's timer: the first stateful call costs about what the stateless one does
+    assert c["dataset_first_call"]["wall_s"] < 2.0 * c["stateless"]["wall_s"] + 0.2
+    assert c["dataset_cached"]["time_per_query_s"] < 0.1 * c["stateless"]["time_per_query_s"]
+    assert d["float64_online_case"]["equals_f32_answer_of_the_same_rows"] is True
+    assert out["cpu_baseline"]["value_blas"] > out["cpu_baseline"]["value"]
 
 
 def test_explicit_synchronous_headline():

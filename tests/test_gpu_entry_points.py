@@ -40,6 +40,7 @@ def test_offline_then_online(feature_store, capsys):
     vecs, qvecs, _ = feature_store
     assert offline.main(["--datasets", "dsA,dsB", "--matching_method", "HIP", "--ifgenerate"]) == 0
     assert "prepared on GPU" in capsys.readouterr().out
+    nnsearch.wait_for_saves()                                         # (written behind the call that built it)
     assert any(f.startswith("mi355_gallery") for f in os.listdir("outputs/database"))     # persisted like the ANN indexes
     nnsearch.drop_cached_galleries()                                  # a new process: the gallery comes from the file
     db, paths = load_database(["dsA", "dsB"])

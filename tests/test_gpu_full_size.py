@@ -1,9 +1,11 @@
-"""GPU: BASELINE.json's full size (rOxford5k + 1M distractors: N = 1,005,994 x D = 2048, K = 100) through
-size-independent properties -- the oracle cannot run here.  Gallery rows are generated on the device."""
+"""GPU: BASELINE.json's full size (rOxford5k + 1M distractors: N = 1,005,994 x D = 2048, K = 100): against the oracle itself
+for 8 queries (every stored row scored in float64 on the host, tests/_fullsize.py) and through size-independent properties
+for whole batches.  Gallery rows are generated on the device."""
 import numpy as np
 import pytest
 
 from isehr_amd.synth import synth_rows
+from _fullsize import assert_oracle_parity, host_f64_scores_and_topk, stored_rows_are_the_normalised_raw_rows
 
 pytestmark = pytest.mark.gpu
 N, D, K = 1005994, 2048, 100
@@ -41,6 +43,29 @@ def _search(g, q, nq):
     g.search_device(q.data_ptr(), nq, K, idx.data_ptr(), sc.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     return idx.cpu().numpy(), sc.cpu().numpy()
+
+
+def test_full_size_against_the_oracle_itself(big):
+    """8 queries x 1 005 994 rows scored in float64 ON THE HOST in 64 k-row chunks of get_rows() (numpy:
+    oracle.exact_scores_f64 / exact_topk_f64 per chunk, oracle.merge_topk over the chunks) -- the ranking matching_L2 computes
+    (src/utils/nnsearch.py:699-703) -- and the library's answers judged by oracle.check_topk_parity at 1e-6: the 8 queries
+    alone (streaming kernel), inside a 64-query batch, and inside the benchmarked 1024-query batch (tile kernel).  The stored
+    rows themselves are checked against the reference's normalisation on two 4096-row stretches regenerated on the host."""
+    g, _, _, q = big
+    pick = np.array([0, 1, 2, 5, 77, 300, 640, 1023])
+    qh = q.cpu().numpy()
+    scores, top_i, top_s = host_f64_scores_and_topk(g, qh[pick], K)
+    assert list(top_i[:3, 0]) == [7, 500000, N - 1]                  # the planted copies, found by the oracle too
+    for nq in (1024, 64):
+        idx, sc = _search(g, q, nq)
+        sel = pick[pick < nq]
+        assert_oracle_parity(idx[sel], sc[sel], scores[:len(sel)], top_i[:len(sel)], top_s[:len(sel)], K)
+    idx8, sc8 = _search(g, q[pick].contiguous(), 8)
+    assert_oracle_parity(idx8, sc8, scores, top_i, top_s, K)
+    assert g.status()["overflow_batches"] == 0
+    for row0 in (8192, N - 4096):                                    # (clear of the planted rows 7, 500000; N - 1 is planted)
+        raw = synth_rows(1234, row0, 4095, D)
+        stored_rows_are_the_normalised_raw_rows(g, raw, row0)
 
 
 def test_full_size_properties(big):
@@ -193,9 +218,9 @@ def test_full_size_answers_equal_the_dense_float64_search(big):
 
 
 def test_full_size_every_mode_gives_the_same_answers(big):
-    """The benchmarked gallery through every mode a stream of batches can run in -- synchronous tail / deferred tail, with and
-    without the next batch announced (mi_knn_set_lookahead), after a calibration, batches of 1024 / 700 / 129 queries in one
-    stream -- against the plain one-call-at-a-time answers, bit for bit."""
+    """The benchmarked gallery through every mode a stream of batches can run in -- synchronous tail / deferred tail, after a
+    calibration, batches of 1024 / 700 / 129 queries in one stream -- against the plain one-call-at-a-time answers, bit for
+    bit."""
     import torch
     g, _, _, q = big
     dev, s = q.device, torch.cuda.current_stream().cuda_stream
@@ -207,20 +232,17 @@ def test_full_size_every_mode_gives_the_same_answers(big):
     qs = [b.contiguous() for b in batches]
     g.calibrate(4, s)
     for tail in (0, 3):
-        for announce in (False, True):
-            g.set_option("async_tail", tail)
-            try:
-                outs = [(torch.empty((b.shape[0], K), dtype=torch.int64, device=dev),
-                         torch.empty((b.shape[0], K), dtype=torch.float32, device=dev)) for b in qs]
-                for rep in range(2):
-                    for j, (b, (oi, os_)) in enumerate(zip(qs, outs)):
-                        if announce and j + 1 < len(qs):
-                            g.set_lookahead(qs[j + 1].data_ptr(), qs[j + 1].shape[0])
-                        g.search_device(b.data_ptr(), b.shape[0], K, oi.data_ptr(), os_.data_ptr(), None, s)
-                g.join(s)
-                torch.cuda.synchronize()
-                assert g.flags() == 0
-                for (ri, rs), (oi, os_) in zip(ref, outs):
-                    assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(os_.cpu().numpy(), rs), (tail, announce)
-            finally:
-                g.set_option("async_tail", 0)
+        g.set_option("async_tail", tail)
+        try:
+            outs = [(torch.empty((b.shape[0], K), dtype=torch.int64, device=dev),
+                     torch.empty((b.shape[0], K), dtype=torch.float32, device=dev)) for b in qs]
+            for rep in range(2):
+                for b, (oi, os_) in zip(qs, outs):
+                    g.search_device(b.data_ptr(), b.shape[0], K, oi.data_ptr(), os_.data_ptr(), None, s)
+            g.join(s)
+            torch.cuda.synchronize()
+            assert g.flags() == 0
+            for (ri, rs), (oi, os_) in zip(ref, outs):
+                assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(os_.cpu().numpy(), rs), tail
+        finally:
+            g.set_option("async_tail", 0)

@@ -168,10 +168,14 @@ def test_matching_hip_dataset_cache(tmp_path, monkeypatch):
     g = synth_rows(2, 0, 2000, 64)
     q = synth_rows(3, 0, 4, 64)
     i1, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=True)
+    assert nnsearch.last_timing["source"] == "built"
+    nnsearch.wait_for_saves()                               # the file is written behind the call (round 5)
     assert os.path.exists(os.path.join("outputs", "unit_test", "mi355_gallery_l2.bin"))
+    assert not [f for f in os.listdir(os.path.join("outputs", "unit_test")) if ".tmp." in f]
     i2, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=False)      # in-process cache
     nnsearch.drop_cached_galleries()
     i3, _ = nnsearch.matching_HIP(10, g, q, dataset="unit/test", ifgenerate=False)      # from disk
+    assert nnsearch.last_timing["source"] == "file"
     nnsearch.drop_cached_galleries()
     assert np.array_equal(i1, i2) and np.array_equal(i1, i3)
 
