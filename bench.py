@@ -753,13 +753,18 @@ def aqe_rparis_block(job, args):
             steps = 10
             t0 = time.perf_counter()
             for i in range(steps):
-                idx1, (idx2, sc2, qx) = step(pool[i % 2])
+                step(pool[i % 2])
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             st = gal.status(reset=True)
-            # checks: (i) the expansion of 4 queries recomputed in float64 from the stored rows, (ii) the re-search of 8 expanded
-            # queries against every row in float64 (dense path: no thresholds)
-            idx1_h, qx_h = idx1[:4].cpu().numpy(), qx[:8].cpu().numpy()
+            # checks (one more, untimed step: the first search's result buffer is reused by the re-search, so its top-3 ids are
+            # copied before the expansion): (i) the expansion of 4 queries recomputed in float64 from the stored rows, (ii) the
+            # re-search of 8 expanded queries against every row in float64 (dense path: no thresholds)
+            idx1, _ = sg.search(pool[(steps - 1) % 2], k)
+            idx1_h = idx1[:4, :3].cpu().numpy()
+            idx2, sc2, qx = sg.aqe_search(idx1.t(), 3, 4.0, k)
+            torch.cuda.synchronize()
+            qx_h = qx[:8].cpu().numpy()
             worst = 0.0
             for qi in range(4):
                 rows = np.stack([gal.get_rows(int(r), 1)[0] for r in idx1_h[qi, :3]]).astype(np.float64)

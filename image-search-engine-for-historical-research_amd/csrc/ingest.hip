@@ -7,6 +7,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include <cstdio>
 #include <cstdlib>
@@ -241,8 +242,9 @@ constexpr int QI_MAX_PER_THREAD = 16;
 // 7 - i inside the half = i ^ 8).  The same partner as __shfl_xor, so the same sums.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+  // (bound_ctrl set: every lane of these permutations has a source, and the compiler then needs no initialised destination)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int O>
@@ -275,6 +277,44 @@ __device__ __forceinline__ double xor_lane_f64(double x) {
     return __hiloint2double((int)phi, (int)plo);
   }
 }
+// Twelve wave butterflies (partners 32, 16, 8, 4, 2, 1) for the price of two.  After the level with partner P the lanes l and
+// l ^ P hold the same sum, so bit log2(P) of the lane number is free to tell two VALUES apart: v_permlane32_swap / v_permlane16_swap
+// move half of one register into the other half of a second one in a single instruction -- (a, b) -> one register with a's sums in
+// one half and b's in the other, one float64 add for both --, and the 8- and 4-lane levels pack by a select.  The adds are the
+// butterfly's adds (x[l] + x[l ^ P], the same operands in every lane that keeps the value), so the sums are the same bits.
+__device__ __forceinline__ double swap32_add(double a, double b) {   // lanes < 32: a[l] + a[l + 32]; lanes >= 32: b[l - 32] + b[l]
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap16_add(double p, double q) {   // 16-lane rows: [p0 + p1, q0 + q1, p2 + p3, q2 + q3]
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(p), (unsigned)__double2loint(q), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p), (unsigned)__double2hiint(q), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int O>
+__device__ __forceinline__ double pack_add(double x, double y, bool upper) {   // lanes with bit O clear: x[l] + x[l ^ O]; set: y[l] + y[l ^ O]
+  const double u = upper ? y : x, v = upper ? x : y;
+  return u + xor_lane_f64<O>(v);
+}
+// g[k], b[k], d[k] (k = 0..3: the four virtual waves): lane 0 receives ((G0 + G1) + G2) + G3 of the butterflied g's, lane 8 the
+// same of the b's, lane 4 of the d's (other lanes: don't care).  Where a value lives: after the 32- and 16-lane levels row
+// (lane >> 4) = 0, 1, 2, 3 holds k = 0, 2, 1, 3; bit 3 tells g from b, bit 2 those two from d.
+__device__ __forceinline__ double reduce_stats12(const double g[4], const double b[4], const double d[4], int lane) {
+  const double rg = swap16_add(swap32_add(g[0], g[1]), swap32_add(g[2], g[3]));
+  const double rb = swap16_add(swap32_add(b[0], b[1]), swap32_add(b[2], b[3]));
+  const double rd = swap16_add(swap32_add(d[0], d[1]), swap32_add(d[2], d[3]));
+  const double z1 = pack_add<8>(rg, rb, (lane & 8) != 0);
+  const double z2 = rd + xor_lane_f64<8>(rd);
+  double w = pack_add<4>(z1, z2, (lane & 4) != 0);
+  w += xor_lane_f64<2>(w);
+  w += xor_lane_f64<1>(w);
+  // rows 0, 2, 1, 3 <-> lanes l, l ^ 32, l ^ 16, l ^ 48 of a lane in row 0
+  const double k1 = xor_lane_f64<32>(w), k2 = xor_lane_f64<16>(w);
+  const double k3 = xor_lane_f64<32>(k2);
+  return ((w + k1) + k2) + k3;
+}
+
 // the butterfly of the block reductions below: partners 32, 16, 8, 4, 2, 1 in this order
 __device__ __forceinline__ void wave_butterfly(double& a) {
   a += xor_lane_f64<32>(a); a += xor_lane_f64<16>(a); a += xor_lane_f64<8>(a);
@@ -450,6 +490,204 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
   }   // rows of this workgroup
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gallery ingest, rows contiguous in memory (round 5): ONE WAVE PER ROW.
+//
+// The kernel above gives a row to a 256-thread workgroup: 8 elements per thread, and around them ~850 instructions per thread
+// and row -- five barriers, three block reductions, address arithmetic, the float64 square root and division repeated by
+// every thread -- i.e. ~3400 wave-instructions per row, which is what its 5 ms for 1 M rows were made of: it was ISSUE-bound
+// (982 rows per SIMD x 3400 x ~3.5 cycles = 4.9 ms), not memory-bound.  Here a wave owns a row, a lane 32 of its elements: the
+// per-row overhead is paid once per 64 lanes instead of once per 256 threads, there is no barrier (the four waves of a
+// workgroup are independent; they take the four consecutive rows of a run, so the image still fills 256-byte stretches), and
+// loads and stores are 16 bytes per lane.
+//
+// THE SUMS ARE THE SAME SUMS, bit for bit (tests/golden/ingest_checksums.json pins the galleries of the old kernel).  The old
+// kernel's thread t (0..255) is a "virtual thread" here:
+//   norm     virtual thread t sums x[t + 256 j]^2, j = 0, 1, ... in this order (fma chain), then the 64 virtual lanes t & 63 of
+//            virtual wave t >> 6 run a butterfly with partners 32, 16, 8, 4, 2, 1, then ((w0 + w1) + w2) + w3.
+//            Lane l loads float4s at columns 4 l + 256 i: it holds virtual threads 4 l + e (e = 0..3) with all their j = i.  Virtual
+//            lane = 4 (l & 15) + e, virtual wave = l >> 4: partners 32, 16, 8, 4 are lanes l ^ 8, 4, 2, 1 -- data-parallel moves
+//            inside the 16-lane rows --, partners 2 and 1 are the lane's own e ^ 2, e ^ 1.
+//   stats    virtual thread t sums over the 8 columns 8 t .. 8 t + 7 (then 2048 + 8 t ... for rows wider than 2048), same
+//            butterfly.  After the regrouping through the wave's own LDS row lane l takes chunks t = l + 64 k (k = 0..3):
+//            virtual lane = l, virtual wave = k -- the plain wave butterfly on 3 x 4 accumulators.
+// f32 rows are stored straight from the load layout (16 bytes per lane, 1 KiB per instruction).
+// FULL: d == 256 * PT and rows 16-byte aligned -- every column of every float4 is inside the row: no per-element selects.
+template <typename InT, int PT, bool PREFETCH, bool FULL>
+__global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs, int norm_mode,
+                                                          float* __restrict__ out_f32, uint16_t* __restrict__ out_img,
+                                                          int img_f16, RowStat* __restrict__ rowstat, int32_t dp,
+                                                          int64_t nrows, int64_t row_base, int vec_ok, int coop) {
+  __shared__ __attribute__((aligned(16))) float wbuf[4][PT * 256];
+  // coop (row_base and nrows multiples of 4): the 16-bit image of a run leaves through the workgroup -- [slice][row of the run][64 B]
+  // is, slice by slice, the 256 contiguous bytes the run owns in that slice's block of the tile, so after one barrier every wave
+  // copies 16 slices out with 256 contiguous bytes per 16 lanes.  Written by each wave for its own row, a row's piece of a
+  // slice block is 64 bytes -- HALF a line, whose other half another wave writes whenever it gets there: 4.1 GB of image cost as
+  // much time as the 8.2 GB of f32 rows (profiles/r05d_ingest_probes.txt).  Two buffers, by run parity: one barrier per run.
+  __shared__ __attribute__((aligned(16))) uint4 wimg[2][PT * 8][4][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* buf = wbuf[wv];
+  struct Raw { InT v[4]; };
+  Raw cur[PT], nxt[PT];
+  // loads are unconditional (row and column clamped into the source; the zero is selected where the value is USED): a load
+  // behind a branch makes the number of outstanding loads path-dependent and the compiler then waits right behind the request
+  auto request = [&](Raw* dst, int64_t r) {
+    const int64_t rr = r < n ? r : n - 1;
+    const InT* rowp = src + rr * rs + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (FULL || vec_ok) {                      // d % 4 == 0 and 16-byte aligned rows: a group of 4 is all inside or all outside
+        const InT* p = (FULL || c < d) ? rowp + 256 * i : rowp - 4 * lane;
+        if constexpr (sizeof(InT) == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(p);
+          dst[i].v[0] = t.x; dst[i].v[1] = t.y; dst[i].v[2] = t.z; dst[i].v[3] = t.w;
+        } else {
+          const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+          dst[i].v[0] = a.x; dst[i].v[1] = a.y; dst[i].v[2] = b.x; dst[i].v[3] = b.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[i].v[e] = rowp[(c + e < d ? c + e : d - 1) - 4 * lane];
+      }
+    }
+  };
+  const int nslices = dp / SLICE_K;
+  const int64_t nruns = (nrows + 3) / 4;
+  int64_t run = blockIdx.x;
+  if (run >= nruns) return;
+  request(cur, run * 4 + wv);
+  for (int par = 0; run < nruns; run += gridDim.x, par ^= 1) {
+    const int64_t row = run * 4 + wv;
+    const int64_t next_row = (run + gridDim.x) * 4 + wv;
+    if (PREFETCH) request(nxt, next_row < nrows ? next_row : row);      // past the end: a harmless re-load
+    const int64_t orow = row_base + row;
+    const int64_t tileidx = orow / TILE;
+    const uint32_t r = (uint32_t)(orow % TILE);
+    uint16_t* tile_base = out_img + tileidx * nslices * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+    if (row < nrows && row >= n) {
+      // padding row of the last tile: a zero image row and zero norms, no f32 row (what the sums below give for a row of zeros)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int h = 0; h < PT / 8; ++h) {
+          const int c0 = 8 * (lane + 64 * k) + 2048 * h;
+          if (c0 < dp) {
+            const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
+            if (coop) wimg[par][sl][wv][swz_chunk(r, ch)] = make_uint4(0, 0, 0, 0);
+            else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = make_uint4(0, 0, 0, 0);
+          }
+        }
+      if (lane < 3) reinterpret_cast<float*>(rowstat + orow)[lane] = 0.0f;
+    } else if (row < nrows) {                                           // (wave-uniform)
+      // ---- norm
+      double scale = 1.0;
+      if (norm_mode != 0) {
+        double ss[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const double v = (FULL || 4 * lane + 256 * i + e < d) ? (double)cur[i].v[e] : 0.0;
+            ss[e] = __builtin_fma(v, v, ss[e]);
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ss[e] += xor_lane_f64<8>(ss[e]);
+          ss[e] += xor_lane_f64<4>(ss[e]);
+          ss[e] += xor_lane_f64<2>(ss[e]);
+          ss[e] += xor_lane_f64<1>(ss[e]);
+        }
+        const double vw = (ss[0] + ss[2]) + (ss[1] + ss[3]);            // partners 2 and 1 of the virtual lane
+        auto lane_value = [&](int src_lane) {
+          return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vw), src_lane),
+                                  __builtin_amdgcn_readlane(__double2loint(vw), src_lane));
+        };
+        const double tot = ((lane_value(0) + lane_value(16)) + lane_value(32)) + lane_value(48);
+        const double nrm = sqrt(tot);
+        scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);      // norm 0 -> inf -> NaN row, like the reference
+      }
+      // ---- normalised f32 row: to memory from the load layout, and into the wave's LDS row for the regrouping
+      float* orow_p = out_f32 + orow * dp + 4 * lane;
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        const int c = 4 * lane + 256 * i;
+        float4 y;
+        y.x = (FULL || c + 0 < d) ? (float)((double)cur[i].v[0] * scale) : 0.0f;
+        y.y = (FULL || c + 1 < d) ? (float)((double)cur[i].v[1] * scale) : 0.0f;
+        y.z = (FULL || c + 2 < d) ? (float)((double)cur[i].v[2] * scale) : 0.0f;
+        y.w = (FULL || c + 3 < d) ? (float)((double)cur[i].v[3] * scale) : 0.0f;
+        *reinterpret_cast<float4*>(buf + c) = y;
+        if ((FULL || c < dp) && !(MI_INGEST_PROBE & 2)) *reinterpret_cast<float4*>(orow_p + 256 * i) = y;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- 16-bit image + rounding statistics: lane l takes the 8-column chunks l + 64 k
+      double s_g[4] = {0.0, 0.0, 0.0, 0.0}, s_b[4] = {0.0, 0.0, 0.0, 0.0}, s_d[4] = {0.0, 0.0, 0.0, 0.0};
+      auto image_pass = [&](auto f16_tag) {
+        constexpr bool F16 = decltype(f16_tag)::value;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int h = 0; h < PT / 8; ++h) {
+            const int c0 = 8 * (lane + 64 * k) + 2048 * h;
+            if (FULL || c0 < dp) {
+              const float4 lo = *reinterpret_cast<const float4*>(buf + c0), hi = *reinterpret_cast<const float4*>(buf + c0 + 4);
+              const float vf[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+              union { uint16_t hh[8]; uint4 u; } pk;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                double vb;
+                pk.hh[e] = cvt_img(vf[e], F16 ? 1 : 0, vb);
+#if !(MI_INGEST_PROBE & 1)
+                s_b[k] = __builtin_fma(vb, vb, s_b[k]);
+                const double df = vb - (double)vf[e];
+                s_d[k] = __builtin_fma(df, df, s_d[k]);
+                s_g[k] = __builtin_fma((double)vf[e], (double)vf[e], s_g[k]);
+#endif
+              }
+              const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
+#if !(MI_INGEST_PROBE & 4)
+              if (coop) wimg[par][sl][wv][swz_chunk(r, ch)] = pk.u;
+              else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = pk.u;
+#else
+              if (pk.u.x == 0x12345678u) *reinterpret_cast<uint4*>(tile_base) = pk.u;
+#endif
+            }
+          }
+      };
+      if (img_f16) image_pass(std::true_type{});
+      else image_pass(std::false_type{});
+      // the butterflies of the four virtual waves, then ((w0 + w1) + w2) + w3: lanes 0 / 8 / 4 end up with the g / b / d totals;
+      // one square root for the three norms, every one of those lanes stores its float
+      const double mine = reduce_stats12(s_g, s_b, s_d, lane);
+      const float nf = (float)(sqrt(mine) * (1.0 + 1e-6));      // rounded UP a little: upper bounds after the f32 conversion
+      if (lane == 0 || lane == 8 || lane == 4) reinterpret_cast<float*>(rowstat + orow)[lane == 0 ? 0 : (lane == 8 ? 1 : 2)] = nf;
+      __builtin_amdgcn_wave_barrier();                            // the LDS row is rewritten by the next row of this wave
+    }
+    if (coop && !(MI_INGEST_PROBE & 4)) {
+      // (nrows % 4 == 0: the four waves of the workgroup are all inside or all outside the rows, the barrier is uniform)
+      __syncthreads();
+      const int64_t orow0 = row_base + run * 4;                 // first row of the run: a multiple of 4, so the run shares one
+      const uint32_t r0 = (uint32_t)(orow0 % TILE);             // tile and one swizzle (swz_chunk depends on row >> 2)
+      uint16_t* run_base = out_img + (orow0 / TILE) * nslices * (int64_t)SLICE_ELEMS + (int64_t)r0 * SLICE_K;
+#pragma unroll
+      for (int j = 0; j < PT / 2; ++j) {
+        const int sl = (PT * 2) * wv + 4 * j + (lane >> 4);      // wave w: slices [PT * 2 * w, PT * 2 * (w + 1))
+        if (sl < nslices)
+          *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) = (&wimg[par][sl][0][0])[lane & 15];
+      }
+    }
+    if (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < PT; ++i) cur[i] = nxt[i];
+    } else if (run + gridDim.x < nruns) {
+      request(cur, next_row < nrows ? next_row : row);
+    }
+  }
+}
+
 bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                            float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int32_t qpad,
                            const float* gstat3, float gamma, int use_img_terms, uint32_t first_cnt, const QueryState& st,
@@ -496,6 +734,36 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                    float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad,
                    hipStream_t stream, int64_t row_base) {
+  if (cs == 1 && dp <= 256 * QI_MAX_PER_THREAD && npad < (int64_t)1 << 31 && !(MI_INGEST_PROBE & 512)) {
+    // rows contiguous in memory (row-major source: device-generated galleries, appended descriptor batches, re-imaging of the
+    // stored rows): one WAVE per row, one pass (round 5; the sums of the kernel below, bit for bit)
+    const size_t esz = dtype == 0 ? 4 : 8;
+    const int vec_ok = (d % 4 == 0) && ((rs * esz) % 16 == 0) && (((uintptr_t)src) % 16 == 0);
+    const int coop = (row_base % 4 == 0) && (npad % 4 == 0) && !(MI_INGEST_PROBE & 2048);
+#define MI_GR_LAUNCH(T, PT, PF, FULL)                                                                                    \
+  do {                                                                                                                  \
+    static int occ = 0;                                                                                                 \
+    if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ingest_rows_kernel<T, PT, PF, FULL>, 256, 0) !=     \
+                     hipSuccess || occ < 1))                                                                            \
+      occ = 2;                                                                                                          \
+    if (MI_INGEST_PROBE && getenv("MI_INGEST_WG_PER_CU")) occ = atoi(getenv("MI_INGEST_WG_PER_CU"));                    \
+    if (MI_INGEST_PROBE) fprintf(stderr, "ingest (wave per row): %d workgroups per CU\n", occ);                         \
+    const unsigned grid = (unsigned)std::min<int64_t>((npad + 3) / 4, (int64_t)current_device_cus() * occ);             \
+    hipLaunchKernelGGL((ingest_rows_kernel<T, PT, PF, FULL>), dim3(grid), dim3(256), 0, stream, (const T*)src, n, d,    \
+                       rs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base, vec_ok, coop); \
+  } while (0)
+    if (dtype == 0) {
+      if (d == 2048 && vec_ok) MI_GR_LAUNCH(float, 8, true, true);          // the descriptors of the reference: 2048-d
+      else if (dp <= 2048) MI_GR_LAUNCH(float, 8, false, false);
+      else MI_GR_LAUNCH(float, 16, false, false);
+    } else {
+      if (d == 2048 && vec_ok) MI_GR_LAUNCH(double, 8, false, true);
+      else if (dp <= 2048) MI_GR_LAUNCH(double, 8, false, false);
+      else MI_GR_LAUNCH(double, 16, false, false);
+    }
+#undef MI_GR_LAUNCH
+    return;
+  }
   if (cs == 1 && dp <= 256 * QI_MAX_PER_THREAD && npad < (int64_t)1 << 31) {
     // rows contiguous in memory (row-major source: device-generated galleries, appended descriptor batches, re-imaging of
     // the stored rows): one workgroup per row, ONE pass over the source with the row held in registers -- a gallery is
