@@ -824,6 +824,35 @@ int mi_gallery_destroy(mi_gallery* g) {
   return MI_OK;
 }
 
+// Rows [row_base, row_base + m) of the gallery from a device source of any strides (m_pad >= m: trailing rows of the last tile
+// to be written as zeros).  Layouts the ingest kernels take in one pass go straight in; anything else -- a [D, N] layout at a
+// width other than 2048, fully strided sources -- is copied, 65 536 rows at a time, into a row-major scratch block first: the
+// values are untouched, the sums are the row kernel's, so the gallery is the same bits whatever the layout.
+static int ingest_rows_any_layout(mi_gallery* g, const void* src, int dtype, int64_t m, int64_t m_pad, int64_t rs, int64_t cs,
+                                  int64_t row_base, hipStream_t s) {
+  if (ingest_takes_layout(g->d, rs, cs)) {
+    launch_ingest(src, dtype, m, g->d, rs, cs, g->norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat, g->dp, m_pad, s,
+                  row_base);
+    HIPC(hipGetLastError());
+    return MI_OK;
+  }
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  const int64_t chunk = 65536;
+  TmpAlloc tmp;
+  char* scratch = tmp.get<char>((size_t)std::min<int64_t>(chunk, m) * g->d * esz);
+  if (!scratch) return fail(MI_ERR_NOMEM, "ingest scratch block");
+  for (int64_t r0 = 0; r0 < m_pad; r0 += chunk) {
+    const int64_t rows = std::max<int64_t>(0, std::min<int64_t>(chunk, m - r0));
+    const int64_t rows_pad = std::min<int64_t>(chunk, m_pad - r0);
+    if (rows > 0) launch_transpose_rows((const char*)src + (size_t)r0 * rs * esz, dtype, rows, g->d, rs, cs, scratch, s);
+    launch_ingest(scratch, dtype, rows, g->d, g->d, 1, g->norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat, g->dp,
+                  rows_pad, s, row_base + r0);
+  }
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(s));           // the scratch block is freed on return
+  return MI_OK;
+}
+
 static int gallery_alloc(mi_gallery* g) {
   g->dp = (int32_t)round_up(g->d, BK);
   g->npad = round_up(g->n, TILE);
@@ -878,8 +907,7 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
   g->img_f16 = g_default_img_f16.load();
   hipError_t e = hipSuccess;
   for (int pass = 0; pass < 2; ++pass) {
-    launch_ingest(src, dtype, n, d, row_stride, col_stride, norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat,
-                  g->dp, g->npad, g->stream);
+    if ((rc = ingest_rows_any_layout(g, src, dtype, n, g->npad, row_stride, col_stride, 0, g->stream)) != MI_OK) return cleanup(rc);
     launch_rowstat_max(g->rowstat, n, g->gstat3, g->stream);
     e = hipStreamSynchronize(g->stream);
     if (e == hipSuccess) e = hipGetLastError();
@@ -975,8 +1003,7 @@ int mi_gallery_append(mi_gallery* g, const void* data, int64_t m, int dtype, int
       src = st;
     }
   }
-  launch_ingest(src, dtype, m, g->d, rs, cs, g->norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat, g->dp, m, s,
-                g->n);
+  if ((rc = ingest_rows_any_layout(g, src, dtype, m, m, rs, cs, g->n, s)) != MI_OK) return rc;
   launch_rowstat_max(g->rowstat + g->n, m, g->gstat3, s, /*reset=*/false);
   HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(s));          // the staging buffer is freed on return

@@ -37,114 +37,6 @@ __device__ __forceinline__ uint16_t cvt_img(float v, int f16, double& back) {
   return __builtin_bit_cast(uint16_t, b);
 }
 
-template <typename InT>
-__global__ __launch_bounds__(256) void ingest_kernel(const InT* __restrict__ src, int64_t n, int32_t d,
-                                                     int64_t rs, int64_t cs, int norm_mode,
-                                                     float* __restrict__ out_f32,
-                                                     uint16_t* __restrict__ out_img, int img_f16,
-                                                     RowStat* __restrict__ rowstat, int32_t dp,
-                                                     int64_t npad) {
-  __shared__ double tile[64][65];
-  const int t = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
-  const bool row_contig = (rs == 1 && cs != 1);
-  // compute-phase mapping: thread -> (row ci, 16 columns starting at cj)
-  const int ci = t >> 2, cj = (t & 3) * 16;
-  const int64_t crow = row0 + ci;
-
-  auto load_tile = [&](int col0) {
-    // load-phase mapping follows the contiguous axis of the input
-    if (row_contig) {
-      const int j = t >> 2, i0 = (t & 3) * 16;
-      const int64_t col = col0 + j;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = row0 + i0 + e;
-        double v = 0.0;
-        if (row < n && col < d) v = (double)src[row * rs + col * cs];
-        tile[i0 + e][j] = v;
-      }
-    } else {
-      const int i = t >> 2, j0 = (t & 3) * 16;
-      const int64_t row = row0 + i;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t col = col0 + j0 + e;
-        double v = 0.0;
-        if (row < n && col < d) v = (double)src[row * rs + col * cs];
-        tile[i][j0 + e] = v;
-      }
-    }
-  };
-
-  double scale = 1.0;
-  if (norm_mode != 0) {
-    double ss = 0.0;
-    for (int col0 = 0; col0 < dp; col0 += 64) {
-      load_tile(col0);
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const double v = tile[ci][cj + e];
-        ss += v * v;
-      }
-      __syncthreads();
-    }
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
-    const double nrm = sqrt(ss);
-    scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);   // norm 0 -> inf -> NaN row, like the reference
-  }
-
-  double s_g = 0.0, s_b = 0.0, s_d = 0.0;
-  for (int col0 = 0; col0 < dp; col0 += 64) {
-    load_tile(col0);
-    __syncthreads();
-    float vf[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) vf[e] = (float)(tile[ci][cj + e] * scale);
-    if (crow < npad) {
-      const int nslices = dp / SLICE_K;
-      const int64_t tileidx = crow / TILE;
-      const uint32_t r = (uint32_t)(crow % TILE);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const uint32_t kcol = (uint32_t)(col0 + cj + half * 8);
-        const uint32_t sl = kcol / SLICE_K, c = (kcol % SLICE_K) >> 3;
-        uint16_t* blk = out_img + (tileidx * nslices + sl) * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
-        union { uint16_t h[8]; uint4 u; } pk;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = (crow < n) ? vf[half * 8 + e] : 0.0f;
-          double vb;
-          pk.h[e] = cvt_img(v, img_f16, vb);
-          s_b += vb * vb;
-          s_d += (vb - (double)v) * (vb - (double)v);
-          s_g += (double)v * (double)v;
-        }
-        *reinterpret_cast<uint4*>(blk + (swz_chunk(r, c) << 3)) = pk.u;
-      }
-      if (crow < n) {
-        float4* o = reinterpret_cast<float4*>(out_f32 + crow * dp + col0 + cj);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = make_float4(vf[4 * e], vf[4 * e + 1], vf[4 * e + 2], vf[4 * e + 3]);
-      }
-    }
-    __syncthreads();
-  }
-  s_g += __shfl_xor(s_g, 1); s_g += __shfl_xor(s_g, 2);
-  s_b += __shfl_xor(s_b, 1); s_b += __shfl_xor(s_b, 2);
-  s_d += __shfl_xor(s_d, 1); s_d += __shfl_xor(s_d, 2);
-  if ((t & 3) == 0 && crow < npad) {
-    RowStat rsd;
-    // round the norms UP a little so that they stay upper bounds after the f32 conversion
-    rsd.norm_f32 = (float)(sqrt(s_g) * (1.0 + 1e-6));
-    rsd.norm_img = (float)(sqrt(s_b) * (1.0 + 1e-6));
-    rsd.norm_diff = (float)(sqrt(s_d) * (1.0 + 1e-6));
-    rowstat[crow] = rsd;
-  }
-}
-
 // Row-per-workgroup variant for small row counts (query batches): 256 threads stride over the columns of ONE
 // row, so a 1024-query batch runs on 1024 workgroups instead of 16.  Same arithmetic as ingest_kernel.
 template <typename InT>
@@ -688,6 +580,295 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gallery ingest of the reference's own layout (round 5): a [D, N] array whose ROWS OF THE GALLERY are the contiguous axis --
+// callers hand over `vecs.T` (src/test_rOP1m.py:136-139,155-157; src/offline.py:107-118; src/online.py:95-102,132): element
+// (row, col) at src[row + col * cs].  One pass, producer / consumer inside the workgroup (12 waves):
+//   * four LOADER waves fetch the next PANEL -- 64 bytes worth of consecutive rows (16 float32 / 8 float64) x all 2048 columns,
+//     16 bytes per lane, of whatever alignment the column stride gives -- into their REGISTERS (128 per lane: the whole 128 KiB
+//     panel is in flight while the current one is processed) and, once the consumers are done with the current panel,
+//     transpose it into LDS as row-major rows;
+//   * eight CONSUMER waves run the body of ingest_rows_kernel on the rows of the panel in LDS, one wave per row, two runs of
+//     four rows at a time: the 32 values per lane come from LDS instead of global memory -- the same virtual threads, the same
+//     sums, the same bits -- the scaled row overwrites the raw row in place (that IS the regrouping buffer), the 16-bit image
+//     leaves through the workgroup 256 bytes at a time.
+// Loads and stores never share a wave: a wave's vector-memory operations retire in order, and with both in one instruction stream
+// either the loads of the next panel waited behind this panel's stores or the compiler drained everything at the loop head (the
+// one-role versions of this kernel ran their load phase and their store phase one after the other: 5.9-7.8 ms against 1.6 +
+// 2.7 ms for the phases alone, profiles/r05e_ingest_cols_probes.txt).
+// A panel's 64-byte column segments are HALF lines: the workgroups of one XCD label (b, b + 8, ...: observed round-robin
+// dispatch, used for speed only) walk ONE contiguous range of panels side by side, so a line is fetched from memory once and
+// its other half is an L2 hit a moment later.  (32-byte segments with two panel buffers in LDS were tried: twice the line
+// requests per byte, 5.2 ms.)
+// LDS row-major with the column index XOR-ed by 8 * (row quad): the transposing 4-byte writes of a loader wave -- 4 row quads x
+// 8 columns per 32 lanes -- then hit 32 different banks, and the 16-byte reads of the consumers stay aligned permutations.
+template <typename InT>
+__global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict__ src, int64_t n, int64_t cs, int norm_mode,
+                                                          float* __restrict__ out_f32, uint16_t* __restrict__ out_img,
+                                                          int img_f16, RowStat* __restrict__ rowstat, int64_t nrows,
+                                                          int64_t row_base, int coop) {
+  constexpr int D = 2048, PT = 8, NSL = D / SLICE_K;
+  constexpr int R = 64 / (int)sizeof(InT);                       // rows of a panel: 16 (float32) / 8 (float64)
+  constexpr int RQ = R / 4;                                      // row quads = runs of a panel: 4 / 2
+  constexpr size_t PANEL_BYTES = (size_t)R * D * sizeof(InT);    // 128 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [R][D] panel | image staging of the two runs in flight [run][slice][row of the run][64 B] (32 KiB)
+  InT* panel = reinterpret_cast<InT*>(smem);
+  uint4 (*wimg)[NSL][4][4] = reinterpret_cast<uint4 (*)[NSL][4][4]>(smem + PANEL_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wv12 = tid >> 6;
+  const bool loader = wv12 >= 8;
+  const int64_t npanels = (nrows + R - 1) / R;
+  const int64_t nx = gridDim.x >> 3;                             // workgroups per XCD label (the grid is a multiple of 8)
+  const int64_t xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+  const int64_t per_x = (npanels + 7) / 8;
+  const int64_t p_begin = xcd * per_x + kx, p_end = min((xcd + 1) * per_x, npanels);
+  const int64_t p_step = nx;
+  // The panel that holds the last row -- and the panels of padding rows behind it -- load the LAST R rows of the source instead
+  // (n >= R): row k of such a panel sits `shift` slots further down; nothing is read past the end, there is no element-wise path.
+  auto panel_shift = [&](int64_t pp) -> int { return pp * R + R <= n ? 0 : (int)(pp * R - (n - R)); };
+  auto slot_swz = [&](int slot) -> int { return 8 * ((slot >> 2) & 3); };
+
+  // ---- loaders: lane -> (row quad, column of a group of 64 / RQ columns); four waves cover 4 * 64 / RQ columns per round
+  constexpr int CPW = 64 / RQ;                                   // columns per wave instruction: 16 / 32
+  constexpr int NLD = D / (4 * CPW);                             // quads of 4 rows per thread: 32 / 16 (128 registers)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  // (The loaders run a loop of their own -- same barriers, count for count: s_barrier counts arrivals, not program counters --
+  // so that their 128 panel registers are live in their instruction stream only.)
+  const int lw = wv12 - 8, lrq = lane % RQ, lcsub = lane / RQ;
+  auto request = [&](InT (*t)[4], int64_t pp) {
+    const int rq = lrq, csub = lcsub;
+    const int64_t first = pp * R + R <= n ? pp * R : n - R;
+    const InT* cp = src + (int64_t)(lw * CPW + csub) * cs + first + 4 * rq;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j, cp += (int64_t)4 * CPW * cs) {
+#if MI_INGEST_PROBE & 16384
+      for (int e = 0; e < 4; ++e) t[j][e] = (InT)(first + j + e);
+#else
+      if constexpr (sizeof(InT) == 4) {
+        const f4u x = *reinterpret_cast<const f4u*>(cp);
+        t[j][0] = x.x; t[j][1] = x.y; t[j][2] = x.z; t[j][3] = x.w;
+      } else {
+        const d2u a = *reinterpret_cast<const d2u*>(cp), c2 = *reinterpret_cast<const d2u*>(cp + 2);
+        t[j][0] = a.x; t[j][1] = a.y; t[j][2] = c2.x; t[j][3] = c2.y;
+      }
+#endif
+    }
+  };
+  auto to_lds = [&](InT (*t)[4]) {
+    const int rq = lrq, csub = lcsub;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int col = (j * 4 + lw) * CPW + csub;
+      const int pc = col ^ (8 * (rq & 3));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) panel[(4 * rq + e) * D + pc] = t[j][e];
+    }
+  };
+
+  // ---- consumers: two runs at a time; wave wv of the pair's run pr takes row 4 (j0 + pr) + wv of the panel
+  const int wv = wv12 & 3, pr = (wv12 >> 2) & 1;
+  auto process_row = [&](int64_t p, int j0) {
+    const int64_t prow0 = p * R;
+    const int64_t row = prow0 + 4 * (j0 + pr) + wv;
+    if (row >= nrows) return;
+    const int64_t orow = row_base + row;
+    const uint32_t r = (uint32_t)(orow % TILE);
+    uint16_t* tile_base = out_img + (orow / TILE) * NSL * (int64_t)SLICE_ELEMS + (int64_t)r * SLICE_K;
+    if (row >= n) {
+      // padding row of the last tile: a zero image row and zero norms, no f32 row
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c0 = 8 * (lane + 64 * k);
+        const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
+        if (coop) wimg[pr][sl][wv][swz_chunk(r, ch)] = make_uint4(0, 0, 0, 0);
+        else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = make_uint4(0, 0, 0, 0);
+      }
+      if (lane < 3) reinterpret_cast<float*>(rowstat + orow)[lane] = 0.0f;
+      return;
+    }
+    const int slot = 4 * (j0 + pr) + wv + panel_shift(p);        // < R for every row < n
+    const int swz = slot_swz(slot);
+    InT* prow = panel + (size_t)slot * D;
+    float* buf = reinterpret_cast<float*>(prow);                // the scaled row replaces the raw one (first D * 4 bytes of its slot)
+    InT cur[PT][4];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const InT* q = prow + ((4 * lane + 256 * i) ^ swz);
+      if constexpr (sizeof(InT) == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(q);
+        cur[i][0] = x.x; cur[i][1] = x.y; cur[i][2] = x.z; cur[i][3] = x.w;
+      } else {
+        const double2 a = *reinterpret_cast<const double2*>(q), c2 = *reinterpret_cast<const double2*>(q + 2);
+        cur[i][0] = a.x; cur[i][1] = a.y; cur[i][2] = c2.x; cur[i][3] = c2.y;
+      }
+    }
+    double scale = 1.0;
+    if (norm_mode != 0) {
+      double ss[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double v = (double)cur[i][e];
+          ss[e] = __builtin_fma(v, v, ss[e]);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ss[e] += xor_lane_f64<8>(ss[e]);
+        ss[e] += xor_lane_f64<4>(ss[e]);
+        ss[e] += xor_lane_f64<2>(ss[e]);
+        ss[e] += xor_lane_f64<1>(ss[e]);
+      }
+      const double vw = (ss[0] + ss[2]) + (ss[1] + ss[3]);
+      auto lane_value = [&](int src_lane) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vw), src_lane),
+                                __builtin_amdgcn_readlane(__double2loint(vw), src_lane));
+      };
+      const double tot = ((lane_value(0) + lane_value(16)) + lane_value(32)) + lane_value(48);
+      const double nrm = sqrt(tot);
+      scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);
+    }
+    if constexpr (sizeof(InT) == 8) {                             // the float32 row is shorter than the float64 one it overwrites:
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // every lane has read its raw values before any lane writes
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    float* orow_p = out_f32 + orow * D + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      float4 y;
+      y.x = (float)((double)cur[i][0] * scale);
+      y.y = (float)((double)cur[i][1] * scale);
+      y.z = (float)((double)cur[i][2] * scale);
+      y.w = (float)((double)cur[i][3] * scale);
+      *reinterpret_cast<float4*>(buf + ((4 * lane + 256 * i) ^ swz)) = y;
+      if (!(MI_INGEST_PROBE & 2)) *reinterpret_cast<float4*>(orow_p + 256 * i) = y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double s_g[4] = {0.0, 0.0, 0.0, 0.0}, s_b[4] = {0.0, 0.0, 0.0, 0.0}, s_d[4] = {0.0, 0.0, 0.0, 0.0};
+    auto image_pass = [&](auto f16_tag) {
+      constexpr bool F16 = decltype(f16_tag)::value;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c0 = 8 * (lane + 64 * k);
+        const float* bp = buf + (c0 ^ swz);
+        const float4 lo = *reinterpret_cast<const float4*>(bp), hi = *reinterpret_cast<const float4*>(bp + 4);
+        const float vf[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        union { uint16_t hh[8]; uint4 u; } pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          double vb;
+          pk.hh[e] = cvt_img(vf[e], F16 ? 1 : 0, vb);
+          s_b[k] = __builtin_fma(vb, vb, s_b[k]);
+          const double df = vb - (double)vf[e];
+          s_d[k] = __builtin_fma(df, df, s_d[k]);
+          s_g[k] = __builtin_fma((double)vf[e], (double)vf[e], s_g[k]);
+        }
+        const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
+        if (coop) wimg[pr][sl][wv][swz_chunk(r, ch)] = pk.u;
+        else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = pk.u;
+      }
+    };
+    if (img_f16) image_pass(std::true_type{});
+    else image_pass(std::false_type{});
+    const double mine = reduce_stats12(s_g, s_b, s_d, lane);
+    const float nf = (float)(sqrt(mine) * (1.0 + 1e-6));
+    if (lane == 0 || lane == 8 || lane == 4) reinterpret_cast<float*>(rowstat + orow)[lane == 0 ? 0 : (lane == 8 ? 1 : 2)] = nf;
+  };
+  auto copy_out = [&](int64_t p, int j0) {                       // the image of run j0 + pr: 256 contiguous bytes per slice and 16 lanes
+    const int64_t run_row = p * R + 4 * (j0 + pr);
+    if (!coop || run_row >= nrows || (MI_INGEST_PROBE & 4)) return;
+    const int64_t orow0 = row_base + run_row;                    // a multiple of 4 (coop): one tile, one swizzle for the run
+    const uint32_t r0 = (uint32_t)(orow0 % TILE);
+    uint16_t* run_base = out_img + (orow0 / TILE) * NSL * (int64_t)SLICE_ELEMS + (int64_t)r0 * SLICE_K;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int sl = 16 * wv + 4 * jj + (lane >> 4);
+      *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) = (&wimg[pr][sl][0][0])[lane & 15];
+    }
+  };
+
+  if (loader) {
+    InT t[NLD][4];
+    if (p_begin < p_end) {
+      request(t, p_begin);
+      to_lds(t);
+    }
+    for (int64_t p = p_begin; p < p_end; p += p_step) {
+      __syncthreads();                                           // A: panel p is in LDS
+      const bool more = p + p_step < p_end;
+      if (more) request(t, p + p_step);                          // in flight, in registers, while panel p is processed
+#pragma unroll
+      for (int j0 = 0; j0 < RQ; j0 += 2) {
+        __syncthreads();                                         // B
+        __syncthreads();                                         // C (the last one: the consumers are done with the panel)
+      }
+      if (more) to_lds(t);
+    }
+    return;
+  }
+  for (int64_t p = p_begin; p < p_end; p += p_step) {
+    __syncthreads();                                             // A
+#pragma unroll
+    for (int j0 = 0; j0 < RQ; j0 += 2) {
+      if (!(MI_INGEST_PROBE & 8192)) process_row(p, j0);
+      __syncthreads();                                           // B: the image of these two runs is staged
+      copy_out(p, j0);
+      __syncthreads();                                           // C: the staging may be rewritten / the panel replaced
+    }
+  }
+}
+
+// Any strides -> row-major rows [m][d] of the same element type, values untouched (generic shapes of the [D, N] layout and
+// fully strided sources go through this copy into a scratch block and then through ingest_rows_kernel: same bits, any shape).
+template <typename InT>
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const InT* __restrict__ src, int64_t m, int32_t d, int64_t rs, int64_t cs,
+                                                             InT* __restrict__ dst) {
+  __shared__ InT tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int col0 = blockIdx.y * 32;
+  // read with the lanes along the axis that is contiguous in the source
+  const bool rows_contig = rs <= cs;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int a = ty + 8 * k;
+    const int64_t row = rows_contig ? row0 + tx : row0 + a;
+    const int col = rows_contig ? col0 + a : col0 + tx;
+    InT v = 0;
+    if (row < m && col < d) v = src[row * rs + (int64_t)col * cs];
+    if (rows_contig) tile[tx][a] = v; else tile[a][tx] = v;      // tile[row in tile][col in tile]
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int a = ty + 8 * k;
+    const int64_t row = row0 + a;
+    const int col = col0 + tx;
+    if (row < m && col < d) dst[row * d + col] = tile[a][tx];
+  }
+}
+
+void launch_transpose_rows(const void* src, int dtype, int64_t m, int32_t d, int64_t rs, int64_t cs, void* dst, hipStream_t stream) {
+  const dim3 grid((unsigned)((m + 31) / 32), (unsigned)((d + 31) / 32));
+  if (dtype == 0)
+    hipLaunchKernelGGL(transpose_rows_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, m, d, rs, cs, (float*)dst);
+  else
+    hipLaunchKernelGGL(transpose_rows_kernel<double>, grid, dim3(256), 0, stream, (const double*)src, m, d, rs, cs, (double*)dst);
+}
+
+// does launch_ingest take this source as it is (one pass, canonical sums)?  Otherwise the caller copies the rows into a
+// row-major scratch block first (launch_transpose_rows) and ingests that.
+bool ingest_takes_layout(int32_t d, int64_t rs, int64_t cs) {
+  const int32_t dp = (int32_t)round_up(d, BK);
+  if (cs == 1) return true;                                      // rows contiguous: ingest_rows_kernel (dp <= 4096) / row-wise kernel
+  if (rs == 1 && d == 2048) return true;                         // the reference's layout at the reference's width: ingest_cols_kernel
+  return dp > 256 * QI_MAX_PER_THREAD;                           // very wide rows: the row-wise kernel takes any strides
+}
+
 bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                            float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int32_t qpad,
                            const float* gstat3, float gamma, int use_img_terms, uint32_t first_cnt, const QueryState& st,
@@ -764,6 +945,22 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
 #undef MI_GR_LAUNCH
     return;
   }
+  if (rs == 1 && cs != 1 && d == 2048 && dp == 2048 && n >= 16 && !(MI_INGEST_PROBE & 4096)) {
+    // the reference's [D, N] layout: one pass, rows rebuilt in LDS by loader waves, consumed by the row body (ingest_cols_kernel)
+    const int coop = (row_base % 4 == 0) && (npad % 4 == 0);
+    const unsigned grid = (unsigned)std::max<int64_t>(8, current_device_cus() / 8 * 8);      // one workgroup per CU, whole XCD labels
+    const size_t lds = (size_t)128 * 1024 + 32 * 1024;
+#define MI_GC_LAUNCH(T)                                                                                                  \
+  do {                                                                                                                  \
+    ensure_dynamic_lds((const void*)ingest_cols_kernel<T>, (int)lds);                                                   \
+    hipLaunchKernelGGL((ingest_cols_kernel<T>), dim3(grid), dim3(768), lds, stream, (const T*)src, n, cs, norm_mode,    \
+                       out_f32, (uint16_t*)out_img, img_f16, rowstat, npad, row_base, coop);                            \
+  } while (0)
+    if (dtype == 0) MI_GC_LAUNCH(float);
+    else MI_GC_LAUNCH(double);
+#undef MI_GC_LAUNCH
+    return;
+  }
   if (cs == 1 && dp <= 256 * QI_MAX_PER_THREAD && npad < (int64_t)1 << 31) {
     // rows contiguous in memory (row-major source: device-generated galleries, appended descriptor batches, re-imaging of
     // the stored rows): one workgroup per row, ONE pass over the source with the row held in registers -- a gallery is
@@ -792,22 +989,16 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
 #undef MI_GI_LAUNCH
     return;
   }
-  if (npad <= 4096 || row_base != 0) {   // small batches (queries): one workgroup per row
-    if (dtype == 0)
-      hipLaunchKernelGGL(ingest_rowwise_kernel<float>, dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
-                         d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base);
-    else
-      hipLaunchKernelGGL(ingest_rowwise_kernel<double>, dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
-                         n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base);
-    return;
-  }
-  const int64_t blocks = (npad + 63) / 64;
+  // anything else -- strided query batches, rows wider than 4096 columns: one workgroup per row, any strides, two passes over the
+  // row (the same sums; galleries in a layout this would be slow for are copied into row-major scratch blocks by the caller,
+  // ingest_takes_layout / launch_transpose_rows).  (The round-1 kernel that read 64 x 64 tiles of a strided source twice and
+  // summed in an order of its own is gone: round 5.)
   if (dtype == 0)
-    hipLaunchKernelGGL(ingest_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, n, d,
-                       rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad);
+    hipLaunchKernelGGL(ingest_rowwise_kernel<float>, dim3((unsigned)npad), dim3(256), 0, stream, (const float*)src, n,
+                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base);
   else
-    hipLaunchKernelGGL(ingest_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)src, n,
-                       d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad);
+    hipLaunchKernelGGL(ingest_rowwise_kernel<double>, dim3((unsigned)npad), dim3(256), 0, stream, (const double*)src,
+                       n, d, rs, cs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base);
 }
 
 // Order-independent 64-bit checksum of a device buffer (8-byte words): sum over words of mix(word ^ index * golden ratio).

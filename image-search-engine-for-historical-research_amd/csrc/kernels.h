@@ -5,6 +5,9 @@
 namespace mi {
 
 // ingest.hip
+// strided source -> row-major [m][d] copy of the same element type (scratch for layouts launch_ingest does not take in one pass)
+void launch_transpose_rows(const void* src, int dtype, int64_t m, int32_t d, int64_t rs, int64_t cs, void* dst, hipStream_t stream);
+bool ingest_takes_layout(int32_t d, int64_t rs, int64_t cs);
 void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode,
                    float* out_f32, void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream,
                    int64_t row_base = 0);

@@ -11,6 +11,10 @@
 // against libmi355_retrieval.so: with it loaded, the kernel of the same mangled name registered by the library is the one
 // that runs, whatever this file was compiled with.
 namespace mi {
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return 0;
+}
 int current_device_cus() {
   hipDeviceProp_t p;
   int dev = 0;
@@ -40,28 +44,34 @@ __global__ void fill(float* p, size_t n) {
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 1005994;
   const int d = argc > 2 ? atoi(argv[2]) : 2048;
+  // layout of the source: "rows" = row-major [n][d] (default); "cols" = the reference's [d][n] (row stride 1, column stride n);
+  // "cols:<stride>" = [d][stride] with stride >= n (e.g. a multiple of 32: every 64-byte column segment of a panel aligned)
+  const char* layout = argc > 3 ? argv[3] : "rows";
+  const bool cols = layout[0] == 'c';
+  const int64_t cstride = (cols && layout[4] == ':') ? atoll(layout + 5) : n;
   const int64_t npad = (n + 255) / 256 * 256;
   float *src, *out;
   uint16_t* img;
   mi::RowStat* rs;
-  CK(hipMalloc(&src, (size_t)n * d * 4));
+  CK(hipMalloc(&src, (size_t)(cols ? cstride : n) * d * 4 + 256));
   CK(hipMalloc(&out, (size_t)n * d * 4 + 256));
   CK(hipMalloc(&img, (size_t)npad * d * 2 + 256));
   CK(hipMalloc(&rs, (size_t)npad * sizeof(mi::RowStat)));
-  hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, src, (size_t)n * d);
+  hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, src, (size_t)(cols ? cstride : n) * d);
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
-    mi::launch_ingest(src, 0, n, d, d, 1, 1, out, img, 1, rs, d, npad, 0, 0);
+    if (cols) mi::launch_ingest(src, 0, n, d, 1, cstride, 1, out, img, 1, rs, d, npad, 0, 0);
+    else mi::launch_ingest(src, 0, n, d, d, 1, 1, out, img, 1, rs, d, npad, 0, 0);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double gb = ((double)n * d * 4 * ((MI_INGEST_PROBE & 2) ? 1 : 2) + ((MI_INGEST_PROBE & 4) ? 0.0 : (double)npad * d * 2)) / 1e9;
-    if (rep) printf("probe %d rows %lld dim %d: %.3f ms, %.2f TB/s of %.1f GB moved\n", MI_INGEST_PROBE, (long long)n, d, ms, gb / ms, gb);
+    if (rep) printf("probe %d %s rows %lld dim %d: %.3f ms, %.2f TB/s of %.1f GB moved\n", MI_INGEST_PROBE, layout, (long long)n, d, ms, gb / ms, gb);
   }
   mi::RowStat h;
   CK(hipMemcpy(&h, rs + 5, sizeof(h), hipMemcpyDeviceToHost));
