@@ -107,6 +107,7 @@ SIGNATURES = {
     "mi_gallery_norm_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "mi_gallery_set_image_dtype": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_debug_read_cycles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi_debug_xcc_shares": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "mi_debug_sample_source_row": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "mi_set_global_option": (C.c_int, [C.c_char_p, C.c_double]),
     "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
@@ -451,6 +452,13 @@ class Gallery:
     # ---- instrumentation
     def set_option(self, name, value):
         check(load().mi_set_option(self._h, name.encode(), float(value)))
+
+    def xcc_shares(self):
+        """-> (float32 [8] shares of the XCD labels, launches that have updated them; -1 = no workspace yet)."""
+        w = np.empty(8, dtype=np.float32)
+        n = C.c_int32()
+        check(load().mi_debug_xcc_shares(self._h, w.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return w, n.value
 
     def norm_bounds(self, raise_to=None):
         """{max ||g||, max ||g_hat||, max ||g_hat - g||} of this shard; raise_to: three floats -> the bounds become

@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -20,6 +21,18 @@ using namespace mi;
 
 static thread_local std::string g_err;
 static std::atomic<int> g_default_img_f16{1};   // mi_set_global_option("image_dtype", 0 = bf16 | 1 = fp16); read at gallery creation
+// mi_set_global_option("host_ingest", ...): how mi_gallery_create moves a HOST array to the device.  1 (default) = row blocks of
+// ~32 MiB copied straight from the caller's (pageable) array by the runtime into two alternating device blocks, the copy of
+// block i + 1 under the ingest of block i, no staging the size of the gallery; 0 = one copy of the whole array into a same-size
+// staging allocation, then one ingest (rounds 1-4).  Measured at 1 005 994 x 2048 float32 (profiles/r05f_host_ingest_modes.json):
+// 53.1 and 53.6 GB/s = 0.96 of the box's pinned H2D rate -- the runtime's pageable path is as fast as a pinned copy here.  A
+// third mode, blocks through two pinned buffers filled by 2-8 host threads (what VERDICT r04 prescribed), reached 30-35 GB/s
+// and was removed again.
+static std::atomic<int> g_host_ingest{1};
+// XCD shares of the tile kernel as the last handle on a device left them (common.h XccBalance): a handle created later -- or
+// loaded from a file written without shares -- starts from these instead of from an even split
+static std::mutex g_bal_mu;
+static std::map<int, std::vector<float>> g_bal_cache;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -109,6 +122,9 @@ struct mi_gallery {
   void* samp_img = nullptr;
   int64_t samp_tiles = 0, samp_for_n = -1;
   int64_t hbm_bytes = 0;
+  // XCD shares read from the prepared-gallery file (MI355GAL trailer) / snapshotted for the next save
+  float file_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool file_w_valid = false;
   hipStream_t stream = nullptr;
   Workspace ws;
   // option "workspace_slot": the phase API of batch i + 1 may run in the other workspace while batch i waits for its
@@ -254,8 +270,16 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
   HIPC(hipMemset(ws.cand_cnt_set[1], 0, (size_t)QB * 4));
   {
+    // the XCD shares start from what is known: the file's, else this process's last ones on the device, else an even split
     XccBalance hb;
     init_xcc_balance_host(&hb);
+    if (g->file_w_valid) {
+      init_xcc_balance_from(&hb, g->file_w);
+    } else {
+      std::lock_guard<std::mutex> l(g_bal_mu);
+      auto it = g_bal_cache.find(g->device);
+      if (it != g_bal_cache.end()) init_xcc_balance_from(&hb, it->second.data());
+    }
     HIPC(hipMemcpy(ws.bal, &hb, sizeof hb, hipMemcpyHostToDevice));
   }
   if (g->ws_alt.flags) {                   // one set of flags / statistics / clocks / XCD shares per handle
@@ -265,6 +289,20 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
     ws.bal = g->ws_alt.bal;
   }
   return MI_OK;
+}
+
+// the shares as the launches so far left them -> process cache (and out_w8, if given); false = none measured yet
+static bool snapshot_balance(const mi_gallery* g, float* out_w8) {
+  const Workspace& sw = g->ws.bal ? g->ws : g->ws_alt;
+  if (!sw.bal) return false;
+  XccBalance hb;
+  if (hipMemcpy(&hb, sw.bal, sizeof hb, hipMemcpyDeviceToHost) != hipSuccess || hb.launches == 0) return false;
+  {
+    std::lock_guard<std::mutex> l(g_bal_mu);
+    g_bal_cache[g->device].assign(hb.w, hb.w + 8);
+  }
+  if (out_w8) memcpy(out_w8, hb.w, sizeof hb.w);
+  return true;
 }
 
 static QueryState make_state(const Workspace& ws) {
@@ -799,6 +837,7 @@ int mi_gallery_destroy(mi_gallery* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->tail_stream) (void)hipStreamSynchronize(g->tail_stream);
   (void)hipDeviceSynchronize();
+  (void)snapshot_balance(g, nullptr);
   for (int i = 0; i < 2; ++i) {
     if (g->ev_p1[i]) (void)hipEventDestroy(g->ev_p1[i]);
     if (g->ev_tail[i]) (void)hipEventDestroy(g->ev_tail[i]);
@@ -869,6 +908,64 @@ static int gallery_alloc(mi_gallery* g) {
   return MI_OK;
 }
 
+// Host array -> gallery, in row blocks.  The reference's layouts: rows contiguous (cs == 1: a block is m whole rows) or the [D, N]
+// layout (rs == 1: a block is d runs of m consecutive rows, packed [d][m] on the device and read with strides (1, m)).  Block i + 1
+// crosses PCIe while block i is ingested; nothing the size of the gallery is allocated besides the gallery.
+static int gallery_ingest_host_blocks(mi_gallery* g, const void* data, int dtype, int64_t n, int64_t rs, int64_t cs) {
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  const int32_t d = g->d;
+  const bool by_cols = rs == 1 && cs != 1;                     // [D, N] layout
+  const int64_t m_blk = std::max<int64_t>(TILE, ((int64_t)32 << 20) / ((int64_t)d * (int64_t)esz) / TILE * TILE);   // ~32 MiB, whole tiles
+  const size_t blk_bytes = (size_t)m_blk * d * esz;
+  TmpAlloc tmp;
+  char* dev[2] = {tmp.get<char>(blk_bytes), tmp.get<char>(blk_bytes)};
+  if (!dev[0] || !dev[1]) return fail(MI_ERR_NOMEM, "host ingest device blocks");
+  hipStream_t cs_stream = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr}, ingested[2] = {nullptr, nullptr};
+  auto release = [&](int code) {
+    if (cs_stream) { (void)hipStreamSynchronize(cs_stream); (void)hipStreamDestroy(cs_stream); }
+    (void)hipStreamSynchronize(g->stream);
+    for (int i = 0; i < 2; ++i) {
+      if (copied[i]) (void)hipEventDestroy(copied[i]);
+      if (ingested[i]) (void)hipEventDestroy(ingested[i]);
+    }
+    return code;
+  };
+#define HIPR(expr)                                                                                           \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess) return release(fail(MI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  HIPR(hipStreamCreateWithFlags(&cs_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    HIPR(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    HIPR(hipEventCreateWithFlags(&ingested[i], hipEventDisableTiming));
+  }
+  const char* base = (const char*)data;
+  int64_t nblk = 0;
+  for (int64_t r0 = 0; r0 < n; r0 += m_blk, ++nblk) {
+    const int slot = (int)(nblk & 1);
+    const int64_t m = std::min<int64_t>(m_blk, n - r0);
+    const bool last = r0 + m >= n;
+    if (nblk >= 2) HIPR(hipStreamWaitEvent(cs_stream, ingested[slot], 0));     // the device block is free again
+    // the runtime copies from the caller's pageable pages (it stages / pins them itself); these calls return when the bytes
+    // have left the host, so block i + 1 is still copied while block i is ingested on the handle's stream
+    if (by_cols) HIPR(hipMemcpy2DAsync(dev[slot], (size_t)m * esz, base + (size_t)r0 * esz, (size_t)cs * esz, (size_t)m * esz,
+                                       (size_t)d, hipMemcpyHostToDevice, cs_stream));
+    else HIPR(hipMemcpy2DAsync(dev[slot], (size_t)d * esz, base + (size_t)r0 * rs * esz, (size_t)rs * esz, (size_t)d * esz,
+                               (size_t)m, hipMemcpyHostToDevice, cs_stream));
+    HIPR(hipEventRecord(copied[slot], cs_stream));
+    HIPR(hipStreamWaitEvent(g->stream, copied[slot], 0));
+    const int64_t m_pad = last ? g->npad - r0 : m;
+    const int rc = by_cols ? ingest_rows_any_layout(g, dev[slot], dtype, m, m_pad, 1, m, r0, g->stream)
+                           : ingest_rows_any_layout(g, dev[slot], dtype, m, m_pad, d, 1, r0, g->stream);
+    if (rc != MI_OK) return release(rc);
+    HIPR(hipEventRecord(ingested[slot], g->stream));
+  }
+#undef HIPR
+  return release(MI_OK);
+}
+
 int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
                       int memspace, int norm_mode, int device, int64_t row_offset, mi_gallery** out) {
   REQUIRE(data && out, "null pointer");
@@ -897,7 +994,11 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
     mi_gallery_destroy(g);
     return code;
   };
-  if (memspace == MI_HOST) {
+  // host arrays in one of the reference's two layouts: block pipeline (no staging the size of the gallery)
+  const int host_mode = g_host_ingest.load();
+  const bool host_blocks = memspace == MI_HOST && host_mode != 0 && (col_stride == 1 || row_stride == 1) && d > 1 &&
+                           (col_stride == 1 ? row_stride >= d : col_stride >= n);
+  if (memspace == MI_HOST && !host_blocks) {
     hipError_t e = hipMalloc(&staged, (size_t)elems * esz + 256);
     if (e != hipSuccess) return cleanup(fail(MI_ERR_NOMEM, std::string("staging hipMalloc: ") + hipGetErrorString(e)));
     e = hipMemcpy(staged, data, (size_t)elems * esz, hipMemcpyHostToDevice);
@@ -907,7 +1008,9 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
   g->img_f16 = g_default_img_f16.load();
   hipError_t e = hipSuccess;
   for (int pass = 0; pass < 2; ++pass) {
-    if ((rc = ingest_rows_any_layout(g, src, dtype, n, g->npad, row_stride, col_stride, 0, g->stream)) != MI_OK) return cleanup(rc);
+    rc = host_blocks ? gallery_ingest_host_blocks(g, data, dtype, n, row_stride, col_stride)
+                     : ingest_rows_any_layout(g, src, dtype, n, g->npad, row_stride, col_stride, 0, g->stream);
+    if (rc != MI_OK) return cleanup(rc);
     launch_rowstat_max(g->rowstat, n, g->gstat3, g->stream);
     e = hipStreamSynchronize(g->stream);
     if (e == hipSuccess) e = hipGetLastError();
@@ -1081,6 +1184,11 @@ uint64_t host_sum(const void* p, size_t bytes) {       // FNV-1a, header only
   for (size_t i = 0; i < bytes; ++i) h = (h ^ ((const unsigned char*)p)[i]) * 0x100000001b3ull;
   return h;
 }
+struct BalanceTrailer {        // optional, after the last section
+  char magic[8];               // "MIXCCBAL"
+  float w[8];
+  uint64_t sum;                // FNV-1a of the bytes above
+};
 struct PinnedPair {
   static constexpr size_t CHUNK = (size_t)32 << 20;
   void* buf[2] = {nullptr, nullptr};
@@ -1174,6 +1282,16 @@ int mi_gallery_save(const mi_gallery* g, const char* path) {
   if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->gal_f32, (size_t)g->n * g->dp * 4);
   if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->gal_img, (size_t)g->npad * g->dp * 2);
   if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
+  if (rc == MI_OK) {
+    // optional trailer: the XCD shares of the tile kernel as measured so far (or as loaded), so that `load -> first search`
+    // starts calibrated; files without it (no large launch has run yet) are complete
+    BalanceTrailer tr{};
+    memcpy(tr.magic, "MIXCCBAL", 8);
+    bool have = snapshot_balance(g, tr.w);
+    if (!have && g->file_w_valid) { memcpy(tr.w, g->file_w, sizeof tr.w); have = true; }
+    tr.sum = host_sum(&tr, offsetof(BalanceTrailer, sum));
+    if (have && fwrite(&tr, sizeof tr, 1, f) != 1) rc = fail(MI_ERR_IO, "short write");
+  }
   if (fclose(f) != 0 && rc == MI_OK) rc = fail(MI_ERR_IO, "close failed");
   return rc;
 }
@@ -1209,7 +1327,17 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->gal_f32, (size_t)g->n * g->dp * 4);
   if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->gal_img, (size_t)g->npad * g->dp * 2);
   if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
-  if (rc == MI_OK && fgetc(f) != EOF) rc = fail(MI_ERR_IO, "trailing bytes after the last section");
+  if (rc == MI_OK) {
+    BalanceTrailer tr{};
+    const size_t got = fread(&tr, 1, sizeof tr, f);
+    if (got == sizeof tr && memcmp(tr.magic, "MIXCCBAL", 8) == 0 && tr.sum == host_sum(&tr, offsetof(BalanceTrailer, sum)) &&
+        fgetc(f) == EOF) {
+      memcpy(g->file_w, tr.w, sizeof tr.w);
+      g->file_w_valid = true;
+    } else if (got != 0) {
+      rc = fail(MI_ERR_IO, "trailing bytes after the last section");
+    }
+  }
   fclose(f);
   if (rc == MI_OK && hipMemcpy(g->gstat3, h.gstat3, 12, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(MI_ERR_HIP, "gstat3 copy failed");
@@ -2304,6 +2432,24 @@ int64_t mi_debug_sample_source_row(int64_t i, int64_t n, int64_t n_s) {
   return sample_source_row_host(i, n, n_s);
 }
 
+int mi_debug_xcc_shares(mi_gallery* g, float* out_w8, int32_t* out_launches) {
+  REQUIRE(g && out_w8, "null");
+  HIPC(hipSetDevice(g->device));
+  HIPC(hipDeviceSynchronize());
+  const Workspace& sw = g->ws.bal ? g->ws : g->ws_alt;
+  if (sw.bal) {
+    XccBalance hb;
+    HIPC(hipMemcpy(&hb, sw.bal, sizeof hb, hipMemcpyDeviceToHost));
+    memcpy(out_w8, hb.w, sizeof hb.w);
+    if (out_launches) *out_launches = (int32_t)hb.launches;
+  } else {
+    // no workspace yet: what the first one will start from (the file's shares, else an even split: -1 launches)
+    for (int x = 0; x < 8; ++x) out_w8[x] = g->file_w_valid ? g->file_w[x] : 0.125f;
+    if (out_launches) *out_launches = -1;
+  }
+  return MI_OK;
+}
+
 int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count) {
   REQUIRE(g && out_host, "null");
   REQUIRE(g->ws.dbg && count <= (int64_t)g->ws.nseg * 8, "no diagnostics buffer");
@@ -2317,6 +2463,10 @@ int mi_set_global_option(const char* name, double value) {
   REQUIRE(name, "null");
   const std::string n(name);
   if (n == "image_dtype") g_default_img_f16 = value != 0;
+  else if (n == "host_ingest") {
+    REQUIRE(value == 0 || value == 1, "host_ingest: 0 (one copy of the whole array) or 1 (row blocks)");
+    g_host_ingest = (int)value;
+  }
   else return fail(MI_ERR_INVALID, "unknown global option: " + n);
   return MI_OK;
 }

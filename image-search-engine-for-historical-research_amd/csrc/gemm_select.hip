@@ -1225,6 +1225,26 @@ void init_xcc_balance_host(XccBalance* h) {
   h->launches = 0;
 }
 
+// shares remembered from earlier launches (the prepared-gallery file, another handle of this process on the same device): the
+// first launch then starts from them instead of from an even split.  Nonsense input falls back to the even split.
+void init_xcc_balance_from(XccBalance* h, const float* w8) {
+  float sum = 0.f;
+  bool ok = true;
+  for (int x = 0; x < 8; ++x) {
+    ok &= w8[x] == w8[x] && w8[x] > 0.02f && w8[x] < 0.5f;
+    sum += w8[x];
+  }
+  if (!ok || !(sum > 0.5f && sum < 2.0f)) return init_xcc_balance_host(h);
+  float c = 0.f;
+  for (int x = 0; x < 8; ++x) {
+    h->w[x] = w8[x] / sum;
+    h->cum[x] = (uint32_t)(c * (float)XCC_ONE + 0.5f);
+    c += w8[x] / sum;
+  }
+  h->cum[8] = XCC_ONE;
+  h->launches = 0;
+}
+
 // The product build holds SIX instantiations of the tile kernel -- {bootstrap, filtered launch, conditional repair launch} x
 // {fp16, bf16 image}, structure 2, snake order -- and nothing else.  Every diagnostic (DBG != 0: stages switched off, stamps),
 // A/B (ORDER, OPT, POL, the paired-XCD walk) and structure-1 instantiation is compiled under -DMI_KBENCH only, i.e. into

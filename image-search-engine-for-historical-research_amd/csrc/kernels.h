@@ -75,6 +75,7 @@ void launch_scatter_records(const SurvRec* rec, const uint32_t* rec_cnt, uint32_
                             QueryState st, const uint32_t* cond, hipStream_t stream, XccBalance* bal = nullptr,
                             const unsigned long long* dbg = nullptr, uint32_t ntiles = 0, int32_t nq = 0);   // nq: queries of the batch
 void init_xcc_balance_host(XccBalance* host);
+void init_xcc_balance_from(XccBalance* host, const float* w8);   // from remembered shares (file / process cache)
 
 // exact_score.hip -- f32 FMA scoring with the same filter (fallback / force_exact)
 struct ExactArgs {

@@ -25,6 +25,36 @@ class Searcher:
         self.method, self.ifgenerate, self.device = matching_method, ifgenerate, device
         self._lock = threading.Lock()
 
+    def _device_chain(self):
+        """The two prepared galleries of the chain -- L2-normalised rows for the search (matching_L2's ranking), the rows as
+        stored for qge1's expansion and re-search (src/online.py:132,148: `vecs` itself) -- wrapped for device tensors."""
+        if getattr(self, "_chain", None) is None:
+            from ..nnsearch import get_gallery, NORM_L2, NORM_NONE
+            from ..sharded import ShardedGallery
+            g1 = get_gallery(self.vecs.T, "database", self.ifgenerate, NORM_L2, self.device)
+            g2 = get_gallery(self.vecs.T, "database_raw", self.ifgenerate, NORM_NONE, self.device)
+            self.ifgenerate = False
+            self._chain = (ShardedGallery(g1), ShardedGallery(g2))
+        return self._chain
+
+    def query_device(self, desc, return_indices=False):
+        """The online chain WITHOUT a host round trip (src/online.py:121-152 copies the descriptor to the CPU,
+        searches there and re-ranks there): `desc` is the extractor tail's output on the device (float32 cuda tensor [D] or
+        [Q, D]: isehr_amd.extractor.DescriptorTail / extract_ms_device -> mi_desc_tail_device), the search (K nearest by cosine),
+        the qge1 expansion from the top-3 rows (k = 3, w = 4, float64 sum, eps-normalised) and the re-search of the expanded
+        query all run on the device through the asynchronous entry points; ONE device-to-host copy of Q x K indices ends it."""
+        if desc.dim() == 1:
+            desc = desc[None, :]
+        desc = desc.contiguous().float()
+        with self._lock:
+            sg1, sg2 = self._device_chain()
+            idx, _ = sg1.search(desc, self.K)
+            idx2, _, _ = sg2.aqe_search(idx.t(), 3, 4.0, self.K)
+            out = idx2.cpu().numpy()                                  # the one D2H copy (synchronises)
+        if return_indices:
+            return out
+        return [[self.img_paths[i] for i in row] for row in out]
+
     def query(self, qvec):
         qvec = np.asarray(qvec)
         if qvec.ndim == 1:

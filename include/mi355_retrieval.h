@@ -330,11 +330,21 @@ int mi_search_flags(mi_gallery* g, uint32_t* out_flags);
 
 /* Process-wide defaults for galleries created afterwards.  "image_dtype": element type of the 16-bit tile-blocked image the
  * MFMA kernel streams, 1 = fp16 (default: 2^-11 rounding, 8x tighter certificate than bf16 at the same MFMA rate;
- * un-normalised galleries whose rows exceed its comfortable range are stored as bf16 automatically), 0 = bf16. */
+ * un-normalised galleries whose rows exceed its comfortable range are stored as bf16 automatically), 0 = bf16.
+ * "host_ingest": how mi_gallery_create moves a HOST array in one of the reference's two layouts to the device: 1 (default) = row
+ * blocks of ~32 MiB copied by the runtime straight from the caller's pageable array into two alternating device blocks, the copy
+ * of block i + 1 under the ingest of block i, no staging allocation the size of the gallery; 0 = one copy of the whole array into
+ * a same-size staging buffer, then one ingest (rounds 1-4).  Both reach 0.96 of the pinned H2D rate (profiles/r05f_*). */
 int mi_set_global_option(const char* name, double value);
 
-/* Diagnostics only: per-wave cycle sums written by the stamped build of the scoring kernel (option "debug"=8);
- * layout [workgroups*8][8] = {load, barrier1, mfma, barrier2, epilogue, slices, -, -}. */
+/* The XCD shares of the tile kernel (relative speeds of the eight XCD labels, summing to 1) as the handle's launches have left
+ * them, and how many launches have updated them since the workspace was created (-1: no workspace yet; the values are then what
+ * the first one will start from).  The shares are saved with the prepared-gallery file (optional trailer) and remembered per
+ * device inside the process, so `load -> first search` and a second gallery of a process start calibrated. */
+int mi_debug_xcc_shares(mi_gallery* g, float* out_w8, int32_t* out_launches);
+/* Diagnostics only: the per-wave words the tile kernel leaves behind, layout [workgroups * 8][8]: word 5 = K-slices done, word 6 =
+ * shader cycles and word 7 = 10-ns ticks around the main loop (what kernel_clock_mhz and the XCD shares are computed from); words
+ * 0-4 are written by the stamped build of scripts/kbench.hip only. */
 int mi_debug_read_cycles(mi_gallery* g, uint64_t* out_host, int64_t count);
 
 /* Diagnostics only: the gallery row that sample row i of the bootstrap sample image is drawn from (shard of n rows, sample

@@ -103,6 +103,8 @@ def test_default_line_gives_every_baseline_config_a_number():
         b = out[name]
         assert b["roofline"]["bound"] == "hbm" and 0.3 < b["roofline"]["frac"] < 1 and b["flagged_batches"] == 0
         assert b["value"] > 0 and b["roofline"]["kernel"] == "stream_select_kernel"
+    o = out["online"]
+    assert o["online_query_ms"] > 0 and o["gallery_rows"] == 1005994 and "one D2H" in o["stages"]
     a = out["aqe_rparis_1m"]
     assert a["gallery_rows"] == 1007323 and a["q1024"]["value"] > 0 and a["q70"]["value"] > 0
     assert a["q1024"]["flagged_batches"] == 0 and "dense float64" in a["q70"]["score_check"]
@@ -111,6 +113,7 @@ def test_default_line_gives_every_baseline_config_a_number():
     assert g["max_abs_map_difference_alpha_qe"] <= 1e-6 and "_ranks_aqe" not in g
     assert 0 < g["map"]["diffusion"]["M"] <= 1
     d = out["dropin"]
+    assert d["device_ingest_both_layouts"]["dn_over_row_major"] < 1.5
     assert d["same_answers"] is True and d["bytes"] == 2048 * 1005994 * 4 and d["pinned_h2d_GBps"] > 5
     c = d["calls"]
     assert c["dataset_first_call"]["gallery"]["source"] == "built" and c["dataset_cached"]["gallery"]["source"] == "cached"

@@ -56,6 +56,43 @@ def test_offline_then_online(feature_store, capsys):
     np.save("q.npy", qvecs[:, :2])
     assert online.main(["--datasets", "dsA,dsB", "--query-npy", "q.npy"]) == 0
     assert ".jpg" in capsys.readouterr().out
+    # the same query through the device chain (descriptor on the device -> search -> qge1 -> one D2H of K indices)
+    import torch
+    got_dev = s.query_device(torch.from_numpy(np.ascontiguousarray(qvecs[:, 3])).cuda())
+    assert got_dev == got
+
+
+def test_online_device_chain_vs_reference_qge1_golden(golden_dir, tmp_path, monkeypatch):
+    """`Searcher.query_device` -- extractor-tail descriptor on the device -> mi_knn_search_device (K) -> qge1
+    expansion (k = 3, w = 4) -> re-search, one D2H of K indices -- against the reference's own feature_enhancement
+    (tests/golden/qge.npz: `base` ranks, expanded queries, re-ranked lists; src/utils/Reranking.py:195-208, 287-306) and
+    against the host chain `Searcher.query`."""
+    import torch
+    from isehr_amd import nnsearch
+    from isehr_amd.entry import online
+    from isehr_amd.synth import synth_rows
+    monkeypatch.chdir(tmp_path)
+    z = np.load(os.path.join(golden_dir, "qge.npz"))
+    seed, n, d, nq = (int(v) for v in z["meta"])
+    vecs = np.ascontiguousarray(synth_rows(seed, 0, n, d).T)          # tests/test_gpu_rerank_and_shards.py::_setup
+    qv = np.ascontiguousarray(synth_rows(seed + 1000, 0, nq, d).T)
+    vecs = vecs / np.linalg.norm(vecs, axis=0, keepdims=True)
+    K = 200
+    s = online.Searcher(vecs, list(range(n)), K)
+    try:
+        got = s.query_device(torch.from_numpy(np.ascontiguousarray(qv.T)).cuda(), return_indices=True)      # [Q, K]
+        host = np.array(s.query(qv))                                  # the host chain, same galleries
+        assert np.array_equal(got, host)
+        # the search stage of the chain equals the golden's `base` ranks (top-3 feed the expansion), the result its re-ranking
+        base = z["base"]
+        first, _ = nnsearch.matching_HIP(K, vecs.T, qv.T)
+        assert np.array_equal(first.T[:3], base[:3])
+        ref_qx, ref_ranks = z["qx3"], z["ranks3_top"]
+        s64 = (vecs.astype(np.float64).T @ ref_qx).T
+        assert oracle.check_topk_parity(got, s64, K, 1e-6) == []
+        assert (got.T == ref_ranks).mean() > 0.99
+    finally:
+        nnsearch.drop_cached_galleries()
 
 
 @pytest.mark.parametrize("mode,gpus", [("100", "0"), ("mAP", "0"), ("100", "0,0")])

@@ -161,6 +161,51 @@ def test_save_load_roundtrip(tmp_path):
         Gallery.load(path)
 
 
+def test_xcd_shares_travel_with_the_file_and_within_the_process(tmp_path):
+    """VERDICT r04 #7b: the XCD shares the tile kernel learns (common.h XccBalance) are written with the prepared-gallery file and
+    remembered per device inside the process: `load -> first search` and a second gallery start from them instead of from an
+    even split that the first ~4 large launches would have to correct (mi_gallery_calibrate stays available, no longer needed)."""
+    from isehr_amd._lib import Gallery
+    n, d = 140000, 64                                      # 547 gallery tiles: launches large enough to measure shares
+    rows = synth_rows(501, 0, n, d)
+    q = synth_rows(502, 0, 512, d)
+    G = Gallery.from_host(rows)
+    path = str(tmp_path / "g.mi355gal")
+    try:
+        w0, l0 = G.xcc_shares()
+        assert l0 == -1                                     # no workspace yet
+        G.calibrate(6)
+        w1, l1 = G.xcc_shares()
+        assert l1 >= 5 and abs(float(w1.sum()) - 1.0) < 1e-5 and (w1 > 0.05).all()
+        ref, _, _ = G.search(q, 10)
+        G.save(path)
+    finally:
+        G.close()
+    L = Gallery.load(path)
+    try:
+        w2, l2 = L.xcc_shares()
+        assert l2 == -1 and not np.allclose(w2, 0.125) and abs(float(w2.sum()) - 1.0) < 1e-5
+        got, _, _ = L.search(q[:4], 10)                     # a small batch: creates the workspace, measures nothing
+        w3, l3 = L.xcc_shares()
+        assert l3 == 0 and np.allclose(w3, w2, atol=1e-6) and not np.allclose(w3, 0.125)
+        assert np.array_equal(L.search(q, 10)[0], ref)      # and the answers do not depend on any of it
+    finally:
+        L.close()
+    # a gallery created afterwards in this process starts from the device's last shares too
+    H = Gallery.from_host(rows[:4000])
+    try:
+        H.search(q[:4], 10)
+        w4, l4 = H.xcc_shares()
+        assert l4 == 0 and not np.allclose(w4, 0.125) and abs(float(w4.sum()) - 1.0) < 1e-5
+    finally:
+        H.close()
+    # a file with anything else behind its last section is refused
+    with open(path, "ab") as f:
+        f.write(b"garbage")
+    with pytest.raises(RuntimeError, match="trailing"):
+        Gallery.load(path)
+
+
 def test_matching_hip_dataset_cache(tmp_path, monkeypatch):
     """The stateful form follows the ANN methods' convention: outputs/<dataset>/ + ifgenerate."""
     from isehr_amd import nnsearch
