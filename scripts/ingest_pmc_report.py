@@ -9,13 +9,14 @@ for layout in ("rows", "cols"):
     vals = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         fs = glob.glob(f"{root}/gpurun_out/{tag}_ingest_{layout}_{kind}/*/*counter_collection.csv")
-        per = []
+        per, name = [], ""
         for f in fs:
             for r in csv.DictReader(open(f)):
                 if "ingest_" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                     per.append(float(r["Counter_Value"]))
+                    name = r["Kernel_Name"].split("(")[0].replace("void mi::", "")[:60]
         if per:
-            vals[kind] = (sum(per) / len(per), len(per), r["Kernel_Name"].split("(")[0][:60])
+            vals[kind] = (sum(per) / len(per), len(per), name)
     if "fetch" in vals and "write" in vals:
         rd, wr = vals["fetch"][0] * 1024 * 2, vals["write"][0] * 1024
         print("%s: %s  launches %d: read %.3f GB (algorithmic %.3f: x %.3f)  written %.3f GB (algorithmic %.3f: x %.3f)  total %.2f GB vs 20.6"
