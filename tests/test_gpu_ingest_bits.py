@@ -89,3 +89,90 @@ def test_gallery_bits_are_layout_independent(name, layout):
     assert got["section_sums"][1] == want["section_sums"][1], "16-bit image differs"
     assert got["section_sums"][2] == want["section_sums"][2], "rounding norms differ"
     assert got["gstat3_hex"] == want["gstat3_hex"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_layouts_blocks_and_odd_shapes_give_the_same_rows(seed):
+    """Seeded sweep over what the fixture cases do not pin: row counts around the panel / run / block boundaries, widths other
+    than 2048 (the scratch-block path), rows with a stride (a [N, D'] array with D' > D), float64, raw (un-normalised) rows,
+    column blocks of odd lengths (appends whose first row is no multiple of 4), host and device sources.  The gallery of every
+    variant must hold the same stored rows, the same norm maxima and give the same answers as the row-major device gallery."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.synth import synth_rows
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([2048, 2048, 2048, 64, 100, 320, 2500]))
+    n = int(rng.choice([1, 3, 15, 16, 17, 255, 256, 257, 1000, 4099, 16385, 40001]))
+    if d != 2048:
+        n = min(n, 4099)
+    f64 = bool(rng.integers(0, 2)) and d <= 2048
+    norm = int(rng.choice([_lib.NORM_L2, _lib.NORM_L2, _lib.NORM_L2_EPS, _lib.NORM_NONE]))
+    rows = synth_rows(2000 + seed, 0, n, d)
+    if norm == _lib.NORM_NONE:
+        rows = (rows / np.linalg.norm(rows, axis=1, keepdims=True)).astype(np.float32)      # unit rows: fp16 image like the others
+    rows = rows.astype(np.float64) if f64 else rows
+    code = _lib.MI_F64 if f64 else _lib.MI_F32
+    q = synth_rows(3000 + seed, 0, 5, d)
+    k = min(n, 10)
+
+    def snapshot(g):
+        try:
+            idx, sc, _ = g.search(q, k)
+            return g.get_rows(0, n).tobytes(), tuple(g.norm_bounds()), idx.tobytes(), sc.tobytes()
+        finally:
+            g.close()
+    t = torch.from_numpy(rows).cuda()
+    ref = snapshot(_lib.Gallery.from_device_ptr(t.data_ptr(), n, d, norm_mode=norm, dtype=code))
+    variants = {}
+    variants["host rows"] = _lib.Gallery.from_host(rows, norm_mode=norm)
+    variants["host [D,N].T"] = _lib.Gallery.from_host(np.ascontiguousarray(rows.T).T, norm_mode=norm)
+    wide = np.zeros((n, d + 24), dtype=rows.dtype)
+    wide[:, :d] = rows
+    variants["host rows with a stride"] = _lib.Gallery.from_host(wide[:, :d], norm_mode=norm)
+    tt = torch.from_numpy(np.ascontiguousarray(rows.T)).cuda()
+    variants["device [D,N]"] = _lib.Gallery.from_device_ptr(tt.data_ptr(), n, d, norm_mode=norm, dtype=code, row_stride=1,
+                                                            col_stride=n)
+    tw = torch.from_numpy(wide).cuda()
+    variants["device rows with a stride"] = _lib.Gallery.from_device_ptr(tw.data_ptr(), n, d, norm_mode=norm, dtype=code,
+                                                                         row_stride=d + 24, col_stride=1)
+    if norm != _lib.NORM_NONE and n >= 3:
+        a = np.ascontiguousarray(rows.T)
+        c1 = max(1, n // 3) | 1                                        # odd: the next block starts at a row that is no multiple of 4
+        variants["odd column blocks"] = _lib.Gallery.from_blocks([a[:, :c1], a[:, c1:]], norm_mode=norm, chunk_rows=999)
+    for mode in (0, 1):
+        _lib.set_global_option("host_ingest", mode)
+        try:
+            variants["host [D,N].T, host_ingest %d" % mode] = _lib.Gallery.from_host(np.ascontiguousarray(rows.T).T, norm_mode=norm)
+        finally:
+            _lib.set_global_option("host_ingest", 1)
+    for name, g in variants.items():
+        got = snapshot(g)
+        assert got[0] == ref[0], (name, n, d, f64, norm, "stored rows differ")
+        assert got[1] == ref[1], (name, n, d, f64, norm, "norm maxima differ")
+        assert got[2] == ref[2] and got[3] == ref[3], (name, n, d, f64, norm, "answers differ")
+
+
+def test_gallery_file_round_trip_small_and_mapped(tmp_path):
+    """The loader maps the file and lets the runtime copy from the mapping; a file of a few KB, one with an odd width, and the
+    checks of a corrupted payload all go through it."""
+    from isehr_amd import _lib
+    from isehr_amd.synth import synth_rows
+    for n, d in ((1, 64), (257, 100), (3000, 2048)):
+        rows = synth_rows(77, 0, n, d)
+        g = _lib.Gallery.from_host(rows)
+        path = str(tmp_path / ("g_%d_%d.bin" % (n, d)))
+        try:
+            want = MAKER.gallery_sums(g)
+            g.save(path)
+        finally:
+            g.close()
+        L = _lib.Gallery.load(path)
+        try:
+            assert MAKER.gallery_sums(L)["section_sums"] == want["section_sums"]
+        finally:
+            L.close()
+        raw = bytearray(open(path, "rb").read())
+        raw[len(raw) // 2] ^= 0x40                                    # one flipped bit in the payload
+        open(path, "wb").write(raw)
+        with pytest.raises(RuntimeError, match="checksum"):
+            _lib.Gallery.load(path)
