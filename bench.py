@@ -390,6 +390,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     _lib.set_global_option("image_dtype", 1 if image_dtype == "f16" else 0)
     alloc_s = None
     ingest_kernel_s = None
+    ingest_launch_ms = None
     t0 = time.time()
     if warm_ingest or (hi - lo) * d * 4 <= 16 << 30:
         gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
@@ -423,13 +424,21 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
             g2.close()
         # and the device work alone: the same rows appended to a gallery whose buffers exist already (what hipMalloc costs
         # differs between boxes and states of the driver by a factor of ten; the kernels do not)
-        g3 = _lib.Gallery.empty(hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index, row_offset=lo)
+        # -- the same rows appended to three galleries back to back, each launch between HIP events on the launch stream.  The
+        # same launch takes 3.5-4.1 ms on one box depending on where the driver put the buffers (scripts/ingest_context_probe.py):
+        # the three destinations are three placements; `ingest_kernel_s` is their median
+        g3 = [_lib.Gallery.empty(hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index, row_offset=lo) for _ in range(3)]
         torch.cuda.synchronize()
-        t0 = time.time()
-        g3.append_device(raw.data_ptr(), hi - lo, stream)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        evs[0].record()
+        for i in range(3):
+            g3[i].append_device(raw.data_ptr(), hi - lo, stream)
+            evs[i + 1].record()
         torch.cuda.synchronize()
-        ingest_kernel_s = time.time() - t0
-        g3.close()
+        ingest_launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(3)]
+        ingest_kernel_s = sorted(ingest_launch_ms)[1] * 1e-3
+        for g in g3:
+            g.close()
     del raw
     torch.cuda.empty_cache()
     for opt in options:
@@ -599,7 +608,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
                job_steps=job_steps,
-               ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, alloc_s=alloc_s, worst=worst,
+               ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, ingest_launch_ms=ingest_launch_ms, alloc_s=alloc_s, worst=worst,
                use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check,
                protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
 
@@ -1232,6 +1241,7 @@ def main():
                            # rate of ONE call that prepares the gallery and answers one batch
                            "ingest_s": round(res["ingest_s"], 4), "ingest_first_s": round(res["ingest_first_s"], 3),
                            "ingest_kernel_s": round(res["ingest_kernel_s"], 5) if res["ingest_kernel_s"] else None,
+                           "ingest_launch_ms": ([round(x, 3) for x in res["ingest_launch_ms"]] if res["ingest_launch_ms"] else None),
                            "queries_per_s_incl_gallery_ingest_per_call_of_one_batch": nq / (ms_step * 1e-3 + res["ingest_s"]),
                            "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                            "survivors_per_query": st["survivors"] / max(1, st["queries"]),

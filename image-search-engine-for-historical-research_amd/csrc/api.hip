@@ -37,6 +37,36 @@ static std::atomic<int> g_host_ingest{1};
 // loaded from a file written without shares -- starts from these instead of from an even split
 static std::mutex g_bal_mu;
 static std::map<int, std::vector<float>> g_bal_cache;
+// mi_set_global_option("keep_buffers", 0 | 1): a caller that prepares a gallery per call -- create, search, destroy: what a
+// stateless matching_<method>(K, train, test) is (src/utils/nnsearch.py:687-706) -- pays hipMalloc + hipFree of the gallery's
+// buffers every time (12.4 GB at 1 005 994 x 2048: 1-6 ms, more than half an ingest, and an idle GPU meanwhile).  With 1
+// (default) mi_gallery_destroy hands the four buffers of a gallery of up to 16 GiB to ONE spare slot per process instead of
+// freeing them, and the next gallery of exactly the same sizes on the same device takes them (every byte a search reads is
+// written by the ingest or by an explicit memset; nothing depends on fresh memory).  0 frees the spare and stops keeping.
+struct SpareBuffers {
+  int device = -1;
+  size_t f32_bytes = 0, img_bytes = 0, stat_bytes = 0;
+  float* gal_f32 = nullptr;
+  void* gal_img = nullptr;
+  RowStat* rowstat = nullptr;
+  float* gstat3 = nullptr;
+};
+static std::mutex g_spare_mu;
+static SpareBuffers g_spare;
+static std::atomic<int> g_keep_buffers{1};
+static const size_t SPARE_MAX_BYTES = (size_t)16 << 30;
+static void spare_release_locked() {
+  if (g_spare.device < 0) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  (void)hipSetDevice(g_spare.device);
+  (void)hipFree(g_spare.gal_f32);
+  (void)hipFree(g_spare.gal_img);
+  (void)hipFree(g_spare.rowstat);
+  (void)hipFree(g_spare.gstat3);
+  (void)hipSetDevice(cur);
+  g_spare = SpareBuffers();
+}
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -126,6 +156,7 @@ struct mi_gallery {
   void* samp_img = nullptr;
   int64_t samp_tiles = 0, samp_for_n = -1;
   int64_t hbm_bytes = 0;
+  size_t buf_bytes[3] = {0, 0, 0};                 // gal_f32 / gal_img / rowstat as allocated (what a spare slot is matched by)
   // XCD shares read from the prepared-gallery file (MI355GAL trailer) / snapshotted for the next save
   float file_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool file_w_valid = false;
@@ -854,12 +885,24 @@ int mi_gallery_destroy(mi_gallery* g) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
-  (void)hipFree(g->gal_f32);
-  (void)hipFree(g->gal_img);
+  {
+    // (every stream of the handle is drained above: nothing in flight touches these buffers any more)
+    std::lock_guard<std::mutex> lock(g_spare_mu);
+    const size_t total = g->buf_bytes[0] + g->buf_bytes[1] + g->buf_bytes[2];
+    if (g_keep_buffers.load() && g->gal_f32 && g->gal_img && g->rowstat && g->gstat3 && total <= SPARE_MAX_BYTES) {
+      spare_release_locked();
+      g_spare.device = g->device;
+      g_spare.f32_bytes = g->buf_bytes[0], g_spare.img_bytes = g->buf_bytes[1], g_spare.stat_bytes = g->buf_bytes[2];
+      g_spare.gal_f32 = g->gal_f32, g_spare.gal_img = g->gal_img, g_spare.rowstat = g->rowstat, g_spare.gstat3 = g->gstat3;
+    } else {
+      (void)hipFree(g->gal_f32);
+      (void)hipFree(g->gal_img);
+      (void)hipFree(g->rowstat);
+      (void)hipFree(g->gstat3);
+    }
+  }
   (void)hipFree(g->samp_img);
   for (void* b : g->io_buf) (void)hipFree(b);
-  (void)hipFree(g->rowstat);
-  (void)hipFree(g->gstat3);
   (void)hipFree(g->dif_ids);
   (void)hipFree(g->dif_vals);
   if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -904,11 +947,23 @@ static int gallery_alloc(mi_gallery* g) {
   HIPC(hipSetDevice(g->device));
   HIPC(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
   const size_t f32_bytes = (size_t)g->cap * g->dp * 4, bf_bytes = (size_t)cap_pad * g->dp * 2;
+  const size_t stat_bytes = (size_t)cap_pad * sizeof(RowStat);
+  g->buf_bytes[0] = f32_bytes, g->buf_bytes[1] = bf_bytes, g->buf_bytes[2] = stat_bytes;
+  g->hbm_bytes = (int64_t)(f32_bytes + bf_bytes + stat_bytes);
+  {
+    std::lock_guard<std::mutex> lock(g_spare_mu);
+    if (g_spare.device == g->device && g_spare.f32_bytes == f32_bytes && g_spare.img_bytes == bf_bytes &&
+        g_spare.stat_bytes == stat_bytes) {                      // the buffers of the gallery destroyed last: same sizes
+      g->gal_f32 = g_spare.gal_f32, g->gal_img = g_spare.gal_img, g->rowstat = g_spare.rowstat, g->gstat3 = g_spare.gstat3;
+      g_spare = SpareBuffers();
+      return MI_OK;
+    }
+    if (f32_bytes + bf_bytes + stat_bytes > SPARE_MAX_BYTES / 2) spare_release_locked();   // a big gallery of other sizes: make room
+  }
   HIPC(hipMalloc((void**)&g->gal_f32, f32_bytes + 256));
   HIPC(hipMalloc(&g->gal_img, bf_bytes + 256));
-  HIPC(hipMalloc((void**)&g->rowstat, (size_t)cap_pad * sizeof(RowStat)));
+  HIPC(hipMalloc((void**)&g->rowstat, stat_bytes));
   HIPC(hipMalloc((void**)&g->gstat3, 16));
-  g->hbm_bytes = (int64_t)(f32_bytes + bf_bytes + (size_t)cap_pad * sizeof(RowStat));
   return MI_OK;
 }
 
@@ -2503,6 +2558,14 @@ int mi_set_global_option(const char* name, double value) {
   else if (n == "host_ingest") {
     REQUIRE(value == 0 || value == 1, "host_ingest: 0 (one copy of the whole array) or 1 (row blocks)");
     g_host_ingest = (int)value;
+  }
+  else if (n == "keep_buffers") {
+    REQUIRE(value == 0 || value == 1, "keep_buffers: 0 or 1");
+    g_keep_buffers = (int)value;
+    if (value == 0) {
+      std::lock_guard<std::mutex> lock(g_spare_mu);
+      spare_release_locked();
+    }
   }
   else return fail(MI_ERR_INVALID, "unknown global option: " + n);
   return MI_OK;

@@ -404,13 +404,18 @@ __global__ __launch_bounds__(256) void ingest_query_kernel(const InT* __restrict
 //            butterfly.  After the regrouping through the wave's own LDS row lane l takes chunks t = l + 64 k (k = 0..3):
 //            virtual lane = l, virtual wave = k -- the plain wave butterfly on 3 x 4 accumulators.
 // f32 rows are stored straight from the load layout (16 bytes per lane, 1 KiB per instruction).
-// FULL: d == 256 * PT and rows 16-byte aligned -- every column of every float4 is inside the row: no per-element selects.
+// FULL: d == 256 * PT, rows 16-byte aligned, coop -- every column of every float4 is inside the row: no per-element selects, no
+//       per-wave image stores compiled in; 152 registers: three waves per SIMD (the generic instantiations take what they need).
+// PREFETCH: the wave's next row is requested into the registers of the current one as soon as those are consumed.
+// Launch-to-launch, the same launch on the same box takes 3.5-4.1 ms depending on where the driver put the three buffers (one
+// process: +-0.5 %; scripts/ingest_context_probe.py, profiles/r05o_*): compare kernels inside ONE process (scripts/ingest_ab.sh).
 template <typename InT, int PT, bool PREFETCH, bool FULL>
-__global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs, int norm_mode,
+__global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const InT* __restrict__ src, int64_t n, int32_t d, int64_t rs, int norm_mode,
                                                           float* __restrict__ out_f32, uint16_t* __restrict__ out_img,
                                                           int img_f16, RowStat* __restrict__ rowstat, int32_t dp,
-                                                          int64_t nrows, int64_t row_base, int vec_ok, int coop) {
-  __shared__ __attribute__((aligned(16))) float wbuf[4][PT * 256];
+                                                          int64_t nrows, int64_t row_base, int vec_ok, int coop_arg, int xcd_walk) {
+  const bool coop = FULL || coop_arg;                // FULL: launched for coop only -- the per-wave image stores are not even compiled in
+  __shared__ __attribute__((aligned(16))) float wbuf[4][1024];
   // coop (row_base and nrows multiples of 4): the 16-bit image of a run leaves through the workgroup -- [slice][row of the run][64 B]
   // is, slice by slice, the 256 contiguous bytes the run owns in that slice's block of the tile, so after one barrier every wave
   // copies 16 slices out with 256 contiguous bytes per 16 lanes.  Written by each wave for its own row, a row's piece of a
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* buf = wbuf[wv];
   struct Raw { InT v[4]; };
-  Raw cur[PT], nxt[PT];
+  Raw cur[PT];
   // loads are unconditional (row and column clamped into the source; the zero is selected where the value is USED): a load
   // behind a branch makes the number of outstanding loads path-dependent and the compiler then waits right behind the request
   auto request = [&](Raw* dst, int64_t r) {
@@ -446,13 +451,25 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
   };
   const int nslices = dp / SLICE_K;
   const int64_t nruns = (nrows + 3) / 4;
-  int64_t run = blockIdx.x;
-  if (run >= nruns) return;
+  // xcd_walk (grid a multiple of 8): the workgroups of one XCD label (b, b + 8, ...: round-robin dispatch, used for speed only)
+  // walk ONE contiguous eighth of the runs (whole tiles) side by side instead of every eighth run of the whole gallery: an
+  // XCD's L2 and translation caches see an eighth of the pages
+  int64_t run, run_hi, step;
+  if (xcd_walk) {
+    const int64_t per_xcd = ((nruns + 7) / 8 + 63) / 64 * 64;
+    const int64_t lo = (int64_t)(blockIdx.x & 7) * per_xcd;
+    run_hi = lo + per_xcd < nruns ? lo + per_xcd : nruns;
+    run = lo + (blockIdx.x >> 3);
+    step = gridDim.x >> 3;
+  } else {
+    run = blockIdx.x, run_hi = nruns, step = gridDim.x;
+  }
+  if (run >= run_hi) return;
   request(cur, run * 4 + wv);
-  for (int par = 0; run < nruns; run += gridDim.x, par ^= 1) {
+  for (int par = 0; run < run_hi; run += step, par ^= 1) {
     const int64_t row = run * 4 + wv;
-    const int64_t next_row = (run + gridDim.x) * 4 + wv;
-    if (PREFETCH) request(nxt, next_row < nrows ? next_row : row);      // past the end: a harmless re-load
+    const int64_t next_row = run + step < run_hi ? (run + step) * 4 + wv : row;
+    bool requested = false;
     const int64_t orow = row_base + row;
     const int64_t tileidx = orow / TILE;
     const uint32_t r = (uint32_t)(orow % TILE);
@@ -499,11 +516,16 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
         const double nrm = sqrt(tot);
         scale = (norm_mode == 1) ? 1.0 / nrm : 1.0 / (nrm + 1e-6);      // norm 0 -> inf -> NaN row, like the reference
       }
-      // ---- normalised f32 row: to memory from the load layout, and into the wave's LDS row for the regrouping
-      // (all of the row's values first, each in registers of its own, then the stores: a store's data registers are busy
-      // until the store has COMPLETED -- vmcnt, in order, behind the prefetch loads -- so re-using one register for the
-      // next store's data made the wave wait for the next row's loads in the middle of this row)
+      // ---- the row in QUARTERS of 1024 columns (four float4 per lane): scaled values to memory from the load layout (16 bytes
+      // per lane, 1 KiB per instruction) and into the wave's 4 KiB of LDS for the regrouping; then lane l takes the 8-column
+      // chunks l and l + 64 of the quarter -- chunks l + 64 k (k = 2 (q & 1), + 1) of the row's 2048-column block q >> 1: virtual
+      // lane l, virtual wave k, blocks ascending: the sums of the old kernel's virtual threads, add for add.
+      // (A quarter at a time: 16 KiB of LDS per workgroup instead of 32, and three workgroups per CU instead of two -- half as
+      // many bytes again in flight.  Every quarter's values sit in registers of their own: a store's data registers are busy
+      // until the store has COMPLETED -- vmcnt, in order, behind the prefetch loads -- so re-using them for the next quarter
+      // made the wave wait for the next row's loads in the middle of this row.)
       float* orow_p = out_f32 + orow * dp + 4 * lane;
+      double s_g[4] = {0.0, 0.0, 0.0, 0.0}, s_b[4] = {0.0, 0.0, 0.0, 0.0}, s_d[4] = {0.0, 0.0, 0.0, 0.0};
       float4 y[PT];
 #pragma unroll
       for (int i = 0; i < PT; ++i) {
@@ -513,25 +535,32 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
         y[i].z = (FULL || c + 2 < d) ? (float)((double)cur[i].v[2] * scale) : 0.0f;
         y[i].w = (FULL || c + 3 < d) ? (float)((double)cur[i].v[3] * scale) : 0.0f;
       }
-#pragma unroll
-      for (int i = 0; i < PT; ++i) *reinterpret_cast<float4*>(buf + 4 * lane + 256 * i) = y[i];
-#pragma unroll
-      for (int i = 0; i < PT; ++i)
-        if ((FULL || 4 * lane + 256 * i < dp) && !(MI_INGEST_PROBE & 2)) *reinterpret_cast<float4*>(orow_p + 256 * i) = y[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // ---- 16-bit image + rounding statistics: lane l takes the 8-column chunks l + 64 k
-      double s_g[4] = {0.0, 0.0, 0.0, 0.0}, s_b[4] = {0.0, 0.0, 0.0, 0.0}, s_d[4] = {0.0, 0.0, 0.0, 0.0};
+      // the next row of this wave is requested INTO `cur` as soon as its values are consumed: in flight during the image pass,
+      // the stores and the copy-out, at no register cost (a second set of 32 registers held 3 waves per SIMD down to 2)
+      if (PREFETCH) {
+        request(cur, next_row < nrows ? next_row : row);                  // past the end: a harmless re-load
+        requested = true;
+      }
       auto image_pass = [&](auto f16_tag) {
         constexpr bool F16 = decltype(f16_tag)::value;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int q = 0; q < PT / 4; ++q) {
 #pragma unroll
-          for (int h = 0; h < PT / 8; ++h) {
-            const int c0 = 8 * (lane + 64 * k) + 2048 * h;
+          for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(buf + 4 * lane + 256 * ii) = y[4 * q + ii];
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+            if ((FULL || 4 * lane + 256 * (4 * q + ii) < dp) && !(MI_INGEST_PROBE & 2))
+              *reinterpret_cast<float4*>(orow_p + 256 * (4 * q + ii)) = y[4 * q + ii];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int k = 2 * (q & 1) + kk;
+            const int c0 = 8 * (lane + 64 * k) + 2048 * (q >> 1);
             if (FULL || c0 < dp) {
-              const float4 lo = *reinterpret_cast<const float4*>(buf + c0), hi = *reinterpret_cast<const float4*>(buf + c0 + 4);
+              const float* cp = buf + 8 * lane + 512 * kk;
+              const float4 lo = *reinterpret_cast<const float4*>(cp), hi = *reinterpret_cast<const float4*>(cp + 4);
               const float vf[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
               union { uint16_t hh[8]; uint4 u; } pk;
 #pragma unroll
@@ -554,6 +583,10 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
 #endif
             }
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();                        // the quarter's LDS is rewritten by the next one
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       };
       if (img_f16) image_pass(std::true_type{});
       else image_pass(std::false_type{});
@@ -562,7 +595,6 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
       const double mine = reduce_stats12(s_g, s_b, s_d, lane);
       const float nf = (float)(sqrt(mine) * (1.0 + 1e-6));      // rounded UP a little: upper bounds after the f32 conversion
       if (lane == 0 || lane == 8 || lane == 4) reinterpret_cast<float*>(rowstat + orow)[lane == 0 ? 0 : (lane == 8 ? 1 : 2)] = nf;
-      __builtin_amdgcn_wave_barrier();                            // the LDS row is rewritten by the next row of this wave
     }
     if (coop && !(MI_INGEST_PROBE & 4)) {
       // (`run` is the same for the four waves of the workgroup: the barrier is uniform; a last run of fewer than four rows --
@@ -581,12 +613,7 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const InT* __restrict_
         if (sl < nslices && row_ok) *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) = piece[j];
       }
     }
-    if (PREFETCH) {
-#pragma unroll
-      for (int i = 0; i < PT; ++i) cur[i] = nxt[i];
-    } else if (run + gridDim.x < nruns) {
-      request(cur, next_row < nrows ? next_row : row);
-    }
+    if (!requested && run + step < run_hi) request(cur, next_row < nrows ? next_row : row);
   }
 }
 
@@ -944,15 +971,17 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     if (MI_INGEST_PROBE && getenv("MI_INGEST_WG_PER_CU")) occ = atoi(getenv("MI_INGEST_WG_PER_CU"));                    \
     if (MI_INGEST_PROBE) fprintf(stderr, "ingest (wave per row): %d workgroups per CU\n", occ);                         \
     const unsigned grid = (unsigned)std::min<int64_t>((npad + 3) / 4, (int64_t)current_device_cus() * occ);             \
+    const int xcd_walk = grid % 8 == 0 && (npad + 3) / 4 >= 8 * (int64_t)grid && !(MI_INGEST_PROBE & 32768);            \
     hipLaunchKernelGGL((ingest_rows_kernel<T, PT, PF, FULL>), dim3(grid), dim3(256), 0, stream, (const T*)src, n, d,    \
-                       rs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base, vec_ok, coop); \
+                       rs, norm_mode, out_f32, (uint16_t*)out_img, img_f16, rowstat, dp, npad, row_base, vec_ok, coop,  \
+                       xcd_walk);                                                                                       \
   } while (0)
     if (dtype == 0) {
-      if (d == 2048 && vec_ok) MI_GR_LAUNCH(float, 8, true, true);          // the descriptors of the reference: 2048-d
+      if (d == 2048 && vec_ok && coop) MI_GR_LAUNCH(float, 8, true, true);  // the descriptors of the reference: 2048-d
       else if (dp <= 2048) MI_GR_LAUNCH(float, 8, false, false);
       else MI_GR_LAUNCH(float, 16, false, false);
     } else {
-      if (d == 2048 && vec_ok) MI_GR_LAUNCH(double, 8, false, true);
+      if (d == 2048 && vec_ok && coop) MI_GR_LAUNCH(double, 8, false, true);
       else if (dp <= 2048) MI_GR_LAUNCH(double, 8, false, false);
       else MI_GR_LAUNCH(double, 16, false, false);
     }

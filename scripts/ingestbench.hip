@@ -2,7 +2,11 @@
 // builds diagnostic variants: 1 = no rounding statistics, 2 = no f32 row store, 4 = no image store; 0 = the product kernel).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -DMI_INGEST_PROBE=0 scripts/ingestbench.hip -o ingestbench
 //   ingestbench [rows] [dim]
+#ifdef MI_INGEST_SRC          // A/B against a kept copy of the kernels: -DMI_INGEST_SRC='"../ab/ingest_old.hip"' -I <csrc>
+#include MI_INGEST_SRC
+#else
 #include "../image-search-engine-for-historical-research_amd/csrc/ingest.hip"
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +27,17 @@ int current_device_cus() {
   return p.multiProcessorCount;
 }
 }  // namespace mi
+#ifdef MI_INGEST_AB
+// same-process A/B on the SAME buffers (launch-to-launch spread between two processes is 10-15 %: where the driver put the
+// buffers): a kept copy of ingest.hip compiled as an object of its own with -Dmi=mi_old (scripts/ingest_ab.sh)
+namespace mi_old {
+struct RowStat;
+int ensure_dynamic_lds(const void* kernel, int bytes) { return mi::ensure_dynamic_lds(kernel, bytes); }
+int current_device_cus() { return mi::current_device_cus(); }
+void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs, int64_t cs, int norm_mode, float* out_f32,
+                   void* out_img, int img_f16, RowStat* rowstat, int32_t dp, int64_t npad, hipStream_t stream, int64_t row_base);
+}  // namespace mi_old
+#endif
 
 #define CK(e)                                                                      \
   do {                                                                             \
@@ -62,16 +77,44 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int rep = 0; rep < 6; ++rep) {
+#ifdef MI_INGEST_AB
+  const int nrep = 13;
+#else
+  const int nrep = 6;
+#endif
+  for (int rep = 0; rep < nrep; ++rep) {
     CK(hipEventRecord(e0, 0));
+#ifdef MI_INGEST_AB
+    if (rep % 2 == 0) {
+      if (cols) mi_old::launch_ingest(src, 0, n, d, 1, cstride, 1, out, img, 1, (mi_old::RowStat*)rs, d, npad, 0, 0);
+      else mi_old::launch_ingest(src, 0, n, d, d, 1, 1, out, img, 1, (mi_old::RowStat*)rs, d, npad, 0, 0);
+      layout = cols ? "cols(old)" : "rows(old)";
+    } else
+#endif
+    {
     if (cols) mi::launch_ingest(src, 0, n, d, 1, cstride, 1, out, img, 1, rs, d, npad, 0, 0);
     else mi::launch_ingest(src, 0, n, d, d, 1, 1, out, img, 1, rs, d, npad, 0, 0);
+#ifdef MI_INGEST_AB
+    layout = cols ? "cols(new)" : "rows(new)";
+#endif
+    }
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double gb = ((double)n * d * 4 * ((MI_INGEST_PROBE & 2) ? 1 : 2) + ((MI_INGEST_PROBE & 4) ? 0.0 : (double)npad * d * 2)) / 1e9;
     if (rep) printf("probe %d %s rows %lld dim %d: %.3f ms, %.2f TB/s of %.1f GB moved\n", MI_INGEST_PROBE, layout, (long long)n, d, ms, gb / ms, gb);
+  }
+  // the runtime's device-to-device copy of the same source into the same f32 destination (8.2 GB read + 8.2 GB written): what a
+  // copy achieves on THESE buffers, wherever the driver put them
+  for (int rep = 0; rep < 3 && !cols; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    CK(hipMemcpyAsync(out, src, (size_t)n * d * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep) printf("copy  %d d2d rows %lld dim %d: %.3f ms, %.2f TB/s of %.1f GB moved\n", MI_INGEST_PROBE, (long long)n, d, ms, 2.0 * n * d * 4 / 1e9 / ms, 2.0 * n * d * 4 / 1e9);
   }
   mi::RowStat h;
   CK(hipMemcpy(&h, rs + 5, sizeof(h), hipMemcpyDeviceToHost));

@@ -25,7 +25,7 @@ fi
 if st 2; then
 for v in "sync:--async-tail 0" "q1:--queries 1" "q70:--queries 70" "bf16:--image-dtype bf16" "aqe:--with-aqe" "aqe_rparis:--workload rparis6k+1m --with-aqe" "10m:--workload 10m --steps 10 --warmup 2"; do
   name=${v%%:*}; args=${v#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_${name}_trace -- python3 bench.py --scale-10m off --no-cpu-baseline $args > $o/${tag}_${name}_bench.json 2> $o/${tag}_${name}.err || echo "$name failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_${name}_trace -- python3 bench.py --scale-10m off --extra-blocks off --no-cpu-baseline $args > $o/${tag}_${name}_bench.json 2> $o/${tag}_${name}.err || echo "$name failed"
   echo "$name done"
 done
 fi
