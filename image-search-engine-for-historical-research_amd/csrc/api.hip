@@ -9,13 +9,13 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -1248,75 +1248,153 @@ struct BalanceTrailer {        // optional, after the last section
   float w[8];
   uint64_t sum;                // FNV-1a of the bytes above
 };
-struct PinnedPair {
-  static constexpr size_t CHUNK = (size_t)32 << 20;
-  void* buf[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  hipStream_t s = nullptr;
-  int init() {
-    for (int i = 0; i < 2; ++i) {
-      HIPC(hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault));
-      HIPC(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    }
-    HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    return MI_OK;
-  }
-  ~PinnedPair() {
-    for (int i = 0; i < 2; ++i) {
-      if (buf[i]) (void)hipHostFree(buf[i]);
-      if (ev[i]) (void)hipEventDestroy(ev[i]);
-    }
-    if (s) (void)hipStreamDestroy(s);
-  }
+struct FileSegment {
+  size_t file_off;
+  char* dev;
+  size_t bytes;
 };
-// device -> file: the D2H copy of chunk c + 1 runs while chunk c is written
-int copy_dev_to_file(PinnedPair& pp, FILE* f, const void* dev, size_t bytes) {
-  const size_t nchunks = (bytes + PinnedPair::CHUNK - 1) / PinnedPair::CHUNK;
-  auto start = [&](size_t c) -> int {
-    const size_t off = c * PinnedPair::CHUNK, len = std::min(PinnedPair::CHUNK, bytes - off);
-    HIPC(hipMemcpyAsync(pp.buf[c & 1], (const char*)dev + off, len, hipMemcpyDeviceToHost, pp.s));
-    HIPC(hipEventRecord(pp.ev[c & 1], pp.s));
-    return MI_OK;
-  };
-  int rc;
-  if (nchunks && (rc = start(0)) != MI_OK) return rc;
-  for (size_t c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks && (rc = start(c + 1)) != MI_OK) return rc;
-    HIPC(hipEventSynchronize(pp.ev[c & 1]));
-    const size_t len = std::min(PinnedPair::CHUNK, bytes - c * PinnedPair::CHUNK);
-    if (fwrite(pp.buf[c & 1], 1, len, f) != len) return fail(MI_ERR_IO, "short write");
+// device -> file: 32 MiB chunks cross PCIe into a ring of eight pinned buffers; four writer threads pwrite() each chunk at its
+// place as soon as its copy is done.  (Measured: 12 GB reach the page cache at 11 GB/s with one writer and with four -- the
+// kernel's dirty-page throttling, not the copy; callers write the file behind their call, nnsearch._save_behind.)
+int copy_dev_to_file_parallel(int fd, int device, const FileSegment* seg, int nseg) {
+  constexpr size_t CH = (size_t)32 << 20;
+  constexpr int WRITERS = 4, RING = 8;
+  struct Chunk { size_t off; char* dev; size_t len; };
+  std::vector<Chunk> ch;
+  for (int i = 0; i < nseg; ++i)
+    for (size_t o = 0; o < seg[i].bytes; o += CH) ch.push_back({seg[i].file_off + o, seg[i].dev + o, std::min(CH, seg[i].bytes - o)});
+  const size_t n = ch.size();
+  if (n == 0) return MI_OK;
+  void* buf[RING] = {};
+  hipEvent_t ev[RING] = {};
+  hipStream_t s = nullptr;
+  hipError_t he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  const int ring = (int)std::min<size_t>(RING, n);
+  for (int i = 0; i < ring && he == hipSuccess; ++i) {
+    he = hipHostMalloc(&buf[i], CH, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
   }
+  std::vector<std::atomic<int>> issued(n), written(n);    // the copy of chunk i is enqueued / chunk i is in the file
+  for (size_t i = 0; i < n; ++i) issued[i] = 0, written[i] = 0;
+  std::atomic<size_t> next{0};
+  std::atomic<int> io_err{0}, hip_err{0}, stop{0};
+  std::vector<std::thread> writers;
+  if (he == hipSuccess)
+    for (int t = 0; t < std::min<int>(WRITERS, ring); ++t)
+      writers.emplace_back([&] {
+        (void)hipSetDevice(device);
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= n) return;
+          while (!issued[i].load(std::memory_order_acquire)) {
+            if (stop.load()) return;
+            std::this_thread::yield();
+          }
+          if (hipEventSynchronize(ev[i % ring]) != hipSuccess) hip_err = 1;
+          size_t put = 0;
+          while (put < ch[i].len && !hip_err.load() && !io_err.load()) {
+            const ssize_t r = pwrite(fd, (const char*)buf[i % ring] + put, ch[i].len - put, (off_t)(ch[i].off + put));
+            if (r <= 0) {
+              io_err = 1;
+              break;
+            }
+            put += (size_t)r;
+          }
+          written[i].store(1, std::memory_order_release);
+        }
+      });
+  for (size_t i = 0; i < n && he == hipSuccess && !io_err.load() && !hip_err.load(); ++i) {
+    if (i >= (size_t)ring)
+      while (!written[i - ring].load(std::memory_order_acquire)) std::this_thread::yield();   // its buffer is free again
+    he = hipMemcpyAsync(buf[i % ring], ch[i].dev, ch[i].len, hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipEventRecord(ev[i % ring], s);
+    if (he == hipSuccess) issued[i].store(1, std::memory_order_release);
+  }
+  if (he != hipSuccess || io_err.load() || hip_err.load()) stop = 1;
+  for (auto& t : writers) t.join();
+  if (s) (void)hipStreamSynchronize(s);
+  for (int i = 0; i < ring; ++i) {
+    if (buf[i]) (void)hipHostFree(buf[i]);
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (he != hipSuccess || hip_err.load()) return fail(MI_ERR_HIP, std::string("device -> gallery file: ") + hipGetErrorString(he));
+  if (io_err.load()) return fail(MI_ERR_IO, "short write");
   return MI_OK;
 }
-// file -> device through a read-only mapping of the file: the runtime copies from the mapped (page-cache) pages like from any
-// pageable array -- 50+ GB/s on these hosts when the file is cached, against 17 GB/s for fread into a pinned buffer (one kernel
-// memcpy stream) -- in 256 MiB pieces so that a file larger than memory never has to be resident at once.  false = no mapping
-// (special files, exotic file systems): the caller falls back to the read pipeline below.
-bool copy_mapped_to_dev(int fd, size_t file_off, void* dev, size_t bytes) {
-  if (bytes == 0) return true;
-  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
-  const size_t map_off = file_off / page * page, lead = file_off - map_off;
-  void* m = mmap(nullptr, bytes + lead, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, (off_t)map_off);
-  if (m == MAP_FAILED) return false;
-  (void)madvise(m, bytes + lead, MADV_SEQUENTIAL);
-  bool ok = true;
-  const size_t piece = (size_t)256 << 20;
-  for (size_t o = 0; o < bytes && ok; o += piece)
-    ok = hipMemcpy((char*)dev + o, (const char*)m + lead + o, std::min(piece, bytes - o), hipMemcpyHostToDevice) == hipSuccess;
-  (void)munmap(m, bytes + lead);
-  return ok;
-}
-// file -> device: chunk c + 1 is read from the file while chunk c crosses PCIe
-int copy_file_to_dev(PinnedPair& pp, FILE* f, void* dev, size_t bytes) {
-  const size_t nchunks = (bytes + PinnedPair::CHUNK - 1) / PinnedPair::CHUNK;
-  for (size_t c = 0; c < nchunks; ++c) {
-    const size_t off = c * PinnedPair::CHUNK, len = std::min(PinnedPair::CHUNK, bytes - off);
-    if (c >= 2) HIPC(hipEventSynchronize(pp.ev[c & 1]));        // the copy that last used this buffer is done
-    if (fread(pp.buf[c & 1], 1, len, f) != len) return fail(MI_ERR_IO, "short read (truncated gallery file)");
-    HIPC(hipMemcpyAsync((char*)dev + off, pp.buf[c & 1], len, hipMemcpyHostToDevice, pp.s));
-    HIPC(hipEventRecord(pp.ev[c & 1], pp.s));
+// file -> device: four reader threads pread() 32 MiB chunks into a ring of eight pinned buffers, every chunk crosses PCIe as soon
+// as it is read.  A cached 12 GB file reaches the device at the pinned H2D rate of the box this way (55 GB/s; one reader and
+// two buffers: 17 GB/s, one kernel memcpy stream; a read-only mapping copied by the runtime as pageable memory: 30-42 GB/s incl.
+// the unmapping -- scripts/mapload_probe.hip, profiles/r05r_mapload_probe.txt).  Nothing the size of the file is resident.
+int copy_file_to_dev_parallel(int fd, const FileSegment* seg, int nseg) {
+  constexpr size_t CH = (size_t)32 << 20;
+  constexpr int READERS = 4, RING = 8;
+  struct Chunk { size_t off; char* dev; size_t len; };
+  std::vector<Chunk> ch;
+  for (int i = 0; i < nseg; ++i)
+    for (size_t o = 0; o < seg[i].bytes; o += CH) ch.push_back({seg[i].file_off + o, seg[i].dev + o, std::min(CH, seg[i].bytes - o)});
+  const size_t n = ch.size();
+  if (n == 0) return MI_OK;
+  void* buf[RING] = {};
+  hipEvent_t ev[RING] = {};
+  hipStream_t s = nullptr;
+  hipError_t he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  const int ring = (int)std::min<size_t>(RING, n);
+  for (int i = 0; i < ring && he == hipSuccess; ++i) {
+    he = hipHostMalloc(&buf[i], CH, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
   }
-  HIPC(hipStreamSynchronize(pp.s));
+  std::vector<std::atomic<int>> filled(n), freed(n);      // chunk i is in its buffer / its copy has left the buffer
+  for (size_t i = 0; i < n; ++i) filled[i] = 0, freed[i] = 0;
+  std::atomic<size_t> next{0};
+  std::atomic<int> io_err{0}, stop{0};
+  std::vector<std::thread> readers;
+  if (he == hipSuccess)
+    for (int t = 0; t < std::min<int>(READERS, ring); ++t)
+      readers.emplace_back([&] {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= n) return;
+          if (i >= (size_t)ring)
+            while (!freed[i - ring].load(std::memory_order_acquire)) {
+              if (stop.load()) return;
+              std::this_thread::yield();
+            }
+          size_t got = 0;
+          while (got < ch[i].len && !stop.load()) {
+            const ssize_t r = pread(fd, (char*)buf[i % ring] + got, ch[i].len - got, (off_t)(ch[i].off + got));
+            if (r <= 0) {
+              io_err = 1;
+              break;
+            }
+            got += (size_t)r;
+          }
+          filled[i].store(1, std::memory_order_release);
+        }
+      });
+  size_t released = 0;
+  for (size_t i = 0; i < n && he == hipSuccess && !io_err.load(); ++i) {
+    while (!filled[i].load(std::memory_order_acquire)) std::this_thread::yield();
+    if (io_err.load()) break;
+    he = hipMemcpyAsync(ch[i].dev, buf[i % ring], ch[i].len, hipMemcpyHostToDevice, s);
+    if (he == hipSuccess) he = hipEventRecord(ev[i % ring], s);
+    // hand buffers back in order once their copies are done; keep half a ring of copies in flight
+    while (he == hipSuccess && released <= i && (i - released >= (size_t)ring / 2 || i + 1 == n)) {
+      he = hipEventSynchronize(ev[released % ring]);
+      freed[released].store(1, std::memory_order_release);
+      ++released;
+    }
+  }
+  stop = (he != hipSuccess || io_err.load()) ? 1 : 0;
+  for (auto& t : readers) t.join();
+  if (s) (void)hipStreamSynchronize(s);
+  for (int i = 0; i < ring; ++i) {
+    if (buf[i]) (void)hipHostFree(buf[i]);
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (he != hipSuccess) return fail(MI_ERR_HIP, std::string("gallery file -> device: ") + hipGetErrorString(he));
+  if (io_err.load()) return fail(MI_ERR_IO, "short read (truncated gallery file)");
   return MI_OK;
 }
 int section_sums(const mi_gallery* g, uint64_t out[3]) {
@@ -1351,14 +1429,19 @@ int mi_gallery_save(const mi_gallery* g, const char* path) {
   int rc = section_sums(g, h.section_sum);
   if (rc != MI_OK) return rc;
   h.header_sum = host_sum(&h, offsetof(FileHeader, header_sum));
-  PinnedPair pp;
-  if ((rc = pp.init()) != MI_OK) return rc;
   FILE* f = fopen(path, "wb");
   if (!f) return fail(MI_ERR_IO, std::string("cannot open for writing: ") + path);
-  if (fwrite(&h, sizeof h, 1, f) != 1) rc = fail(MI_ERR_IO, "short write");
-  if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->gal_f32, (size_t)g->n * g->dp * 4);
-  if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->gal_img, (size_t)g->npad * g->dp * 2);
-  if (rc == MI_OK) rc = copy_dev_to_file(pp, f, g->rowstat, (size_t)g->npad * sizeof(RowStat));
+  if (fwrite(&h, sizeof h, 1, f) != 1 || fflush(f) != 0) rc = fail(MI_ERR_IO, "short write");
+  const size_t sec[3] = {(size_t)g->n * g->dp * 4, (size_t)g->npad * g->dp * 2, (size_t)g->npad * sizeof(RowStat)};
+  char* src[3] = {(char*)g->gal_f32, (char*)g->gal_img, (char*)g->rowstat};
+  FileSegment seg[3];
+  size_t off = sizeof h;
+  for (int i = 0; i < 3; ++i) {
+    seg[i] = {off, src[i], sec[i]};
+    off += sec[i];
+  }
+  if (rc == MI_OK) rc = copy_dev_to_file_parallel(fileno(f), g->device, seg, 3);
+  if (rc == MI_OK && fseeko(f, (off_t)off, SEEK_SET) != 0) rc = fail(MI_ERR_IO, "seek failed");
   if (rc == MI_OK) {
     // optional trailer: the XCD shares of the tile kernel as measured so far (or as loaded), so that `load -> first search`
     // starts calibrated; files without it (no large launch has run yet) are complete
@@ -1402,22 +1485,14 @@ int mi_gallery_load(const char* path, int device, mi_gallery** out) {
   if (rc == MI_OK) {
     const size_t sec[3] = {(size_t)g->n * g->dp * 4, (size_t)g->npad * g->dp * 2, (size_t)g->npad * sizeof(RowStat)};
     void* dst[3] = {g->gal_f32, g->gal_img, g->rowstat};
+    FileSegment seg[3];
     size_t off = sizeof(FileHeader);
-    struct stat stt;
-    bool mapped = fstat(fileno(f), &stt) == 0 && (size_t)stt.st_size >= off + sec[0] + sec[1] + sec[2];
-    for (int i = 0; i < 3 && mapped; ++i) {
-      mapped = copy_mapped_to_dev(fileno(f), off, dst[i], sec[i]);
+    for (int i = 0; i < 3; ++i) {
+      seg[i] = {off, (char*)dst[i], sec[i]};
       off += sec[i];
     }
-    if (mapped) {
-      if (fseeko(f, (off_t)off, SEEK_SET) != 0) rc = fail(MI_ERR_IO, "seek failed");
-    } else {
-      // (also the path of a truncated file: the reads below report it)
-      PinnedPair pp;
-      rc = pp.init();
-      if (rc == MI_OK && fseeko(f, (off_t)sizeof(FileHeader), SEEK_SET) != 0) rc = fail(MI_ERR_IO, "seek failed");
-      for (int i = 0; i < 3 && rc == MI_OK; ++i) rc = copy_file_to_dev(pp, f, dst[i], sec[i]);
-    }
+    rc = copy_file_to_dev_parallel(fileno(f), seg, 3);
+    if (rc == MI_OK && fseeko(f, (off_t)off, SEEK_SET) != 0) rc = fail(MI_ERR_IO, "seek failed");
   }
   if (rc == MI_OK) {
     BalanceTrailer tr{};

@@ -18,8 +18,10 @@ size = os.path.getsize(path)
 g.close()
 t0 = time.time(); h = _lib.Gallery.load(path); t_load = time.time() - t0      # page cache warm (just written)
 h.close()
+t0 = time.time(); h = _lib.Gallery.load(path); t_load = min(t_load, time.time() - t0)
+h.close()
 os.remove(path)
 print(json.dumps({"rows": n, "dim": d, "file_bytes": size, "save_s": round(t_save, 3), "save_GBps": round(size / t_save / 1e9, 2),
                   "load_s": round(t_load, 3), "load_GBps": round(size / t_load / 1e9, 2),
-                  "note": "load = fread into 2 x 32 MiB pinned buffers overlapped with hipMemcpyAsync + device-side section "
+                  "note": "load = 4 reader threads pread() into a ring of 8 pinned 32 MiB buffers, hipMemcpyAsync per chunk + device-side section "
                           "checksums; file in the page cache"}))
