@@ -17,10 +17,10 @@ for f in ("timeline_full.txt", "timeline_s8.txt", "rank_all.txt", "host_api.txt"
           "diffusion_refsize.txt", "mfma_probe.txt", "kbench.txt", "rehearse2.txt", "rehearse4.txt", "ladder_probe.txt",
           "shard_model.txt", "protocol_rccl1.txt", "layout_model.txt", "rehearse4_rows_pipelined.txt", "tile4_probe.txt",
           "kbench_thr.txt", "bare_gpus2.txt", "bare_gpus4.txt", "tailbench.txt", "ab_r02.txt", "sweep_seeds.txt", "graph_replay.txt", "timeline_q1.txt", "timeline_q70.txt", "kbench_pmc.txt", "gap_probe.txt",
-          "first_launches.txt", "shard_model_10m.txt"):
+          "first_launches.txt", "shard_model_10m.txt", "ingestbench.txt", "ingest_pmc.txt"):
     src = os.path.join(go, f"{tag}_{f}")
     if os.path.exists(src) and os.path.getsize(src) < 200000:
         text = open(src, errors="replace").read()
         text = "\n".join(l for l in text.splitlines() if "amdgpu.ids" not in l and "at::native" not in l)
         open(os.path.join(pr, f"{tag}_{f}"), "w").write(text + "\n")
-print(sorted(os.listdir(pr)))
+print(sorted(f for f in os.listdir(pr) if f.startswith(tag + "_")))
