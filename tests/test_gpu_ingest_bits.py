@@ -100,6 +100,7 @@ def test_layouts_blocks_and_odd_shapes_give_the_same_rows(seed):
     import torch
     from isehr_amd import _lib
     from isehr_amd.synth import synth_rows
+    seed += 100 * int(os.environ.get("ISEHR_SWEEP_SEED", "0"))           # further seeds: ISEHR_SWEEP_SEED=n python -m pytest ...
     rng = np.random.default_rng(1000 + seed)
     d = int(rng.choice([2048, 2048, 2048, 64, 100, 320, 2500]))
     n = int(rng.choice([1, 3, 15, 16, 17, 255, 256, 257, 1000, 4099, 16385, 40001]))
