@@ -1,9 +1,9 @@
-// How fast can a 12 GB file that sits in the page cache reach the device?  (The prepared-gallery loader, csrc/api.hip
-// copy_mapped_to_dev: 25 GB/s in round 5's record against 55 GB/s of pinned H2D.)  Variants, same file, same device buffer:
-//   a  mmap(MAP_POPULATE) of everything, then hipMemcpy in 256 MiB pieces            (the loader as it is)
+// How fast can a 12 GB file that sits in the page cache reach the device?  (The prepared-gallery loader of csrc/api.hip went
+// through a mapping until round 5: 25 GB/s against 55 GB/s of pinned H2D; it is variant d now.)  Same file, same device buffer:
+//   a  mmap(MAP_POPULATE) of everything, then hipMemcpy in 256 MiB pieces            (the loader as it was)
 //   b  mmap without populate, T threads populate pieces ahead (MADV_POPULATE_READ), hipMemcpy of a piece when it is populated
 //   c  mmap without populate, hipMemcpy straight away (the runtime faults the pages in)
-//   d  T threads pread() pieces into a ring of pinned buffers, hipMemcpyAsync per piece
+//   d  T threads pread() pieces into a ring of pinned buffers, hipMemcpyAsync per piece   (copy_file_to_dev_parallel)
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 scripts/mapload_probe.hip -o build/mapload_probe -lpthread
 //   mapload_probe <file> [GiB to write if the file does not exist]
 #include <hip/hip_runtime.h>
