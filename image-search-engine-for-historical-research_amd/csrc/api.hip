@@ -53,6 +53,12 @@ struct SpareBuffers {
 };
 static std::mutex g_spare_mu;
 static SpareBuffers g_spare;
+struct SpareArena {           // the search workspace of the handle destroyed last (one carved allocation, ~200 MB)
+  int device = -1;
+  size_t bytes = 0;
+  void* p = nullptr;
+};
+static SpareArena g_spare_ws;
 static std::atomic<int> g_keep_buffers{1};
 static const size_t SPARE_MAX_BYTES = (size_t)16 << 30;
 static void spare_release_locked() {
@@ -66,6 +72,15 @@ static void spare_release_locked() {
   (void)hipFree(g_spare.gstat3);
   (void)hipSetDevice(cur);
   g_spare = SpareBuffers();
+}
+static void spare_ws_release_locked() {
+  if (!g_spare_ws.p) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  (void)hipSetDevice(g_spare_ws.device);
+  (void)hipFree(g_spare_ws.p);
+  (void)hipSetDevice(cur);
+  g_spare_ws = SpareArena();
 }
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -115,6 +130,8 @@ struct Workspace {
   XccBalance* bal = nullptr;      // measured XCD shares of the tile kernel (device memory)
   uint32_t rec_cap = 4096, nseg = 0;
   std::vector<void*> allocs;
+  size_t arena_bytes = 0;   // allocs[0] is one carved allocation of this size on device arena_device (ws_ensure)
+  int arena_device = -1;
 };
 struct TmpAlloc {
   std::vector<void*> v;
@@ -220,17 +237,15 @@ struct mi_gallery {
 };
 
 static int ws_free(Workspace& ws) {
-  for (void* p : ws.allocs) (void)hipFree(p);
+  if (ws.allocs.size() == 1 && ws.arena_bytes && g_keep_buffers.load()) {
+    // (callers have drained every stream that used the workspace)
+    std::lock_guard<std::mutex> lock(g_spare_mu);
+    spare_ws_release_locked();
+    g_spare_ws.device = ws.arena_device, g_spare_ws.bytes = ws.arena_bytes, g_spare_ws.p = ws.allocs[0];
+  } else {
+    for (void* p : ws.allocs) (void)hipFree(p);
+  }
   ws = Workspace();
-  return MI_OK;
-}
-
-template <typename T>
-static int dev_alloc(Workspace& ws, T** p, size_t count) {
-  void* v = nullptr;
-  HIPC(hipMalloc(&v, count * sizeof(T) + 256));
-  ws.allocs.push_back(v);
-  *p = reinterpret_cast<T*>(v);
   return MI_OK;
 }
 
@@ -256,54 +271,76 @@ static int ws_ensure(mi_gallery* g, int32_t k) {
   ws.kcap = kcap;
   ws.cap = g->surv_cap;
   ws.rcap = g->rescore_cap;
-  int rc;
-#define A(ptr, count) \
-  if ((rc = dev_alloc(ws, &ws.ptr, (count))) != MI_OK) return rc;
-  A(q_f32, (size_t)QB * g->dp);
-  {
-    __hip_bfloat16* tmp = nullptr;
-    if ((rc = dev_alloc(ws, &tmp, (size_t)QB * g->dp)) != MI_OK) return rc;
-    ws.q_img = tmp;
-  }
-  A(q_stat, QB);
-  A(thr, QB);
-  A(margin, QB);
-  A(thr2, QB);
-  A(qflag, QB);
-  A(lad_tc, QB);
-  A(lad_pack, QB);
-  A(lad_cnt, QB);
-  A(cnt, (size_t)QB * CNT_STRIDE);
-  A(surv, (size_t)QB * ws.cap);
-  A(flags, 4);
-  A(repair, 4);
-  A(topvals, (size_t)QB * kcap);
-  A(L, QB);
-  A(cand_rows, (size_t)QB * ws.rcap);
-  A(cand_cnt, QB);
-  A(cand_score, (size_t)QB * ws.rcap);
-  A(stats2, 3 * (size_t)QB);     // per query: (survivors, candidates) accumulators, then [2 QB ..) in-kernel repairs -- one writer each, no atomics
+  // ONE allocation, carved: ~30 hipMalloc / hipFree pairs per handle cost a caller that prepares a gallery per call (create,
+  // search, destroy) 4-5 ms, several times its search.  Two passes over the same list: sizes first, pointers second.  The
+  // buffers that start as zeros come first, so one memset covers them.
   ws.rec_cap = 4096;          // records per wave segment and launch (K = 1000 at 1M rows needs ~1800)
   ws.nseg = gemm_select_grid() * 8;
-  A(rec, (size_t)ws.nseg * ws.rec_cap);
-  A(rec_cnt, ws.nseg);
-  A(dbg, (size_t)ws.nseg * 8);
-  A(bal, 1);
+  char* base = nullptr;
+  size_t total = 0, zeroed = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    total = 0;
+    auto carve = [&](auto** ptr, size_t count) {
+      using T = typename std::remove_pointer<typename std::remove_pointer<decltype(ptr)>::type>::type;
+      if (base) *ptr = reinterpret_cast<T*>(base + total);
+      total += (count * sizeof(T) + 511) / 256 * 256;
+    };
+#define A(ptr, count) carve(&ws.ptr, (count))
+    A(flags, 4);
+    A(repair, 4);
+    A(stats2, 3 * (size_t)QB);     // per query: (survivors, candidates) accumulators, then [2 QB ..) in-kernel repairs -- one writer each, no atomics
+    A(dbg, (size_t)ws.nseg * 8);
+    A(cand_cnt, QB);
+    A(cand_cnt_set[1], QB);
+    zeroed = total;
+    A(q_f32, (size_t)QB * g->dp);
+    {
+      __hip_bfloat16* tmp = nullptr;
+      carve(&tmp, (size_t)QB * g->dp);
+      ws.q_img = tmp;
+    }
+    A(q_stat, QB);
+    A(thr, QB);
+    A(margin, QB);
+    A(thr2, QB);
+    A(qflag, QB);
+    A(lad_tc, QB);
+    A(lad_pack, QB);
+    A(lad_cnt, QB);
+    A(cnt, (size_t)QB * CNT_STRIDE);
+    A(surv, (size_t)QB * ws.cap);
+    A(topvals, (size_t)QB * kcap);
+    A(L, QB);
+    A(cand_rows, (size_t)QB * ws.rcap);
+    A(cand_score, (size_t)QB * ws.rcap);
+    A(rec, (size_t)ws.nseg * ws.rec_cap);
+    A(rec_cnt, ws.nseg);
+    A(bal, 1);
+    A(q_f32_set[1], (size_t)QB * g->dp);
+    A(cand_rows_set[1], (size_t)QB * ws.rcap);
+    A(cand_score_set[1], (size_t)QB * ws.rcap);
+#undef A
+    if (pass == 0) {
+      void* v = nullptr;
+      {
+        std::lock_guard<std::mutex> lock(g_spare_mu);
+        if (g_spare_ws.p && g_spare_ws.device == g->device && g_spare_ws.bytes == total) {
+          v = g_spare_ws.p;
+          g_spare_ws = SpareArena();
+        }
+      }
+      if (!v) HIPC(hipMalloc(&v, total));
+      ws.allocs.push_back(v);
+      ws.arena_bytes = total;
+      ws.arena_device = g->device;
+      base = reinterpret_cast<char*>(v);
+    }
+  }
   ws.q_f32_set[0] = ws.q_f32;
   ws.cand_rows_set[0] = ws.cand_rows;
   ws.cand_cnt_set[0] = ws.cand_cnt;
   ws.cand_score_set[0] = ws.cand_score;
-  A(q_f32_set[1], (size_t)QB * g->dp);
-  A(cand_rows_set[1], (size_t)QB * ws.rcap);
-  A(cand_cnt_set[1], QB);
-  A(cand_score_set[1], (size_t)QB * ws.rcap);
-#undef A
-  HIPC(hipMemset(ws.flags, 0, 16));
-  HIPC(hipMemset(ws.repair, 0, 16));
-  HIPC(hipMemset(ws.stats2, 0, 3 * (size_t)QB * 8));
-  HIPC(hipMemset(ws.dbg, 0, (size_t)ws.nseg * 8 * 8));
-  HIPC(hipMemset(ws.cand_cnt, 0, (size_t)QB * 4));
-  HIPC(hipMemset(ws.cand_cnt_set[1], 0, (size_t)QB * 4));
+  HIPC(hipMemset(base, 0, zeroed));
   {
     // the XCD shares start from what is known: the file's, else this process's last ones on the device, else an even split
     XccBalance hb;
@@ -2640,6 +2677,7 @@ int mi_set_global_option(const char* name, double value) {
     if (value == 0) {
       std::lock_guard<std::mutex> lock(g_spare_mu);
       spare_release_locked();
+      spare_ws_release_locked();
     }
   }
   else return fail(MI_ERR_INVALID, "unknown global option: " + n);

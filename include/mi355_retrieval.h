@@ -335,10 +335,11 @@ int mi_search_flags(mi_gallery* g, uint32_t* out_flags);
  * blocks of ~32 MiB copied by the runtime straight from the caller's pageable array into two alternating device blocks, the copy
  * of block i + 1 under the ingest of block i, no staging allocation the size of the gallery; 0 = one copy of the whole array into
  * a same-size staging buffer, then one ingest (rounds 1-4).  Both reach 0.96 of the pinned H2D rate (profiles/r05f_*).
- * "keep_buffers": 1 (default) = mi_gallery_destroy keeps the buffers of a gallery of up to 16 GiB in one spare slot per process
- * and the next gallery of exactly the same sizes on the same device takes them instead of allocating: a caller that prepares a
- * gallery per call (create, search, destroy: a stateless matching_<method>, src/utils/nnsearch.py:687-706) stops paying 1-6 ms of
- * hipMalloc / hipFree per 12 GB; 0 = free the spare now and keep nothing. */
+ * "keep_buffers": 1 (default) = mi_gallery_destroy keeps the buffers of a gallery of up to 16 GiB and its search workspace (one
+ * carved allocation of ~200 MB) in one spare slot each per process, and the next gallery of exactly the same sizes on the same
+ * device takes them instead of allocating: a caller that prepares a gallery per call (create, search, destroy: a stateless
+ * matching_<method>, src/utils/nnsearch.py:687-706) stops paying 1-6 ms of hipMalloc / hipFree per 12 GB and ~4 ms for the
+ * workspace; 0 = free the spares now and keep nothing. */
 int mi_set_global_option(const char* name, double value);
 
 /* The XCD shares of the tile kernel (relative speeds of the eight XCD labels, summing to 1) as the handle's launches have left
