@@ -391,6 +391,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
     alloc_s = None
     ingest_kernel_s = None
     ingest_launch_ms = None
+    stateless_call_s = None
     t0 = time.time()
     if warm_ingest or (hi - lo) * d * 4 <= 16 << 30:
         gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
@@ -424,6 +425,22 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
             g2.close()
         # and the device work alone: the same rows appended to a gallery whose buffers exist already (what hipMalloc costs
         # differs between boxes and states of the driver by a factor of ten; the kernels do not)
+        # -- what a stateless caller's timer spans (matching_L2 normalises the gallery inside every call): create + ONE batch +
+        # destroy on the resident rows, wall clock, device-synchronised, best of three
+        qtmp = torch.empty((nq_job // gq, d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(qtmp.data_ptr(), args.seed + 1, 0, qtmp.shape[0], d, stream)
+        itmp = torch.empty((qtmp.shape[0], args.topk), dtype=torch.int64, device=dev)
+        stmp = torch.empty((qtmp.shape[0], args.topk), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            t0 = time.time()
+            g2 = _lib.Gallery.from_device_ptr(raw.data_ptr(), hi - lo, d, norm_mode=_lib.NORM_L2, device=job.dev_index,
+                                              row_offset=lo)
+            g2.search_device(qtmp.data_ptr(), qtmp.shape[0], args.topk, itmp.data_ptr(), stmp.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            g2.close()
+            stateless_call_s = min(stateless_call_s or 1e9, time.time() - t0)
+        del qtmp, itmp, stmp
         # -- the same rows appended to three galleries back to back, each launch between HIP events on the launch stream.  The
         # same launch takes 3.5-4.1 ms on one box depending on where the driver put the buffers (scripts/ingest_context_probe.py):
         # the three destinations are three placements; `ingest_kernel_s` is their median
@@ -608,7 +625,7 @@ def run_workload(job, n_total, nq_job, image_dtype, steps, warmup, layout, with_
 
     res = dict(n_total=n_total, nq_job=nq_job, nq=nq, gq=gq, gs=gs, lo=lo, hi=hi, elapsed=elapsed, steps=steps, st=st,
                job_steps=job_steps,
-               ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, ingest_launch_ms=ingest_launch_ms, alloc_s=alloc_s, worst=worst,
+               ingest_s=ingest_s, ingest_first_s=ingest_first_s, ingest_kernel_s=ingest_kernel_s, ingest_launch_ms=ingest_launch_ms, stateless_call_s=stateless_call_s, alloc_s=alloc_s, worst=worst,
                use_stream=use_stream, launch_ms=[float(v) for v in launch_ms], dense_check=dense_check,
                protocol=sg._protocol, pipelined=pipelined, image_dtype=image_dtype, graph=bool(graph))
 
@@ -1243,6 +1260,9 @@ def main():
                            "ingest_kernel_s": round(res["ingest_kernel_s"], 5) if res["ingest_kernel_s"] else None,
                            "ingest_launch_ms": ([round(x, 3) for x in res["ingest_launch_ms"]] if res["ingest_launch_ms"] else None),
                            "queries_per_s_incl_gallery_ingest_per_call_of_one_batch": nq / (ms_step * 1e-3 + res["ingest_s"]),
+                           # measured, not composed: create + one batch (first search of the handle) + destroy, wall clock
+                           "stateless_call_s": round(res["stateless_call_s"], 5) if res["stateless_call_s"] else None,
+                           "queries_per_s_of_one_stateless_call": (nq / res["stateless_call_s"]) if res["stateless_call_s"] else None,
                            "candidates_per_query": st["candidates"] / max(1, st["queries"]),
                            "survivors_per_query": st["survivors"] / max(1, st["queries"]),
                            "score_check": ("16 queries x top-%d re-computed in float64: max |d| %.2e; completeness: %s"

@@ -58,6 +58,9 @@ def test_one_gpu_line_has_the_contract_fields():
         assert key in out, key
     assert out["n_gpus"] == 1 and out["config"]["rccl_ranks"] == 1
     assert out["config"]["ingest_s"] > 0 and out["config"]["ingest_first_s"] > 0
+    # create + one batch + destroy, measured: never less than the ingest alone, and three launch times of the ingest kernel
+    assert out["config"]["stateless_call_s"] > out["config"]["ingest_kernel_s"] > 0
+    assert len(out["config"]["ingest_launch_ms"]) == 3 and out["config"]["queries_per_s_of_one_stateless_call"] > 0
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["cpu_model"]
     pts = {(p["queries"], p["threads"] == 1) for p in cb["blas"]["points"]}
