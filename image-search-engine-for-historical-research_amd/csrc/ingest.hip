@@ -639,11 +639,12 @@ __global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const In
 // requests per byte, 5.2 ms.)
 // LDS row-major with the column index XOR-ed by 8 * (row quad): the transposing 4-byte writes of a loader wave -- 4 row quads x
 // 8 columns per 32 lanes -- then hit 32 different banks, and the 16-byte reads of the consumers stay aligned permutations.
-template <typename InT>
+template <typename InT, bool COOP>
 __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict__ src, int64_t n, int64_t cs, int norm_mode,
                                                           float* __restrict__ out_f32, uint16_t* __restrict__ out_img,
                                                           int img_f16, RowStat* __restrict__ rowstat, int64_t nrows,
-                                                          int64_t row_base, int coop) {
+                                                          int64_t row_base) {
+  constexpr bool coop = COOP;                                    // (row_base % 4 == 0: the image leaves through the workgroup)
   constexpr int D = 2048, PT = 8, NSL = D / SLICE_K;
   constexpr int R = 64 / (int)sizeof(InT);                       // rows of a panel: 16 (float32) / 8 (float64)
   constexpr int RQ = R / 4;                                      // row quads = runs of a panel: 4 / 2
@@ -993,14 +994,14 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     const int coop = row_base % 4 == 0;
     const unsigned grid = (unsigned)std::max<int64_t>(8, current_device_cus() / 8 * 8);      // one workgroup per CU, whole XCD labels
     const size_t lds = (size_t)128 * 1024 + 32 * 1024;
-#define MI_GC_LAUNCH(T)                                                                                                  \
+#define MI_GC_LAUNCH(T, C)                                                                                               \
   do {                                                                                                                  \
-    ensure_dynamic_lds((const void*)ingest_cols_kernel<T>, (int)lds);                                                   \
-    hipLaunchKernelGGL((ingest_cols_kernel<T>), dim3(grid), dim3(768), lds, stream, (const T*)src, n, cs, norm_mode,    \
-                       out_f32, (uint16_t*)out_img, img_f16, rowstat, npad, row_base, coop);                            \
+    ensure_dynamic_lds((const void*)ingest_cols_kernel<T, C>, (int)lds);                                                \
+    hipLaunchKernelGGL((ingest_cols_kernel<T, C>), dim3(grid), dim3(768), lds, stream, (const T*)src, n, cs, norm_mode, \
+                       out_f32, (uint16_t*)out_img, img_f16, rowstat, npad, row_base);                                  \
   } while (0)
-    if (dtype == 0) MI_GC_LAUNCH(float);
-    else MI_GC_LAUNCH(double);
+    if (dtype == 0) { if (coop) MI_GC_LAUNCH(float, true); else MI_GC_LAUNCH(float, false); }
+    else { if (coop) MI_GC_LAUNCH(double, true); else MI_GC_LAUNCH(double, false); }
 #undef MI_GC_LAUNCH
     return;
   }
