@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 // the one symbol ingest.hip takes from another translation unit of the library (select.hip).  The program is NOT linked
 // against libmi355_retrieval.so: with it loaded, the kernel of the same mangled name registered by the library is the one
@@ -77,6 +78,38 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  if (getenv("MI_INGEST_PADS")) {
+    // placement probe (row-major source): source | f32 rows | image inside ONE allocation, the two destinations shifted by the
+    // listed paddings -- does the launch time follow the distances between the three streams?  MI_INGEST_PADS="0,4096,65536,..."
+    const size_t sb = (size_t)n * d * 4, ib = (size_t)npad * d * 2, room = (size_t)64 << 20;
+    char* arena;
+    CK(hipMalloc((void**)&arena, 2 * sb + ib + 2 * room));
+    float* asrc = (float*)arena;
+    CK(hipMemcpy(asrc, src, sb, hipMemcpyDeviceToDevice));
+    std::vector<size_t> pads;
+    for (const char* p = getenv("MI_INGEST_PADS"); *p;) {
+      pads.push_back((size_t)atoll(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+    for (size_t p1 : pads)
+      for (size_t p2 : pads) {
+        float* aout = (float*)(arena + sb + p1);
+        uint16_t* aimg = (uint16_t*)(arena + sb + room + sb + p2);
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+          CK(hipEventRecord(e0, 0));
+          mi::launch_ingest(asrc, 0, n, d, d, 1, 1, aout, aimg, 1, rs, d, npad, 0, 0);
+          CK(hipEventRecord(e1, 0));
+          CK(hipEventSynchronize(e1));
+          float ms = 0;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep) best = std::min(best, ms);
+        }
+        printf("pads f32 rows +%zu image +%zu: %.3f ms\n", p1, p2, best);
+      }
+    return 0;
+  }
 #ifdef MI_INGEST_AB
   const int nrep = 13;
 #else
