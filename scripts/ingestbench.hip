@@ -84,6 +84,7 @@ int main(int argc, char** argv) {
     const size_t sb = (size_t)n * d * 4, ib = (size_t)npad * d * 2, room = (size_t)64 << 20;
     char* arena;
     CK(hipMalloc((void**)&arena, 2 * sb + ib + 2 * room));
+    printf("arena %p (offset in its GiB: %zu MiB)\n", (void*)arena, ((size_t)arena & (((size_t)1 << 30) - 1)) >> 20);
     float* asrc = (float*)arena;
     CK(hipMemcpy(asrc, src, sb, hipMemcpyDeviceToDevice));
     std::vector<size_t> pads;
