@@ -238,7 +238,9 @@ struct mi_gallery {
 
 static int ws_free(Workspace& ws) {
   if (ws.allocs.size() == 1 && ws.arena_bytes && g_keep_buffers.load()) {
-    // (callers have drained every stream that used the workspace)
+    // hipFree waits for the device before it gives memory back; so does this: the next owner clears the allocation, and
+    // launches of this handle on a caller's (non-blocking) stream may still be reading it when a workspace is re-built
+    (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lock(g_spare_mu);
     spare_ws_release_locked();
     g_spare_ws.device = ws.arena_device, g_spare_ws.bytes = ws.arena_bytes, g_spare_ws.p = ws.allocs[0];
