@@ -154,3 +154,23 @@ def test_bare_gpus_2_line_answers_layout_overlap_and_collective_cost():
     assert out["row_shard_1xN"]["parallelism"].startswith("row-shard x2")
     br = out["batch_replicas"]                                         # whole-gallery replicas, the batches dealt to the ranks
     assert br["value"] > 0 and br["steps"] == 3 and br["steps_of_rank_0"] == 2 and "mi_knn_dense64_search" in br["score_check"]
+
+
+def test_a_hang_in_the_pipelined_collectives_cannot_cost_the_synchronous_headline():
+    """The asynchronous all-gathers of search_stream have never run on real RCCL before the driver's multi-GPU run: they are
+    timed AFTER the headline line is out and under a deadline of their own.  Here rank 1 hangs inside that block (two ranks
+    on the shared GPU over gloo): the headline line is on stdout, parsable, the block says timeout, the job ends non-zero
+    within the deadline."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"ISEHR_DIST_BACKEND": "gloo", "ISEHR_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                "ISEHR_BENCH_TEST_HANG": "pipelined_collectives:1", "ISEHR_BENCH_DEADLINE_S": "25"})
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "200000", "--steps", "4",
+                        "--warmup", "2", "--no-cpu-baseline", "--layout", "1x2"], env=env, capture_output=True, text=True,
+                       timeout=400, cwd=ROOT)
+    took = time.time() - t0
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert r.returncode != 0 and took < 300, (r.returncode, took, r.stderr[-2000:])
+    assert lines and lines[0]["value"] > 0 and lines[0]["n_gpus"] == 2 and lines[0]["complete"] is False
+    assert lines[-1]["value"] == lines[0]["value"] and lines[-1]["pipelined_collectives"] == {"error": "timeout", "deadline_s": 25}
