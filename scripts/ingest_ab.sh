@@ -3,6 +3,9 @@
 # the driver put the buffers.)  Usage on the GPU box: bash scripts/ingest_ab.sh [process runs]
 set -e
 cd $GRAFT_REPO_ROOT
+# the baseline is a file you keep yourself (ab/ is git-ignored and travels with gpurun): e.g.
+#   git show <commit>:image-search-engine-for-historical-research_amd/csrc/ingest.hip > ab/ingest_old.hip
+[ -f ab/ingest_old.hip ] || { echo "ab/ingest_old.hip is missing (see the comment in this script)"; exit 2; }
 P=image-search-engine-for-historical-research_amd/build
 mkdir -p $P
 C=image-search-engine-for-historical-research_amd/csrc
