@@ -19,3 +19,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _keep_buffers_mode():
+    """ISEHR_KEEP_BUFFERS=0 python -m pytest -m gpu ...: the whole suite with the spare-buffer slots switched off (every handle
+    allocates and frees its own memory, as before round 5).  Default: the library's default (slots on)."""
+    mode = os.environ.get("ISEHR_KEEP_BUFFERS")
+    if mode is not None:
+        from isehr_amd import _lib
+        _lib.set_global_option("keep_buffers", int(mode))
+    yield
