@@ -45,7 +45,8 @@ PG_TIMEOUT_S = 90                # process-group timeout: a rank that never arri
 # (ISEHR_BENCH_DEADLINE_S overrides every one of them: tests)
 DEADLINES = {"headline": 420, "synchronous": 120, "cpu_baseline": 240, "row_shard_1xN": 150, "batch_replicas": 150,
              "scale_10m": 300, "map": 120, "q1": 60, "q70": 60, "aqe_rparis_1m": 150, "qge_small": 120, "dropin": 240,
-             "online": 60, "pipelined_collectives": 150, "shutdown": 60}
+             "online": 60, "pipelined_collectives": 150, "shutdown": 60, "qsweep": 90, "hard_data": 240, "whiten": 120,
+             "online_concurrent": 90}
 
 
 def parse():
@@ -110,6 +111,10 @@ def parse():
                          "(HBM-bound small batches on the resident gallery), `aqe_rparis_1m` (configs[4]), `qge_small` (the "
                          "N < 120 000 diffusion branch at rOxford5k size), `dropin` (matching_HIP on a host [D, N] array at "
                          "BASELINE size: what the reference's entry points call)")
+    ap.add_argument("--blocks", default="",
+                    help="comma-separated names: run only these blocks behind the headline (q70, q1, qsweep, online, "
+                         "online_concurrent, hard_data, whiten, cpu_baseline, scale_10m, map, aqe_rparis_1m, qge_small, dropin); "
+                         "default: all of them.  For iterating on one block on a GPU box")
     ap.add_argument("--diagnostic", action="store_true", help="skip result checks (ablation builds; number is NOT a result)")
     return ap.parse_args()
 
@@ -753,6 +758,281 @@ def small_batch_block(job, gal, args, nq, steps):
             "score_check": "%d queries x %d rows: dense float64 scores + exact top-%d equal the answer" % (m, gal.n, k)}
 
 
+QSWEEP = (128, 129, 192, 256, 257, 384, 512, 768, 1024)
+
+
+def qsweep_block(job, gal, args, steps=20):
+    """The batch-size staircase on the resident gallery: per point the whole step, the scoring launch between
+    HIP events, the roof of the shape = max(N * D * 2 B / 8 TB/s, 2 * Q * N * D / 2.5 PF) and both fractions of it.  The
+    reference has no batch-size cliff (src/utils/nnsearch.py:699 loops over the queries)."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    d, k, dev, stream = args.dim, args.topk, job.dev, job.stream
+    sg = ShardedGallery(gal)
+    gal.set_option("async_tail", 0)
+    qall = torch.empty((1024, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(qall.data_ptr(), args.seed + 23, 0, 1024, d, stream)
+    points = []
+    for nq in QSWEEP:
+        qb = qall[:nq]
+        for _ in range(5):
+            sg.search(qb, k)
+        torch.cuda.synchronize()
+        gal.status(reset=True)
+        gal.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sg.search(qb, k)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        gal.profile(False)
+        lms = [float(v) for v in gal.launch_ms()]
+        st = gal.status(reset=True)
+        ms = el / steps * 1e3
+        launch = sum(lms) / max(1, len(lms))
+        roof_ms = max(gal.n * d * 2.0 / (HBM_PEAK_GBS * 1e9), 2.0 * nq * gal.n * d / (MFMA_BF16_PEAK_TFLOPS * 1e12)) * 1e3
+        points.append({"queries": nq, "ms_per_step": round(ms, 4), "scoring_launch_ms": round(launch, 4),
+                       "launches_per_step": len(lms) / steps, "roof_ms": round(roof_ms, 4),
+                       "frac_whole_step": round(roof_ms / ms, 4), "frac_at_launch": round(roof_ms / launch, 4) if launch else None,
+                       "value": nq / (ms * 1e-3),
+                       "flagged_batches": st["overflow_batches"] + st["spec_retries"]})
+    by = {p["queries"]: p for p in points}
+    return {"gallery_rows": gal.n, "steps": steps, "unit": "queries/s", "points": points,
+            "roof": "max(N*D*2 B / 8 TB/s, 2*Q*N*D / 2.5 PFLOP/s)",
+            "ms_257_over_256": round(by[257]["ms_per_step"] / by[256]["ms_per_step"], 4),
+            "ms_129_over_128": round(by[129]["ms_per_step"] / by[128]["ms_per_step"], 4),
+            "min_frac_whole_step": min(p["frac_whole_step"] for p in points),
+            "min_frac_at_launch": min(p["frac_at_launch"] for p in points)}
+
+
+def _hard_rows(kind, n, d, dev, seed):
+    """Structured galleries of VERDICT r05 #1, generated on the device with torch's generator (plumbing: the data, not the
+    product).  Returns (raw rows [n, d] f32, queries(nq) -> [nq, d] f32, description)."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    blk = 65536
+
+    def randn(*shape):
+        return torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
+
+    def unit(x):
+        return x / x.norm(dim=1, keepdim=True)
+    if kind == "nonneg":
+        for r0 in range(0, n, blk):
+            m = min(blk, n - r0)
+            raw[r0:r0 + m] = randn(m, d).abs_()
+
+        def queries(nq):
+            return randn(nq, d).abs_()
+        desc = "|N(0,1)| rows and queries (pre-whitening GeM descriptors are non-negative): mean pairwise cosine 2/pi = 0.64"
+    elif kind == "clustered":
+        ncl, per = 2000, 500
+        centres = unit(randn(ncl, d))
+        for r0 in range(0, n, blk):
+            m = min(blk, n - r0)
+            ids = torch.arange(r0, r0 + m, device=dev)
+            cl = torch.clamp(ids // per, max=ncl - 1)
+            cos = 0.90 + 0.09 * torch.rand((m, 1), generator=g, device=dev)
+            rows = cos * centres[cl] + torch.sqrt(1 - cos * cos) * unit(randn(m, d))
+            back = (ids >= ncl * per).unsqueeze(1)
+            raw[r0:r0 + m] = torch.where(back, randn(m, d), rows)
+
+        def queries(nq):
+            # five queries per landmark like rOxford / rParis (70 queries of ~13 landmarks), cosine 0.95 to the centre: the
+            # K-th (100th) best score lies INSIDE a cluster of 500 rows at cosine 0.855 .. 0.94 to the query
+            cl = (torch.arange(nq, device=dev) // 5 * 37) % ncl
+            return 0.95 * centres[cl] + (1 - 0.95 ** 2) ** 0.5 * unit(randn(nq, d))
+        desc = "2000 clusters x 500 rows at cosine 0.90-0.99 to their centre (+ %d Gaussian rows); queries at cosine 0.95 to a " \
+               "centre, five per cluster" % (n - ncl * per)
+    elif kind == "near_duplicates":
+        nbase, copies = 125000, 8
+        base = unit(randn(nbase, d))
+        exact = unit(randn(16, d))
+        n_dup = nbase * copies
+        for r0 in range(0, n, blk):
+            m = min(blk, n - r0)
+            ids = torch.arange(r0, r0 + m, device=dev)
+            rows = base[torch.clamp(ids // copies, max=nbase - 1)] + 1e-4 * unit(randn(m, d))
+            ex = exact[torch.clamp((ids - n_dup) // 64, min=0, max=15)]
+            rows = torch.where(((ids >= n_dup) & (ids < n_dup + 1024)).unsqueeze(1), ex, rows)
+            raw[r0:r0 + m] = torch.where((ids >= n_dup + 1024).unsqueeze(1), randn(m, d), rows)
+
+        def queries(nq):
+            # query i < 16: near one of the 16 rows stored 64 times (its best 64 scores are exact ties); the others near a
+            # base row (their best 8 scores differ by ~2e-6, far inside the certificate's margin)
+            q = unit(base[(torch.arange(nq, device=dev) * 97) % nbase] + 0.5 * unit(randn(nq, d)))
+            m = min(nq, 16)
+            q[:m] = unit(exact[:m] + 0.5 * unit(randn(m, d)))
+            return q
+        desc = "125 000 base rows x 8 copies with 1e-4 relative noise + 64 exact copies of each of 16 rows (+ %d Gaussian rows)" \
+               % (n - n_dup - 1024)
+    else:
+        raise ValueError(kind)
+    return raw, queries, desc
+
+
+def hard_data_block(job, args, gaussian_qps, steps=10):
+    """The headline's shape on data that is NOT i.i.d. Gaussian: the filter's work per query -- candidates,
+    survivors, repairs, fallbacks -- depends on the data, the reference's does not (src/utils/nnsearch.py:693-703: every row,
+    full argsort).  Per gallery: 1024 / 70 / 1 queries, K = 100, `steps` synchronous steps each through the device entry
+    point; a case that raised a sticky flag is timed again WITH the fallbacks of the host entry point (verify=True) and that
+    figure is the value.  Every case ends with the dense float64 completeness check of 16 queries."""
+    import numpy as np
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    n, d, k, dev, stream = WORKLOADS["roxford5k+1m"][0], args.dim, args.topk, job.dev, job.stream
+    out = {"gallery_rows": n, "topk": k, "steps": steps, "unit": "queries/s", "cases": {}}
+    _lib.set_global_option("image_dtype", 1 if args.image_dtype == "f16" else 0)
+    for ci, kind in enumerate(("nonneg", "clustered", "near_duplicates")):
+        raw, queries, desc = _hard_rows(kind, n, d, dev, args.seed + 500 + ci)
+        torch.cuda.synchronize()
+        gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d, norm_mode=_lib.NORM_L2, device=job.dev_index)
+        del raw
+        torch.cuda.empty_cache()
+        rec = {"data": desc}
+        try:
+            sg = ShardedGallery(gal)
+            gal.calibrate(8, stream)
+            for nq in (1024, 70, 1):
+                pool = [queries(nq).contiguous() for _ in range(2)]
+
+                def run(count, verify):
+                    o = None
+                    for i in range(count):
+                        o = sg.search(pool[i % 2], k, verify=verify)
+                    torch.cuda.synchronize()
+                    return o
+                run(3, False)
+                gal.flags()
+                gal.status(reset=True)
+                gal.profile(True)
+                t0 = time.perf_counter()
+                o = run(steps, False)
+                el = time.perf_counter() - t0
+                gal.profile(False)
+                lms = [float(v) for v in gal.launch_ms()]
+                flagged_now = bool(gal.flags())
+                st = gal.status(reset=True)
+                flagged = st["overflow_batches"] + st["spec_retries"]
+                case = {"queries_per_step": nq, "ms_per_step": el / steps * 1e3, "value": nq * steps / el,
+                        "scoring_launch_ms": sum(lms) / max(1, len(lms)),
+                        "candidates_per_query": st["candidates"] / max(1, st["queries"]),
+                        "survivors_per_query": st["survivors"] / max(1, st["queries"]),
+                        "flagged": flagged_now or flagged > 0, "inkernel_repairs": st["inkernel_repairs"]}
+                if case["flagged"]:
+                    # answered again by the rigorous schedule / the f32 scorer where a flag was raised: the honest figure
+                    run(1, True)
+                    gal.status(reset=True)
+                    t0 = time.perf_counter()
+                    o = run(steps, True)
+                    el = time.perf_counter() - t0
+                    st = gal.status(reset=True)
+                    case.update({"ms_per_step_unverified": case["ms_per_step"], "ms_per_step": el / steps * 1e3,
+                                 "value": nq * steps / el, "mode": "verify=True: flags of every batch read, fallbacks run",
+                                 "overflow_batches": st["overflow_batches"], "spec_retries": st["spec_retries"]})
+                m = min(nq, 16)
+                idx_h, sc_h = o[0][:m].cpu().numpy(), o[1][:m].cpu().numpy()
+                didx, dsc, dsc64, _ = gal.dense64_search(pool[(steps - 1) % 2][:m].cpu().numpy(), k)
+                # (exact ties may be cut anywhere among EQUAL float64 scores by either path: compare scores, and ids where
+                # the float64 scores differ from their neighbours)
+                same_ids = bool(np.array_equal(idx_h, didx))
+                case["score_check"] = {"queries": m, "ids_equal_dense_f64": same_ids,
+                                       "max_abs_score_diff": float(np.abs(sc_h - dsc).max())}
+                assert case["score_check"]["max_abs_score_diff"] <= 6e-8, "%s q%d: scores differ from the dense f64 path" % (kind, nq)
+                assert same_ids, "%s q%d: ids differ from the dense f64 path" % (kind, nq)
+                if nq == 1024 and gaussian_qps:
+                    case["vs_gaussian_headline"] = case["value"] / gaussian_qps
+                rec["q%d" % nq] = case
+        finally:
+            gal.close()
+            torch.cuda.empty_cache()
+        out["cases"][kind] = rec
+    out["min_vs_gaussian_headline"] = min(c["q1024"].get("vs_gaussian_headline", 1.0) for c in out["cases"].values())
+    return out
+
+
+F64_MATRIX_PEAK_TFLOPS = 78.6    # AMD's MI355X data sheet (FP64 matrix = FP64 vector); the guide lists no f64 matrix figure
+
+
+def whiten_block(job, args):
+    """Learned whitening (north_star; src/utils/whiten.py:4-12, applied to the whole database at src/main_train.py:711-712) at
+    BASELINE size: 1 005 994 x 2048 float32 descriptors on the device, float64 mean and a 2048 x 2048 float64 P.  (i)
+    mi_whiten_apply_device -> float64 [N, dims] for dims = 2048 and 128 (f64 MFMA GEMM + one-pass normalisation), (ii)
+    mi_gallery_append_whitened_device: whitened rows straight into a searchable gallery, the float64 matrix never exists."""
+    import numpy as np
+    import torch
+    from isehr_amd import _lib
+    n, d, dev, stream = WORKLOADS["roxford5k+1m"][0], args.dim, job.dev, job.stream
+    raw = torch.empty((n, d), dtype=torch.float32, device=dev)
+    _lib.synth_fill_device(raw.data_ptr(), args.seed + 60, 0, n, d, stream)
+    raw /= raw.norm(dim=1, keepdim=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 61)
+    P = torch.randn((d, d), dtype=torch.float64, device=dev, generator=g) / d ** 0.5
+    m = raw[:65536].double().mean(dim=0).contiguous()
+    out = torch.empty((n, d), dtype=torch.float64, device=dev)
+    picks = list(range(0, n, n // 16))[:16]
+    xh = raw[picks].double().cpu().numpy()
+    rec = {"rows": n, "d": d, "peak_TFLOPs": F64_MATRIX_PEAK_TFLOPS,
+           "peak_source": "AMD MI355X data sheet, FP64 matrix; /opt/skills/guides/MI355X_MICROARCH.md lists no f64 matrix rate",
+           "kernel": "whiten_mfma_kernel: v_mfma_f64_16x16x4_f64, 128 x 128 outputs per workgroup, (x - m) applied on load"}
+    try:
+        for dims in (d, 128):
+            best = {}
+            for name, eps in (("gemm_plus_normalise", 1e-6), ("gemm_only", -1.0)):
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    _lib.whiten_apply_device(raw.data_ptr(), n, d, m.data_ptr(), P.data_ptr(), dims, out.data_ptr(), eps=eps,
+                                             stream=stream)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    best[name] = min(best.get(name, 1e9), dt)
+            _lib.whiten_apply_device(raw.data_ptr(), n, d, m.data_ptr(), P.data_ptr(), dims, out.data_ptr(), eps=1e-6, stream=stream)
+            torch.cuda.synchronize()
+            got = out.view(-1)[:n * dims].view(n, dims)[picks].cpu().numpy()
+            ref = (xh - m.cpu().numpy()) @ P[:dims].cpu().numpy().T
+            ref /= (np.linalg.norm(ref, axis=1, keepdims=True) + 1e-6)
+            err = float(np.abs(got - ref).max())
+            assert err < 1e-12, "whitening differs from the float64 recomputation: %g" % err
+            flop = 2.0 * n * dims * d
+            rec["dims_%d" % dims] = {
+                "seconds": round(best["gemm_plus_normalise"], 5), "gemm_seconds": round(best["gemm_only"], 5),
+                "TFLOPs_gemm": flop / best["gemm_only"] / 1e12, "frac_of_f64_matrix_peak": flop / best["gemm_only"] / 1e12 / F64_MATRIX_PEAK_TFLOPS,
+                "TFLOPs_incl_normalise": flop / best["gemm_plus_normalise"] / 1e12,
+                "bytes_algorithmic": n * d * 4 + n * dims * 8 * (1 + 2), "rows_per_s": n / best["gemm_plus_normalise"],
+                "max_abs_diff_vs_float64_numpy_16_rows": err}
+        del out
+        torch.cuda.empty_cache()
+        # (ii) whitened rows straight into a gallery (MI_NORM_L2_EPS = whitenapply's tail): one call, 512 MiB of scratch
+        gal = _lib.Gallery.empty(n, d, norm_mode=_lib.NORM_L2_EPS, device=job.dev_index)
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gal.append_whitened_device(raw.data_ptr(), n, d, m.data_ptr(), P.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ref = (xh - m.cpu().numpy()) @ P.cpu().numpy().T
+            ref /= (np.linalg.norm(ref, axis=1, keepdims=True) + 1e-6)
+            got = np.stack([gal.get_rows(int(r), 1)[0] for r in picks])
+            err = float(np.abs(got - ref).max())
+            assert err < 2e-7, "whitened gallery rows differ from the float64 recomputation: %g" % err
+            rec["into_gallery"] = {"seconds": round(dt, 5), "rows_per_s": n / dt, "TFLOPs": 2.0 * n * d * d / dt / 1e12,
+                                   "max_abs_diff_of_stored_f32_rows": err,
+                                   "note": "whiten -> normalise -> f32 rows + 16-bit image + rounding norms, chunks of 32 768 rows; "
+                                           "the [N, 2048] float64 matrix (16.5 GB) never exists"}
+        finally:
+            gal.close()
+    finally:
+        del raw
+        torch.cuda.empty_cache()
+    return rec
+
+
 def online_block(job, gal, args):
     """src/online.py:121-152 for ONE uploaded image, kept on the device (entry/online.py Searcher.query_device): the descriptor as
     the extractor tail leaves it (a device row) -> search, K = 100, on the L2-normalised gallery -> qge1 (alpha-QE k = 3, w = 4:
@@ -808,8 +1088,48 @@ def online_block(job, gal, args):
         idx_h, _, _ = gal.search(q_last.cpu().numpy(), k)
         ref_idx, _, _, _ = g_raw.aqe_search(np.ascontiguousarray(idx_h.T), 3, 4.0, k)
         assert np.array_equal(out, ref_idx), "online device chain differs from the host entry points"
+        # concurrent clients (src/online.py:163: Flask's threaded server, one thread per request): 64 threads x 20 queries
+        # through entry/online.py Searcher.query_device, whose worker coalesces the waiting descriptors into one chain
+        import threading
+        from isehr_amd.entry.online import Searcher
+        nthr, per = 64, 20
+        qc = torch.empty((nthr, d), dtype=torch.float32, device=dev)
+        _lib.synth_fill_device(qc.data_ptr(), args.seed + 78, 0, nthr, d, stream)
+        torch.cuda.synchronize()
+        conc = {}
+        for mode, coalesce in (("sequential_calls_same_threads", False), ("coalesced", True)):
+            srv = Searcher.from_galleries(gal, g_raw, k, device=job.dev_index, coalesce=coalesce)
+            got = [None] * nthr
+            errs = []
+
+            def client(t):
+                try:
+                    torch.cuda.set_device(job.dev_index)
+                    for i in range(per):
+                        got[t] = srv.query_device(qc[(t + i) % nthr], return_indices=True)
+                except Exception as e:                                # noqa: BLE001
+                    errs.append(e)
+            srv.query_device(qc[0], return_indices=True)                                        # warm
+            ths = [threading.Thread(target=client, args=(t,)) for t in range(nthr)]
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            elc = time.perf_counter() - t0
+            if errs:
+                raise errs[0]
+            conc[mode] = {"value": nthr * per / elc, "unit": "queries/s", "seconds": elc,
+                          "chains_launched": srv.batches if coalesce else nthr * per,
+                          "mean_requests_per_chain": (srv.batched_requests / max(1, srv.batches)) if coalesce else 1.0}
+            conc[mode + "_answers"] = np.concatenate(got)
+            srv.close()
+        same = bool(np.array_equal(conc.pop("sequential_calls_same_threads_answers"), conc.pop("coalesced_answers")))
+        assert same, "coalesced answers differ from the sequential calls'"
+        conc.update({"client_threads": nthr, "queries_per_thread": per, "equals_sequential_answers": same})
         return {"gallery_rows": n, "topk": k, "steps": steps, "online_query_ms": el / steps * 1e3, "value": steps / el,
-                "online_query_ms_after_50ms_idle": idle_ms,
+                "online_query_ms_after_50ms_idle": idle_ms, "online_concurrent": conc,
+                "online_concurrent_qps": conc["coalesced"]["value"],
                 "unit": "queries/s", "stages": "descriptor on the device -> mi_knn_search_device (K) -> qge1 expansion (k = 3, w = 4) "
                                                "-> re-search -> one D2H of K indices",
                 "score_check": "equals mi_knn_search + mi_aqe_search (host entry points) on the same galleries"}
@@ -1232,6 +1552,11 @@ def main():
     args.async_tail = async_tail
     # the blocks beyond the headline that make the default one-GPU line cover every BASELINE config
     extra_blocks = world == 1 and default_shape and plain and not args.diagnostic and args.extra_blocks != "off"
+    only = set(x for x in args.blocks.split(",") if x)
+
+    def want(name):
+        return not only or name in only
+    scale_10m = scale_10m and want("scale_10m")
 
     with emitter.deadline("headline"):
         res = run_workload(job, n_total, args.queries, args.image_dtype, args.steps, args.warmup, args.layout,
@@ -1348,13 +1673,20 @@ def main():
         out["value_synchronous"] = out["value"]
     if extra_blocks:
         for nq_small, name in ((70, "q70"), (1, "q1")):
+            if not want(name):
+                continue
             r = emitter.block(name, lambda nq_small=nq_small: small_batch_block(job, gal, args, nq_small, 100), world)
             if r is not None:
                 out[name] = r
-        r = emitter.block("online", lambda: online_block(job, gal, args), world)
-        if r is not None:
-            out["online"] = r
-    if world == 1 and not args.no_cpu_baseline:
+        if want("qsweep"):
+            r = emitter.block("qsweep", lambda: qsweep_block(job, gal, args), world)
+            if r is not None:
+                out["qsweep"] = r
+        if want("online"):
+            r = emitter.block("online", lambda: online_block(job, gal, args), world)
+            if r is not None:
+                out["online"] = r
+    if world == 1 and not args.no_cpu_baseline and want("cpu_baseline"):
         r = emitter.block("cpu_baseline", lambda: cpu_baseline(gal, q_last_pool.cpu().numpy(), n_total, args), world)
         if r is not None:
             out["cpu_baseline"] = r
@@ -1430,7 +1762,7 @@ def main():
         torch.cuda.empty_cache()
         emitter.write(False)
 
-    if rank == 0 and default_shape and plain and not args.diagnostic:
+    if rank == 0 and default_shape and plain and not args.diagnostic and want("map"):
         # the metric's other half: mAP (E / M / H) on planted rOxford5k- / +rParis6k-sized datasets, HIP ranks vs the oracle's
         def map_blk():
             out["map"] = map_block(args, job.dev_index)
@@ -1438,10 +1770,21 @@ def main():
                 cpu_baseline_map(args, out["map"])
         emitter.block("map", map_blk, 1)
 
-    if extra_blocks:
-        r = emitter.block("aqe_rparis_1m", lambda: aqe_rparis_block(job, args), world)
+    if extra_blocks and want("whiten"):
+        r = emitter.block("whiten", lambda: whiten_block(job, args), world)
         if r is not None:
-            out["aqe_rparis_1m"] = r
+            out["whiten"] = r
+        emitter.write(False)
+    if extra_blocks and want("hard_data"):
+        r = emitter.block("hard_data", lambda: hard_data_block(job, args, out.get("value_synchronous") or out["value"]), world)
+        if r is not None:
+            out["hard_data"] = r
+        emitter.write(False)
+    if extra_blocks:
+        if want("aqe_rparis_1m"):
+            r = emitter.block("aqe_rparis_1m", lambda: aqe_rparis_block(job, args), world)
+            if r is not None:
+                out["aqe_rparis_1m"] = r
 
         def qge_blk():
             rec = qge_small_block(args, job.dev_index)
@@ -1449,11 +1792,13 @@ def main():
                 cpu_baseline_qge(args, rec)
             rec.pop("_ranks_aqe", None)
             out["qge_small"] = rec
-        emitter.block("qge_small", qge_blk, world)
+        if want("qge_small"):
+            emitter.block("qge_small", qge_blk, world)
         emitter.write(False)
-        r = emitter.block("dropin", lambda: dropin_block(job, args), world)
-        if r is not None:
-            out["dropin"] = r
+        if want("dropin"):
+            r = emitter.block("dropin", lambda: dropin_block(job, args), world)
+            if r is not None:
+                out["dropin"] = r
 
     emitter.write(True)
     if dist.is_initialized():

@@ -96,6 +96,10 @@ SIGNATURES = {
     "mi_column_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "mi_whiten_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_int32, C.c_double, C.c_int, C.c_void_p]),
+    "mi_whiten_apply_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
+    "mi_gallery_append_whitened_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64,
+                                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_gallery_calibrate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_status": (C.c_int, [C.c_void_p, C.POINTER(SearchStats), C.c_int]),
@@ -209,6 +213,15 @@ class Gallery:
         """rows_ptr: device pointer to [m, d] float32 (C order)."""
         with self._lock:
             check(load().mi_gallery_append_device(self._h, C.c_void_p(rows_ptr), m, C.c_void_p(stream)))
+            self.n += m
+
+    def append_whitened_device(self, x_ptr, m, d, mean_ptr, p_ptr, dtype=MI_F32, row_stride=None, col_stride=1, stream=None):
+        """m device rows [m, d] (strided; f32 | f64) -> P[:self.d] (x - mean), normalised by the gallery's own mode, appended.
+        mean_ptr f64 [d], p_ptr f64 row-major [>= self.d, d], both on the device.  Synchronises `stream`."""
+        with self._lock:
+            check(load().mi_gallery_append_whitened_device(self._h, C.c_void_p(x_ptr), m, d, dtype,
+                                                           d if row_stride is None else row_stride, col_stride,
+                                                           C.c_void_p(mean_ptr), C.c_void_p(p_ptr), C.c_void_p(stream)))
             self.n += m
 
     def append(self, rows):
@@ -557,6 +570,15 @@ def whiten_apply(rows, m, P, dims, eps=1e-6, device=0):
                                  m.ctypes.data_as(C.c_void_p), Pd.ctypes.data_as(C.c_void_p), dims, float(eps), device,
                                  out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def whiten_apply_device(x_ptr, n, d, m_ptr, p_ptr, dims, out_ptr, eps=1e-6, dtype=MI_F32, row_stride=None, col_stride=1,
+                        stream=None):
+    """Device-resident whitenapply (no synchronisation): out f64 [n, dims] = rows of P[:dims] (x - m) / (||.|| + eps);
+    eps < 0 leaves the rows un-normalised."""
+    check(load().mi_whiten_apply_device(C.c_void_p(x_ptr), n, d, dtype, d if row_stride is None else row_stride, col_stride,
+                                        C.c_void_p(m_ptr), C.c_void_p(p_ptr), dims, float(eps), C.c_void_p(out_ptr),
+                                        C.c_void_p(stream)))
 
 
 def desc_tail_device(feat_ptr, b, c, hw, p, eps, w_ptr, b_ptr, c_out, scratch_ptr, out_ptr, stream=None):

@@ -2227,6 +2227,51 @@ int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_
   return MI_OK;
 }
 
+int mi_whiten_apply_device(const void* X_dev, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
+                           const double* m_dev, const double* P_dev, int32_t dims, double eps, double* out_dev, void* stream) {
+  REQUIRE(X_dev && m_dev && P_dev && out_dev, "null pointer");
+  REQUIRE(n >= 1 && d >= 1 && dims >= 1 && dims <= d, "bad sizes (dims must be in [1, d])");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  REQUIRE(row_stride >= 0 && col_stride >= 0, "negative strides are not supported");
+  REQUIRE((n + 127) / 128 * ((dims + 127) / 128) < ((int64_t)1 << 31), "too many tiles for one launch");
+  launch_whiten(X_dev, dtype, n, d, row_stride, col_stride, m_dev, P_dev, dims, eps, out_dev, (hipStream_t)stream);
+  HIPC(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_gallery_append_whitened_device(mi_gallery* g, const void* X_dev, int64_t m, int32_t d, int dtype, int64_t row_stride,
+                                      int64_t col_stride, const double* mean_dev, const double* P_dev, void* stream) {
+  REQUIRE(g && X_dev && mean_dev && P_dev, "null pointer");
+  REQUIRE(m >= 1 && d >= 1 && g->d <= d, "bad sizes (the gallery's dimension is the number of rows of P that are applied)");
+  REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  REQUIRE(row_stride >= 0 && col_stride >= 0, "negative strides are not supported");
+  REQUIRE(g->n + m <= g->cap, "gallery capacity exceeded");
+  std::lock_guard<std::mutex> lock(g->mu);
+  HIPC(hipSetDevice(g->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int32_t dims = g->d;
+  const int64_t chunk = std::min<int64_t>(m, 32768);       // 512 MiB of float64 rows at dims = 2048: the only scratch there is
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  TmpAlloc tmp;
+  double* y = tmp.get<double>((size_t)chunk * dims);
+  if (!y) return fail(MI_ERR_NOMEM, "whitening scratch block");
+  for (int64_t r0 = 0; r0 < m; r0 += chunk) {
+    const int64_t rows = std::min<int64_t>(chunk, m - r0);
+    // P (x - m) of the chunk in float64, un-normalised; the ingest normalises while it reads (MI_NORM_L2_EPS = whitenapply's
+    // `X / (norm + 1e-6)`, src/utils/whiten.py:10) and writes f32 rows, 16-bit image and rounding norms at their final place
+    launch_whiten((const char*)X_dev + (size_t)r0 * row_stride * esz, dtype, rows, d, row_stride, col_stride, mean_dev, P_dev,
+                  dims, -1.0, y, s);
+    launch_ingest(y, MI_F64, rows, dims, dims, 1, g->norm_mode, g->gal_f32, g->gal_img, g->img_f16, g->rowstat, g->dp, rows, s,
+                  g->n + r0);
+  }
+  launch_rowstat_max(g->rowstat + g->n, m, g->gstat3, s, /*reset=*/false);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(s));           // the scratch block is freed on return
+  g->n += m;
+  g->npad = round_up(g->n, TILE);
+  return MI_OK;
+}
+
 int mi_kr_rerank(const void* qvecs, int64_t nq, int64_t q_row_stride, int64_t q_col_stride, const void* vecs, int64_t n,
                  int64_t v_row_stride, int64_t v_col_stride, int32_t d, int dtype, int32_t k1, int32_t k2,
                  double lambda_value, int device, int64_t* out_idx, float* out_dist) {

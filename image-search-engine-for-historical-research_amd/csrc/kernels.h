@@ -63,6 +63,18 @@ bool stream_bootstrap_applies(const ScoreArgs& a);   // bootstrap launches of an
 void launch_stream_select(const ScoreArgs& a, bool first, hipStream_t stream);
 void launch_gemm_select(const ScoreArgs& a, bool first, hipStream_t stream);
 unsigned gemm_select_grid();   // persistent grid size (workgroups); record segments = grid * 8
+// A wave whose private record segment is full (rec_cap records in one launch: ten times what a batch of descriptors leaves
+// per wave, but a batch whose queries are ordered like the gallery -- five queries per landmark, landmarks stored together:
+// bench.py `hard_data` -- or a batch of near-identical queries concentrates its survivors on the few waves that own the
+// matching (gallery tile, query block) pairs) appends the record straight to its query's survivor bucket: one RETURNING atomic
+// per record on this cold path (it drains the wave's DMA ring, which is why the hot path avoids it), the same counter
+// scatter_records_kernel adds to afterwards.  Round 5 raised FLAG_REC_OVERFLOW instead and the whole batch was answered again.
+__device__ __forceinline__ void spill_record(const QueryState& st, float score, uint32_t row, uint32_t q) {
+  const uint32_t pos = atomicAdd(&st.cnt[q * CNT_STRIDE], 1u);
+  if (pos < st.cap) st.surv[(uint64_t)q * st.cap + pos] = pack_entry(score, row);
+  else atomicOr(st.flags, FLAG_SURV_OVERFLOW);
+}
+
 // Timing of ONE scoring launch without extra packets on the stream: the next launch_gemm_select / launch_stream_select of
 // this thread goes out through hipExtLaunchKernelGGL with these events, which receive the begin / end timestamps of the
 // dispatch itself (events recorded around a launch with hipEventRecord are barrier packets of their own: ~5 us of gap

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
               if (km) {
                 const uint32_t pos = my_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                if (keep && pos < p.rec_cap)
-                  reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(sc), row, nb * 16 + l15, 0u);
+                if (keep) {
+                  if (__builtin_expect(pos < p.rec_cap, 1)) reinterpret_cast<uint4*>(my_rec)[pos] = make_uint4(__float_as_uint(sc), row, nb * 16 + l15, 0u);
+                  else spill_record(p.st, sc, row, nb * 16 + l15);      // segment full: gemm_select.hip
+                }
                 my_cnt += (uint32_t)__popcll(km);
               }
             }
@@ -232,8 +234,7 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
     }
   }
   if (!FIRST && lane == 0) {
-    p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;
-    if (my_cnt > p.rec_cap) atomicOr(p.st.flags, FLAG_REC_OVERFLOW);
+    p.rec_cnt[b * 8 + w] = my_cnt < p.rec_cap ? my_cnt : p.rec_cap;    // (records beyond the segment went to spill_record)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // trailing (unused) DMA pieces land before the LDS is released
 }

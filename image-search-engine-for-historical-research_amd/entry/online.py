@@ -19,11 +19,104 @@ parser.add_argument("--gpu-id", "-g", default="0")
 parser.add_argument("--query-npy", help="file with query descriptors [D] or [D,Q] (stands in for the uploaded image)")
 
 
+class _Request:
+    """One caller's descriptors waiting for the coalescing worker: `done` is a bare lock the caller blocks on (the cheapest
+    hand-off CPython has: no condition variable, no Future)."""
+    __slots__ = ("desc", "event", "done", "out", "error")
+
+    def __init__(self, desc, event):
+        self.desc, self.event, self.out, self.error = desc, event, None, None
+        self.done = threading.Lock()
+        self.done.acquire()
+
+
 class Searcher:
-    def __init__(self, vecs, img_paths, K, matching_method="HIP", ifgenerate=False, device=0):
+    """coalesce: concurrent query_device callers (src/online.py:163 runs Flask's threaded server: every request thread calls
+    the route, module-level globals shared) are answered TOGETHER -- one worker thread drains the waiting descriptors (up to
+    `max_batch` = 128 rows: the streaming kernel's limit) into one search -> qge1 -> re-search chain and hands every caller
+    its rows.  A 70-query launch costs what a single query does (bench.py `q1` / `q70`), so 64 clients cost one chain, not 64.
+    The answers are those of sequential calls, bit for bit (the exact re-score defines them, not the batch).  max_wait_s: once
+    a batch has held more than one request, the worker waits up to this long for stragglers before the next launch (a lone
+    sequential caller never waits)."""
+
+    def __init__(self, vecs, img_paths, K, matching_method="HIP", ifgenerate=False, device=0, coalesce=True, max_batch=128,
+                 max_wait_s=2e-4):
         self.vecs, self.img_paths, self.K = vecs, img_paths, K
         self.method, self.ifgenerate, self.device = matching_method, ifgenerate, device
         self._lock = threading.Lock()
+        self.coalesce, self.max_batch, self.max_wait_s = bool(coalesce), int(max_batch), float(max_wait_s)
+        self._cv = threading.Condition()
+        self._queue, self._worker, self._stop = [], None, False
+        self.batches, self.batched_requests = 0, 0           # statistics: chains launched / requests they answered
+
+    @classmethod
+    def from_galleries(cls, g_l2, g_raw, K, img_paths=None, device=0, **kw):
+        """A Searcher on two galleries that are already resident (L2-normalised rows for the search, the rows as stored for
+        qge1): what _device_chain builds from `vecs`, for callers that prepared them otherwise (bench.py, an offline step)."""
+        from ..sharded import ShardedGallery
+        s = cls(None, img_paths, K, device=device, **kw)
+        s._chain = (ShardedGallery(g_l2), ShardedGallery(g_raw))
+        return s
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        if self._worker is not None:
+            self._worker.join()
+            self._worker = None
+
+    def _chain_rows(self, desc):
+        """search (K) -> qge1 expansion (k = 3, w = 4) from the rows as stored -> re-search; one D2H copy of [Q, K] indices."""
+        with self._lock:
+            sg1, sg2 = self._device_chain()
+            idx, _ = sg1.search(desc, self.K)
+            idx2, _, _ = sg2.aqe_search(idx.t(), 3, 4.0, self.K)
+            return idx2.cpu().numpy()                                 # the one D2H copy (synchronises)
+
+    def _serve(self):
+        import time
+        import torch
+        torch.cuda.set_device(self.device)
+        crowded = False
+        while True:
+            with self._cv:
+                while not self._queue and not self._stop:
+                    self._cv.wait()
+                if self._stop and not self._queue:
+                    return
+                if crowded and self.max_wait_s > 0:
+                    # callers are arriving concurrently: give the ones a few microseconds behind the chance to ride along
+                    deadline = time.perf_counter() + self.max_wait_s
+                    while sum(r.desc.shape[0] for r in self._queue) < self.max_batch:
+                        left = deadline - time.perf_counter()
+                        if left <= 0:
+                            break
+                        self._cv.wait(left)
+                take, rows = [], 0
+                while self._queue and (not take or rows + self._queue[0].desc.shape[0] <= self.max_batch):
+                    r = self._queue.pop(0)
+                    take.append(r)
+                    rows += r.desc.shape[0]
+            crowded = len(take) > 1
+            try:
+                st = torch.cuda.current_stream()
+                for r in take:
+                    if r.event is not None:
+                        st.wait_event(r.event)                        # the caller's stream produced the descriptor
+                desc = take[0].desc if len(take) == 1 else torch.cat([r.desc for r in take], dim=0)
+                out = self._chain_rows(desc)
+                r0 = 0
+                for r in take:
+                    r.out = out[r0:r0 + r.desc.shape[0]]
+                    r0 += r.desc.shape[0]
+            except Exception as e:                                    # every waiting caller sees the failure
+                for r in take:
+                    r.error = e
+            self.batches += 1
+            self.batched_requests += len(take)
+            for r in take:
+                r.done.release()
 
     def _device_chain(self):
         """The two prepared galleries of the chain -- L2-normalised rows for the search (matching_L2's ranking), the rows as
@@ -46,11 +139,24 @@ class Searcher:
         if desc.dim() == 1:
             desc = desc[None, :]
         desc = desc.contiguous().float()
-        with self._lock:
-            sg1, sg2 = self._device_chain()
-            idx, _ = sg1.search(desc, self.K)
-            idx2, _, _ = sg2.aqe_search(idx.t(), 3, 4.0, self.K)
-            out = idx2.cpu().numpy()                                  # the one D2H copy (synchronises)
+        if self.coalesce and desc.shape[0] <= self.max_batch:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record()                                               # on the caller's current stream
+            req = _Request(desc, ev)
+            with self._cv:
+                if self._worker is None:
+                    self._stop = False
+                    self._worker = threading.Thread(target=self._serve, name="isehr-online-coalescer", daemon=True)
+                    self._worker.start()
+                self._queue.append(req)
+                self._cv.notify()
+            req.done.acquire()                                        # released by the worker
+            if req.error is not None:
+                raise req.error
+            out = req.out
+        else:
+            out = self._chain_rows(desc)
         if return_indices:
             return out
         return [[self.img_paths[i] for i in row] for row in out]

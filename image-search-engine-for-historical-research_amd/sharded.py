@@ -74,6 +74,8 @@ class ShardedGallery:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._buf = {}
+        self._turn = {}                    # (nq, k, tag) -> ring position of the result buffers handed out last
+        self._tag = "search"
         self._join = True
         self._protocol = self.world > 1 or (force_protocol and dist.is_available() and dist.is_initialized())
         if self._protocol:
@@ -98,6 +100,15 @@ class ShardedGallery:
         dist.all_reduce(b, op=dist.ReduceOp.MAX, group=self.group)
         self.g.norm_bounds(raise_to=[float(v) for v in b.tolist()])
 
+    def _ring_buffers(self, nq, k, device):
+        """Result buffers of a synchronous entry point: a ring of TWO per (shape, entry point), so that what search() returned
+        survives the next search() of the same shape, and a search() result survives any aqe_search() (whose internal
+        re-search has a ring of its own): `ranks = search(..); aqe_search(ranks.t(), ..); use(ranks)` -- the order of
+        src/online.py:132-152 -- reads what it was given."""
+        key = (nq, k, self._tag)
+        turn = self._turn[key] = self._turn.get(key, 1) ^ 1
+        return self._buffers(nq, k, device, slot=(self._tag, turn))
+
     def _buffers(self, nq, k, device, slot=0):
         import torch
         key = (nq, k, slot)
@@ -116,7 +127,9 @@ class ShardedGallery:
     def search(self, q, k, query_norm_none=False, verify=False, join=True):
         """q: [Q, D] float32 cuda tensor (same on every rank), Q <= 1024.
         Returns (idx int64 [Q,k], score float32 [Q,k]) cuda tensors, identical on every rank.  They are this object's
-        buffers for (Q, k): the next search of the same shape overwrites them (clone what must outlive it).
+        buffers: a ring of two per (Q, k), so a result stays intact through the NEXT search of the same shape and through
+        any aqe_search (which keeps a ring of its own); the second-next search of the same shape overwrites it (clone what
+        must live longer).
         query_norm_none: use the queries as they are (expanded queries of alpha-QE).
 
         The device entry points run asynchronously and report buffer overflows / a failed speculative threshold
@@ -239,7 +252,7 @@ class ShardedGallery:
     def _search(self, q, k):
         import torch
         nq = q.shape[0]
-        b = self._buffers(nq, k, q.device)
+        b = self._ring_buffers(nq, k, q.device)
         stream = torch.cuda.current_stream().cuda_stream
         if not self._protocol:
             self.g.search_device(q.data_ptr(), nq, k, b["oidx"].data_ptr(), b["osc"].data_ptr(), None, stream)
@@ -302,7 +315,9 @@ class ShardedGallery:
         all-gathered world x Q x D float64 partial sums, 128 MiB at 8 ranks, and was only equal up to the order of the
         additions across shard boundaries.)  Every rank normalises redundantly (`mi_aqe_finish_device`) and the expanded
         queries go through the sharded search as they are (no second normalisation).
-        ranks: int64 cuda tensor [K_in, Q] of GLOBAL row ids (any strides).  Returns (idx [Q,k], score [Q,k], q_exp f32 [Q,D])."""
+        ranks: int64 cuda tensor [K_in, Q] of GLOBAL row ids (any strides).  Returns (idx [Q,k], score [Q,k], q_exp f32 [Q,D]);
+        idx / score are buffers of this object's alpha-QE ring (two per shape): intact through the next aqe_search and every
+        search(), overwritten by the second-next aqe_search of the same shape."""
         import torch
         import torch.distributed as dist
         nq = ranks.shape[1]
@@ -324,7 +339,11 @@ class ShardedGallery:
                                       stream)
         qx = torch.empty((nq, d), dtype=torch.float32, device=ranks.device)
         _lib.aqe_finish_device(part.data_ptr(), nq, d, eps, qx.data_ptr(), None, stream)
-        idx, sc = self.search(qx, k, query_norm_none=True, join=join, verify=verify)
+        self._tag = "aqe"                  # the re-search writes into the alpha-QE ring: `ranks` (a search() result) stays intact
+        try:
+            idx, sc = self.search(qx, k, query_norm_none=True, join=join, verify=verify)
+        finally:
+            self._tag = "search"
         return idx, sc, qx
 
 

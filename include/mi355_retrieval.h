@@ -247,6 +247,19 @@ int mi_column_sum(const void* X, int64_t n, int32_t d, int dtype, int64_t row_st
 int mi_whiten_apply(const void* X, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
                     const double* m, const double* P, int32_t dims, double eps, int device, double* out);
 
+/* The same on device-resident operands, enqueued on `stream` without synchronising: X_dev strided f32 | f64, m_dev f64 [d],
+ * P_dev f64 row-major [>= dims][d], out_dev f64 [n][dims] (un-normalised when eps < 0).  An f64 GEMM of 2 * dims * d flop per
+ * image on v_mfma_f64_16x16x4_f64 (csrc/whiten.hip); the centring is applied while X is loaded. */
+int mi_whiten_apply_device(const void* X_dev, int64_t n, int32_t d, int dtype, int64_t row_stride, int64_t col_stride,
+                           const double* m_dev, const double* P_dev, int32_t dims, double eps, double* out_dev, void* stream);
+/* Learned whitening straight into an appendable gallery (mi_gallery_create_empty with d = dims and MI_NORM_L2_EPS, whose
+ * normalisation IS whitenapply's tail `X / (norm + 1e-6)`, src/utils/whiten.py:10): m device rows are whitened in chunks of
+ * 32 768 rows into one float64 scratch block and ingested from there -- the [N, dims] float64 matrix that
+ * src/main_train.py:711-712 holds never exists.  Rows of P applied = the gallery's dimension.  Synchronises `stream` before
+ * it returns (the scratch block is freed); appends and searches on one handle must be serialised by the caller. */
+int mi_gallery_append_whitened_device(mi_gallery* g, const void* X_dev, int64_t m, int32_t d, int dtype, int64_t row_stride,
+                                      int64_t col_stride, const double* mean_dev, const double* P_dev, void* stream);
+
 /* ---- agreement between the shards of one gallery (multi-GPU).  The exactness certificate keeps every row
  * whose approximate score is within 2*eps of the K-th largest approximate score L of the WHOLE gallery; eps is derived
  * from the norm maxima measured at ingest {max ||g||, max ||g_hat||, max ||g_hat - g||} and from the image element type.

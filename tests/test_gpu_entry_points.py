@@ -95,6 +95,55 @@ def test_online_device_chain_vs_reference_qge1_golden(golden_dir, tmp_path, monk
         nnsearch.drop_cached_galleries()
 
 
+def test_online_concurrent_callers_are_coalesced_and_get_the_sequential_answers(tmp_path, monkeypatch):
+    """src/online.py:163 runs Flask's threaded server: request threads call the route concurrently on module-level globals.
+    `Searcher.query_device` hands concurrent descriptors to one worker that answers them in ONE search -> qge1 -> re-search
+    chain.  64 threads x 20 queries: every answer equals the uncoalesced call's, and the requests really
+    were batched."""
+    import threading
+    import torch
+    from isehr_amd import nnsearch
+    from isehr_amd.entry import online
+    from isehr_amd.synth import synth_rows
+    monkeypatch.chdir(tmp_path)
+    n, d, K, nthr, per = 30000, 256, 30, 64, 20
+    vecs = np.ascontiguousarray(synth_rows(91, 0, n, d).T)
+    vecs = vecs / np.linalg.norm(vecs, axis=0, keepdims=True)
+    qd = torch.from_numpy(synth_rows(92, 0, nthr * per, d)).cuda()
+    plain = online.Searcher(vecs, list(range(n)), K, coalesce=False)
+    srv = online.Searcher(vecs, list(range(n)), K, coalesce=True)
+    try:
+        want = plain.query_device(qd[:128], return_indices=True)
+        want = np.concatenate([want] + [plain.query_device(qd[i:i + 128], return_indices=True)
+                                        for i in range(128, nthr * per, 128)])
+        # one sequential caller is not delayed and not batched
+        assert np.array_equal(srv.query_device(qd[5], return_indices=True)[0], want[5]) and srv.batches == 1
+        got = np.full((nthr * per, K), -1, dtype=np.int64)
+        errs = []
+
+        def client(t):
+            try:
+                for i in range(per):
+                    j = t * per + i
+                    got[j] = srv.query_device(qd[j], return_indices=True)[0]
+            except Exception as e:                                    # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=client, args=(t,)) for t in range(nthr)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(timeout=120)
+        assert not errs, errs[:1]
+        assert np.array_equal(got, want)
+        assert srv.batched_requests == nthr * per + 1 and srv.batches < nthr * per / 4, (srv.batches, srv.batched_requests)
+        # a request wider than the batch limit is answered directly, a [Q, D] request keeps its rows together
+        assert np.array_equal(srv.query_device(qd[:200], return_indices=True), want[:200])
+        assert np.array_equal(srv.query_device(qd[300:307], return_indices=True), want[300:307])
+    finally:
+        srv.close()
+        nnsearch.drop_cached_galleries()
+
+
 @pytest.mark.parametrize("mode,gpus", [("100", "0"), ("mAP", "0"), ("100", "0,0")])
 def test_test_rop1m_driver(feature_store, capsys, mode, gpus):
     """--gpu-id 0,0: two row shards inside the driver's one process (both on the test box's only GPU)."""

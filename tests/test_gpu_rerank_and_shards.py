@@ -448,6 +448,91 @@ def test_alpha_qe_across_shards_equals_single_shard():
     single.close()
 
 
+def test_search_result_survives_the_alpha_qe_that_follows_it():
+    """src/online.py:132-152 searches, keeps `ranks`, calls qge1 on them and uses both.  Through ShardedGallery the first
+    result used to be the very buffer the re-search of aqe_search wrote into (VERDICT r05 Weak #6: it bit bench.py's own
+    checker).  Results now come from a ring of two per (shape, entry point): intact through any aqe_search and through the
+    next search of the same shape."""
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.sharded import ShardedGallery
+    n, d, nq, k = 20000, 128, 33, 50
+    g = synth_rows(61, 0, n, d)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    q = torch.from_numpy(synth_rows(62, 0, 2 * nq, d)).cuda()
+    gal = _lib.Gallery.from_host(g, norm_mode=_lib.NORM_NONE)
+    try:
+        sg = ShardedGallery(gal)
+        idx1, sc1 = sg.search(q[:nq], k)
+        keep_i, keep_s = idx1.clone(), sc1.clone()
+        idx2, sc2, _ = sg.aqe_search(idx1.t(), 3, 4.0, k)                 # same (Q, k): used to overwrite idx1 / sc1
+        torch.cuda.synchronize()
+        assert torch.equal(idx1, keep_i) and torch.equal(sc1, keep_s)
+        assert idx2.data_ptr() != idx1.data_ptr() and not torch.equal(idx2, idx1)
+        keep2 = idx2.clone()
+        idx3, _ = sg.search(q[nq:], k)                                    # the NEXT search of the shape: both earlier results stay
+        torch.cuda.synchronize()
+        assert torch.equal(idx1, keep_i) and torch.equal(idx2, keep2) and idx3.data_ptr() != idx1.data_ptr()
+        sg.search(q[:nq], k)                                              # the second-next one takes idx1's buffer again
+        torch.cuda.synchronize()
+        assert torch.equal(idx1, keep_i)                                  # (same queries: same content, same buffer)
+        assert sg.search(q[nq:], k)[0].data_ptr() == idx3.data_ptr()
+    finally:
+        gal.close()
+
+
+def test_whitening_on_the_device_and_into_a_gallery(golden_dir):
+    """mi_whiten_apply_device (f64 MFMA GEMM, centring on load, one-pass normalisation) against the reference's own
+    whitenapply outputs (tests/golden/normalise.npz, 1e-12) for row-major and [D, N] sources of both dtypes, and
+    mi_gallery_append_whitened_device: the whitened rows ingested straight into a searchable MI_NORM_L2_EPS gallery equal
+    float32(whitenapply) and are found by the search."""
+    import torch
+    from isehr_amd import _lib
+    z = np.load(os.path.join(golden_dir, "normalise.npz"))
+    X = synth_rows(32, 0, 40, 24, np.float64).T.copy()   # [D, N] like the reference (the inputs of test_whitenapply_golden)
+    m = X.mean(axis=1, keepdims=True)
+    P = synth_rows(33, 0, 24, 24, np.float64)
+    D, N = X.shape
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    md = torch.from_numpy(np.ascontiguousarray(m.reshape(-1))).to(dev)
+    Pd = torch.from_numpy(np.ascontiguousarray(P)).to(dev)
+    for dims, ref in ((D, z["whiten"]), (16, z["whiten16"])):
+        for dt in (np.float64, np.float32):
+            Xc = X.astype(dt)
+            want = ref if dt == np.float64 else oracle.whitenapply(Xc.astype(np.float64), m, P, dims)
+            for layout in ("dn", "rows"):
+                src = torch.from_numpy(np.ascontiguousarray(Xc if layout == "dn" else Xc.T)).to(dev)
+                out = torch.empty((N, dims), dtype=torch.float64, device=dev)
+                rs, cs = (1, N) if layout == "dn" else (D, 1)
+                _lib.whiten_apply_device(src.data_ptr(), N, D, md.data_ptr(), Pd.data_ptr(), dims, out.data_ptr(),
+                                         dtype=_lib.MI_F64 if dt == np.float64 else _lib.MI_F32, row_stride=rs, col_stride=cs,
+                                         stream=st)
+                torch.cuda.synchronize()
+                assert np.abs(out.cpu().numpy().T - want).max() < 1e-12, (dims, dt, layout)
+    # a bigger, ragged case straight into a gallery: 5000 x 200 descriptors -> 72 dims
+    rng = np.random.default_rng(3)
+    n, d, dims = 5000, 200, 72
+    Xb = rng.standard_normal((n, d)).astype(np.float32)
+    mb = Xb.mean(axis=0).astype(np.float64)
+    Pb = rng.standard_normal((d, d)) / np.sqrt(d)
+    want = oracle.whitenapply(Xb.T.astype(np.float64), mb.reshape(-1, 1), Pb, dims).T          # [n, dims]
+    xd = torch.from_numpy(Xb).to(dev)
+    gal = _lib.Gallery.empty(n, dims, norm_mode=_lib.NORM_L2_EPS)
+    try:
+        gal.append_whitened_device(xd.data_ptr(), 3000, d, torch.from_numpy(mb).to(dev).data_ptr(),
+                                   torch.from_numpy(Pb).to(dev).data_ptr(), stream=st)
+        gal.append_whitened_device(xd[3000:].data_ptr(), 2000, d, torch.from_numpy(mb).to(dev).data_ptr(),
+                                   torch.from_numpy(Pb).to(dev).data_ptr(), stream=st)
+        assert gal.n == n
+        got = gal.get_rows(0, n)
+        assert np.abs(got - want).max() < 1e-7
+        idx, sc, _ = gal.search(want[:7].astype(np.float32), 5)
+        assert np.array_equal(idx[:, 0], np.arange(7)) and np.abs(sc[:, 0] - 1.0).max() < 1e-5
+    finally:
+        gal.close()
+
+
 def test_aqe_and_dba_vs_reference_golden(golden_dir):
     """f-4: average_query_expansion / database_augmentation against ranks captured from the reference functions."""
     from isehr_amd.reranking import average_query_expansion_hip, database_augmentation_hip
