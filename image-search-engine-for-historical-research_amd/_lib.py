@@ -114,6 +114,7 @@ SIGNATURES = {
     "mi_debug_xcc_shares": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "mi_debug_sample_source_row": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "mi_set_global_option": (C.c_int, [C.c_char_p, C.c_double]),
+    "mi_get_global_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
     "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
 }
 
@@ -620,6 +621,13 @@ def set_global_option(name, value):
     if name == "image_dtype":
         _default_image_f16[0] = 1 if value else 0
     check(load().mi_set_global_option(name.encode(), float(value)))
+
+
+def get_global_option(name):
+    """"image_dtype", "host_ingest", "keep_buffers", "spare_bytes" (device memory held in the spare slots right now)."""
+    v = C.c_double(0.0)
+    check(load().mi_get_global_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def sample_source_rows(n, n_s=8192):

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void dense_topk_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Last resort of the exhaustive search (csrc/api.hip search_sync): data with MASSIVE ties -- more rows within the error
+// Last resort of the exhaustive search (csrc/api_schedule.hip search_sync): data with MASSIVE ties -- more rows within the error
 // margin of the K-th score than any candidate buffer holds (thousands of near-duplicates of one image).  No filter can
 // help there, so every score is computed at full precision (f32 stored rows, exact f64 products, f64 accumulation: the
 // arithmetic of rescore_kernel) into a dense [queries][rows] f64 matrix and the exact top-k is selected from it.

@@ -1249,8 +1249,8 @@ void init_xcc_balance_from(XccBalance* h, const float* w8) {
   h->launches = 0;
 }
 
-// The product build holds SIX instantiations of the tile kernel -- {bootstrap, filtered launch, conditional repair launch} x
-// {fp16, bf16 image}, structure 2, snake order -- and nothing else.  Every diagnostic (DBG != 0: stages switched off, stamps),
+// The product build holds EIGHT instantiations of the tile kernel -- {bootstrap, filtered launch, filtered launch with nt gallery
+// pieces (one query tile), conditional repair launch} x {fp16, bf16 image}, structure 2, snake order -- and nothing else.  Every diagnostic (DBG != 0: stages switched off, stamps),
 // A/B (ORDER, OPT, POL, the paired-XCD walk) and structure-1 instantiation is compiled under -DMI_KBENCH only, i.e. into
 // scripts/kbench.hip's own program (scripts/kbench_build.sh), whose records are under profiles/ (r04a_kbench*, r04c_kbench_rotated,
 // r04m_kbench*): several of them return wrong answers by design and none is reachable from the C ABI.
@@ -1366,6 +1366,18 @@ void launch_gemm_select(const ScoreArgs& a_in, bool first, hipStream_t stream) {
                                : launch_tile<false, 0, false, true, 3>(a, lds, stream);
   if (first) return a.img_f16 ? launch_tile<true, 0, true, false, 3>(a, lds, stream)
                               : launch_tile<true, 0, false, false, 3>(a, lds, stream);
+  // ONE query tile (129 .. 256 queries; the filtered launch only): every gallery tile is read once, by one workgroup, and
+  // the launch is paced by HBM, not by the matrix pipe -- its gallery pieces carry the nt policy like the streaming
+  // kernel's: 1.038 -> 0.998 ms at 256 queries, 0.977 -> 0.92 at 129 (profiles/r06_one_tile_rings_ab.txt; giving the gallery
+  // ring a sixth or seventh slot instead was measured in the same run: 6 + 3 slots 1.059 ms, 7 + 2 1.23 -- the query stream
+  // needs its lead).  With more query tiles the second one re-reads the gallery tile from L2: default policy.
+  // Round 6 also built a HALF-TILE mode for batches whose last query tile holds <= 128 queries (257 .. 384, ...: 4 x 2 waves of
+  // 64 x 64 outputs, 16 MFMAs per wave and slice instead of 32 for the padding): bit-identical answers, and slower -- 384
+  // queries 1.775 -> 1.96 ms, 640 2.59 -> 2.82 (profiles/r06g_half_tile_ab.txt; as two instantiations of the slice loop it
+  // spilled 161 VGPRs, r06f_half_tile_first_attempt.txt).  A slice of 16 MFMAs per wave is shorter than the LDS round trip
+  // and the two barriers that frame it; the half tile costs ~0.8 of a full one and the branches cost the full tiles more.
+  if (a.nqt == 1) return a.img_f16 ? launch_tile<false, 0, true, false, 3, 0, 2>(a, lds, stream)
+                                   : launch_tile<false, 0, false, false, 3, 0, 2>(a, lds, stream);
   return a.img_f16 ? launch_tile<false, 0, true, false, 3>(a, lds, stream)
                    : launch_tile<false, 0, false, false, 3>(a, lds, stream);
 }

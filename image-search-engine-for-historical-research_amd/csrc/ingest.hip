@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const In
           const int c0 = 8 * (lane + 64 * k) + 2048 * h;
           if (c0 < dp) {
             const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
-            if (coop) wimg[par][sl][wv][swz_chunk(r, ch)] = make_uint4(0, 0, 0, 0);
+            if (coop) wimg[par][sl][wv ^ (sl & 3)][swz_chunk(r, ch)] = make_uint4(0, 0, 0, 0);
             else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = make_uint4(0, 0, 0, 0);
           }
         }
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const In
 #pragma unroll
         for (int q = 0; q < PT / 4; ++q) {
 #pragma unroll
-          for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(buf + 4 * lane + 256 * ii) = y[4 * q + ii];
+          for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(buf + 4 * (lane ^ ((lane >> 4) & 1)) + 256 * ii) = y[4 * q + ii];
 #pragma unroll
           for (int ii = 0; ii < 4; ++ii)
             if ((FULL || 4 * lane + 256 * (4 * q + ii) < dp) && !(MI_INGEST_PROBE & 2))
@@ -559,8 +561,12 @@ __global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const In
             const int k = 2 * (q & 1) + kk;
             const int c0 = 8 * (lane + 64 * k) + 2048 * (q >> 1);
             if (FULL || c0 < dp) {
-              const float* cp = buf + 8 * lane + 512 * kk;
-              const float4 lo = *reinterpret_cast<const float4*>(cp), hi = *reinterpret_cast<const float4*>(cp + 4);
+              // (round 6) 16-byte chunk c of the quarter sits at c ^ ((c >> 4) & 1): the two reads below, 32 bytes apart from lane
+              // to lane, were 2-way bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.38, profiles/r05t_pmc_summary.json)
+              const float* cp = buf + 512 * kk;
+              const int sw = (lane >> 3) & 1;
+              const float4 lo = *reinterpret_cast<const float4*>(cp + 4 * ((2 * lane) ^ sw)),
+                           hi = *reinterpret_cast<const float4*>(cp + 4 * ((2 * lane + 1) ^ sw));
               const float vf[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
               union { uint16_t hh[8]; uint4 u; } pk;
 #pragma unroll
@@ -576,7 +582,8 @@ __global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const In
               }
               const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
 #if !(MI_INGEST_PROBE & 4)
-              if (coop) wimg[par][sl][wv][swz_chunk(r, ch)] = pk.u;
+              // (round 6) row slot wv ^ (sl & 3): the four slices a 16-lane group writes no longer share their four 16-byte slots
+              if (coop) wimg[par][sl][wv ^ (sl & 3)][swz_chunk(r, ch)] = pk.u;
               else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = pk.u;
 #else
               if (pk.u.x == 0x12345678u) *reinterpret_cast<uint4*>(tile_base) = pk.u;
@@ -606,7 +613,10 @@ __global__ __launch_bounds__(256, FULL ? 3 : 1) void ingest_rows_kernel(const In
       const bool row_ok = run * 4 + ((lane & 15) >> 2) < nrows;
       uint4 piece[PT / 2];
 #pragma unroll
-      for (int j = 0; j < PT / 2; ++j) piece[j] = (&wimg[par][(PT * 2) * wv + 4 * j + (lane >> 4)][0][0])[lane & 15];
+      for (int j = 0; j < PT / 2; ++j) {
+        const int sl = (PT * 2) * wv + 4 * j + (lane >> 4);
+        piece[j] = (&wimg[par][sl][0][0])[(lane & 15) ^ ((sl & 3) << 2)];
+      }
 #pragma unroll
       for (int j = 0; j < PT / 2; ++j) {
         const int sl = (PT * 2) * wv + 4 * j + (lane >> 4);      // wave w: slices [PT * 2 * w, PT * 2 * (w + 1))
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict_
       for (int k = 0; k < 4; ++k) {
         const int c0 = 8 * (lane + 64 * k);
         const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
-        if (coop) wimg[pr][sl][wv][swz_chunk(r, ch)] = make_uint4(0, 0, 0, 0);
+        if (coop) wimg[pr][sl][wv ^ (sl & 3)][swz_chunk(r, ch)] = make_uint4(0, 0, 0, 0);
         else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = make_uint4(0, 0, 0, 0);
       }
       if (lane < 3) reinterpret_cast<float*>(rowstat + orow)[lane] = 0.0f;
@@ -780,7 +790,8 @@ __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict_
       y.y = (float)((double)cur[i][1] * scale);
       y.z = (float)((double)cur[i][2] * scale);
       y.w = (float)((double)cur[i][3] * scale);
-      *reinterpret_cast<float4*>(buf + ((4 * lane + 256 * i) ^ swz)) = y;
+      const int wc4 = ((4 * lane + 256 * i) ^ swz) >> 2;              // 16-byte chunk of the scaled row; stored at c ^ ((c >> 4) & 1):
+      *reinterpret_cast<float4*>(buf + 4 * (wc4 ^ ((wc4 >> 4) & 1))) = y;   // see ingest_rows_kernel (every lane has read its raw values)
       if (!(MI_INGEST_PROBE & 2)) *reinterpret_cast<float4*>(orow_p + 256 * i) = y;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -792,8 +803,9 @@ __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c0 = 8 * (lane + 64 * k);
-        const float* bp = buf + (c0 ^ swz);
-        const float4 lo = *reinterpret_cast<const float4*>(bp), hi = *reinterpret_cast<const float4*>(bp + 4);
+        const int rc4 = (c0 ^ swz) >> 2, sw = (rc4 >> 4) & 1;
+        const float4 lo = *reinterpret_cast<const float4*>(buf + 4 * (rc4 ^ sw)),
+                     hi = *reinterpret_cast<const float4*>(buf + 4 * ((rc4 + 1) ^ sw));
         const float vf[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         union { uint16_t hh[8]; uint4 u; } pk;
 #pragma unroll
@@ -806,7 +818,7 @@ __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict_
           s_g[k] = __builtin_fma((double)vf[e], (double)vf[e], s_g[k]);
         }
         const uint32_t sl = (uint32_t)c0 / SLICE_K, ch = ((uint32_t)c0 % SLICE_K) >> 3;
-        if (coop) wimg[pr][sl][wv][swz_chunk(r, ch)] = pk.u;
+        if (coop) wimg[pr][sl][wv ^ (sl & 3)][swz_chunk(r, ch)] = pk.u;
         else *reinterpret_cast<uint4*>(tile_base + (int64_t)sl * SLICE_ELEMS + (swz_chunk(r, ch) << 3)) = pk.u;
       }
     };
@@ -826,7 +838,8 @@ __global__ __launch_bounds__(768) void ingest_cols_kernel(const InT* __restrict_
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int sl = 16 * wv + 4 * jj + (lane >> 4);
-      *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) = (&wimg[pr][sl][0][0])[lane & 15];
+      *reinterpret_cast<uint4*>(run_base + (int64_t)sl * SLICE_ELEMS + ((lane & 15) << 3)) =
+          (&wimg[pr][sl][0][0])[(lane & 15) ^ ((sl & 3) << 2)];
     }
   };
 
@@ -965,10 +978,15 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     const int coop = (row_base % 4 == 0) && !(MI_INGEST_PROBE & 2048);
 #define MI_GR_LAUNCH(T, PT, PF, FULL)                                                                                    \
   do {                                                                                                                  \
-    static int occ = 0;                                                                                                 \
-    if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ingest_rows_kernel<T, PT, PF, FULL>, 256, 0) !=     \
-                     hipSuccess || occ < 1))                                                                            \
-      occ = 2;                                                                                                          \
+    /* occupancy of this instantiation: the same on every (identical) device of the node; cached in an atomic */        \
+    static std::atomic<int> occ_cache{0};                                                                               \
+    int occ = occ_cache.load(std::memory_order_relaxed);                                                                \
+    if (!occ) {                                                                                                         \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ingest_rows_kernel<T, PT, PF, FULL>, 256, 0) !=            \
+              hipSuccess || occ < 1)                                                                                    \
+        occ = 2;                                                                                                        \
+      occ_cache.store(occ, std::memory_order_relaxed);                                                                  \
+    }                                                                                                                   \
     if (MI_INGEST_PROBE && getenv("MI_INGEST_WG_PER_CU")) occ = atoi(getenv("MI_INGEST_WG_PER_CU"));                    \
     if (MI_INGEST_PROBE) fprintf(stderr, "ingest (wave per row): %d workgroups per CU\n", occ);                         \
     const unsigned grid = (unsigned)std::min<int64_t>((npad + 3) / 4, (int64_t)current_device_cus() * occ);             \
@@ -1017,10 +1035,14 @@ void launch_ingest(const void* src, int dtype, int64_t n, int32_t d, int64_t rs,
     // rows at a lower occupancy: the launch is bound by the per-row latency chain, not by bytes); runs of 4 rows
 #define MI_GI_LAUNCH(T, PT)                                                                                             \
   do {                                                                                                                  \
-    static int occ = 0;                                                                                                 \
-    if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ingest_query_kernel<T, false, PT>, 256, 0) !=       \
-                     hipSuccess || occ < 1))                                                                            \
-      occ = 4;                                                                                                          \
+    static std::atomic<int> occ_cache{0};                                                                               \
+    int occ = occ_cache.load(std::memory_order_relaxed);                                                                \
+    if (!occ) {                                                                                                         \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ingest_query_kernel<T, false, PT>, 256, 0) !=              \
+              hipSuccess || occ < 1)                                                                                    \
+        occ = 4;                                                                                                        \
+      occ_cache.store(occ, std::memory_order_relaxed);                                                                  \
+    }                                                                                                                   \
     if (MI_INGEST_PROBE && getenv("MI_INGEST_WG_PER_CU")) occ = atoi(getenv("MI_INGEST_WG_PER_CU"));                    \
     if (MI_INGEST_PROBE) fprintf(stderr, "ingest: %d workgroups per CU\n", occ);                                        \
     const unsigned grid = (unsigned)std::min<int64_t>((npad + MI_INGEST_RUN - 1) / MI_INGEST_RUN,                          \

@@ -197,14 +197,14 @@ constexpr int MAINT_PER_THREAD_MAX = 32;        // 512 * 32 = 16384 = largest su
 
 // MODE 0 (after the bootstrap chunk).  spec_r > 0: SPECULATIVE threshold for the single remaining scoring launch =
 //   the spec_r-th largest sample score (>= K rows above it exist in the whole shard with probability 1 - 1e-6, see
-//   api.hip), and thr2 = the (4*spec_r)-th largest as the looser threshold of the repair pass.  A speculative
+//   api_schedule.hip), and thr2 = the (4*spec_r)-th largest as the looser threshold of the repair pass.  A speculative
 //   threshold needs no error margin: it is verified after the scan (MODE 1).
 // MODE 1 (after the last launch): topvals / L, and with spec != 0 the verification: the survivors are ALL rows with
 //   approximate score >= thr, so if there are >= K of them L is the true K-th largest approximate score, and if also
 //   L - margin >= thr every candidate row is among them.  Otherwise the query is flagged for the repair pass
 //   (device-side, conditional launches, no host round trip); a query failing again raises FLAG_SPEC_FAIL.
 //   repair == 1: the repair pass itself, only flagged queries are processed; repair == 2: no repair pass will follow (small
-//   batches, api.hip), a failed query raises FLAG_SPEC_FAIL at once.  cond: skip the launch when *cond == 0.
+//   batches, api_schedule.hip), a failed query raises FLAG_SPEC_FAIL at once.  cond: skip the launch when *cond == 0.
 // PT = entries per thread kept in registers (PT * 512 >= survivor_cap): 24 instead of 32 at the default cap frees the
 // registers for a second workgroup per CU in MODE 1
 //   repair == 3 (instantiation SCAN; small batches on the asynchronous entry points, round 4): no repair pass follows EITHER,
@@ -452,18 +452,20 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 
 // ------------------------------------------------------------------------------------------------
 // Thresholds from the bootstrap sample (single-launch schedule): only the r-th and the (4r)-th largest of the n_s sample
-// scores are needed (r < K; see api.hip), i.e. the top few dozen of 8192 values -- a full radix select over all keys
+// scores are needed (r < K; see api_schedule.hip), i.e. the top few dozen of 8192 values -- a full radix select over all keys
 // (select_maintain_kernel<0>) spends most of its time funnelling LDS atomics into the 2-4 bins that share the scores'
 // sign and exponent.  Here every thread keeps its 16 scores in registers and contributes its maximum; the W-th largest
 // of the 512 maxima (W = 4r) is a lower bound of the W-th largest overall, so the values >= it (W plus a few) are
 // gathered and ranked exactly by counting.  Falls back to the plain select if more than 256 values qualify (ties).
 // The sample entries are dropped afterwards (cnt = 0), like select_maintain_kernel<0> with spec != 0.
-constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores
+constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores; 48 = 24 576
+                                                           // (round 6: the sample of shards beyond 160 x 8192 rows; 4-byte scores only)
 template <int SAMP_PER_THREAD>
 __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QueryState st, int32_t k, int32_t spec_r,
                                                                         int32_t lad_r, int32_t f32_scores, int dbg_phase,
                                                                         float order_slack) {
-  __shared__ uint32_t keys[SAMP_THREADS * SAMP_PER_THREAD];   // only used by the fallback (up to 32 KiB)
+  constexpr int LDS_PER = SAMP_PER_THREAD < 16 ? SAMP_PER_THREAD : 16;
+  __shared__ uint32_t keys[SAMP_THREADS * LDS_PER];           // only used by the fallback (up to 32 KiB; keys beyond: from memory)
   __shared__ __attribute__((aligned(16))) uint32_t hist[1024];   // the select's histograms; first 256 words: gather buffer
   __shared__ uint32_t sh[8];
   const uint32_t q = blockIdx.x;
@@ -513,11 +515,14 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
   } else {                                                  // a crowd of ties: plain selects over all keys
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < SAMP_PER_THREAD; ++j) keys[threadIdx.x + j * SAMP_THREADS] = kv[j];
+    for (int j = 0; j < LDS_PER; ++j) keys[threadIdx.x + j * SAMP_THREADS] = kv[j];
     __syncthreads();
-    key1 = block_kth_largest(keys, n, w1, hist);
-    key2 = block_kth_largest(keys, n, w2, hist);
-    if (lad_r > 0) key3 = block_kth_largest(keys, n, (uint32_t)lad_r, hist);
+    auto rest_at = [&](uint32_t i) -> uint32_t {            // keys beyond the LDS part (24 576-score samples only)
+      return f2key(f32_scores ? reinterpret_cast<const float*>(gsurv)[i] : entry_score(gsurv[i]));
+    };
+    key1 = block_kth_largest_f(keys, (uint32_t)(SAMP_THREADS * LDS_PER), rest_at, n, w1, hist);
+    key2 = block_kth_largest_f(keys, (uint32_t)(SAMP_THREADS * LDS_PER), rest_at, n, w2, hist);
+    if (lad_r > 0) key3 = block_kth_largest_f(keys, (uint32_t)(SAMP_THREADS * LDS_PER), rest_at, n, (uint32_t)lad_r, hist);
   }
   if (threadIdx.x == 0) {
     // order_slack: the sample scores were summed in another order than the scoring launch sums (K-split bootstrap,
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
 
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {
   const bool size_ok = first_cnt == SAMP_THREADS * 2u || first_cnt == SAMP_THREADS * 4u || first_cnt == SAMP_THREADS * 8u ||
-                       first_cnt == SAMP_THREADS * 16u;
+                       first_cnt == SAMP_THREADS * 16u || first_cnt == SAMP_THREADS * 48u;
   return size_ok && spec_r >= 1 && spec_r < k && 4 * spec_r <= 256 && (int64_t)first_cnt >= k;
 }
 
@@ -561,8 +566,11 @@ void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_
   else if (first_cnt == SAMP_THREADS * 8u)
     hipLaunchKernelGGL(sample_threshold_kernel<8>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
                        g_tail_debug_phase, order_slack);
-  else
+  else if (first_cnt == SAMP_THREADS * 16u)
     hipLaunchKernelGGL(sample_threshold_kernel<16>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
+                       g_tail_debug_phase, order_slack);
+  else
+    hipLaunchKernelGGL(sample_threshold_kernel<48>, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, k, spec_r, lad_r, f32_scores,
                        g_tail_debug_phase, order_slack);
 }
 

@@ -35,12 +35,12 @@ class Searcher:
     the route, module-level globals shared) are answered TOGETHER -- one worker thread drains the waiting descriptors (up to
     `max_batch` = 128 rows: the streaming kernel's limit) into one search -> qge1 -> re-search chain and hands every caller
     its rows.  A 70-query launch costs what a single query does (bench.py `q1` / `q70`), so 64 clients cost one chain, not 64.
-    The answers are those of sequential calls, bit for bit (the exact re-score defines them, not the batch).  max_wait_s: once
-    a batch has held more than one request, the worker waits up to this long for stragglers before the next launch (a lone
-    sequential caller never waits)."""
+    The answers are those of sequential calls, bit for bit (the exact re-score defines them, not the batch).  max_wait_s: when
+    the recent chains held several requests, the worker waits up to this long for as many to be queued again before the next
+    launch (the callers just answered are on their way back); a lone sequential caller never waits."""
 
     def __init__(self, vecs, img_paths, K, matching_method="HIP", ifgenerate=False, device=0, coalesce=True, max_batch=128,
-                 max_wait_s=2e-4):
+                 max_wait_s=5e-4):
         self.vecs, self.img_paths, self.K = vecs, img_paths, K
         self.method, self.ifgenerate, self.device = matching_method, ifgenerate, device
         self._lock = threading.Lock()
@@ -66,6 +66,18 @@ class Searcher:
             self._worker.join()
             self._worker = None
 
+    @staticmethod
+    def _caller_event(desc):
+        """An event behind what the caller's stream has enqueued so far (the descriptor's producer), for the worker's stream
+        to wait on -- or None when the caller works on the device's default stream, which the worker uses too (stream order
+        does it; an event per request is ~10 us of a 30 us budget)."""
+        import torch
+        if not desc.is_cuda or torch.cuda.current_stream(desc.device).cuda_stream == 0:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
     def _chain_rows(self, desc):
         """search (K) -> qge1 expansion (k = 3, w = 4) from the rows as stored -> re-search; one D2H copy of [Q, K] indices."""
         with self._lock:
@@ -78,17 +90,20 @@ class Searcher:
         import time
         import torch
         torch.cuda.set_device(self.device)
-        crowded = False
+        recent = [1, 1, 1, 1]                                         # requests of the last chains: how many callers are around
         while True:
             with self._cv:
                 while not self._queue and not self._stop:
                     self._cv.wait()
                 if self._stop and not self._queue:
                     return
-                if crowded and self.max_wait_s > 0:
-                    # callers are arriving concurrently: give the ones a few microseconds behind the chance to ride along
+                crowd = min(max(recent), self.max_batch)
+                if crowd > 1 and self.max_wait_s > 0:
+                    # callers arrive concurrently: the ones the previous chain has just answered are on their way back (a chain
+                    # of 64 descriptors costs what a chain of one does).  Wait -- briefly -- until as many requests as the
+                    # recent chains held are queued; a lone sequential caller (crowd 1) never waits
                     deadline = time.perf_counter() + self.max_wait_s
-                    while sum(r.desc.shape[0] for r in self._queue) < self.max_batch:
+                    while len(self._queue) < crowd:
                         left = deadline - time.perf_counter()
                         if left <= 0:
                             break
@@ -98,7 +113,7 @@ class Searcher:
                     r = self._queue.pop(0)
                     take.append(r)
                     rows += r.desc.shape[0]
-            crowded = len(take) > 1
+            recent = recent[1:] + [len(take)]
             try:
                 st = torch.cuda.current_stream()
                 for r in take:
@@ -140,10 +155,7 @@ class Searcher:
             desc = desc[None, :]
         desc = desc.contiguous().float()
         if self.coalesce and desc.shape[0] <= self.max_batch:
-            import torch
-            ev = torch.cuda.Event()
-            ev.record()                                               # on the caller's current stream
-            req = _Request(desc, ev)
+            req = _Request(desc, self._caller_event(desc))
             with self._cv:
                 if self._worker is None:
                     self._stop = False

@@ -16,6 +16,7 @@ HIP library; there is no CPU path.
 import os
 import threading
 import time
+import uuid
 
 import numpy as np
 
@@ -27,6 +28,8 @@ TOPK_PATH_MAX_K = 2048      # beyond this the full-length ranking path is used
 _cache = {}
 _cache_lock = threading.Lock()
 _savers = {}                # cache key -> thread writing that gallery's file behind the call that built it
+_state_lock = threading.Lock()   # _savers, _path_locks, last_timing["save"] (written by saver threads)
+_path_locks = {}            # gallery file -> lock: one writer per file at a time
 last_timing = {}            # what the last get_gallery() did: {"source": built | cached | file, "build_s", "save": ...}
 
 
@@ -40,36 +43,49 @@ def _gallery_path(dataset, norm_mode=NORM_L2):
 def _save_behind(key, g, path):
     """The prepared-gallery file (12 GB at the 1M-row size: ~1.2 s of D2H + page-cache writes) is written by a thread of its
     own AFTER the gallery is usable: the caller's timer (matching_<method> times everything it does, src/utils/nnsearch.py:688-705)
-    no longer spans it.  mi_gallery_save only reads the handle's immutable buffers on a stream of its own, so searches run
-    beside it.  Written to a temporary name and renamed: a reader never sees half a file."""
+    no longer spans it.  mi_gallery_save reads the handle's immutable buffers (checksums and copies on streams of its own) and
+    takes the handle's mutex for the one mutable thing it stores, the XCD shares of the search workspace; searches run beside
+    it.  Written to a temporary name of its own and renamed: a reader never sees half a file."""
     def work():
-        tmp = "%s.tmp.%d" % (path, os.getpid())
+        # one temporary name per writer (two galleries of one dataset on two devices share `path`), one writer per path at a time
+        tmp = "%s.tmp.%d.%s" % (path, os.getpid(), uuid.uuid4().hex[:12])
         t0 = time.time()
-        try:
-            g.save(tmp)
-            os.replace(tmp, path)
-            last_timing["save"] = {"seconds": time.time() - t0, "path": path, "behind_the_call": True}
-        except Exception as e:            # the file is a cache: failing to write it must not fail a search that succeeded
-            last_timing["save"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        with _path_lock(path):
             try:
-                os.unlink(tmp)
-            except OSError:
-                pass
+                g.save(tmp)
+                os.replace(tmp, path)
+                rec = {"seconds": time.time() - t0, "path": path, "behind_the_call": True}
+            except Exception as e:        # the file is a cache: failing to write it must not fail a search that succeeded
+                rec = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
+        with _state_lock:
+            last_timing["save"] = rec
     th = threading.Thread(target=work, name="mi355-gallery-save", daemon=False)
-    _savers[key] = th
+    with _state_lock:
+        _savers[key] = th
     th.start()
+
+
+def _path_lock(path):
+    with _state_lock:
+        return _path_locks.setdefault(os.path.abspath(path), threading.Lock())
 
 
 def wait_for_saves():
     """Blocks until every write-behind gallery file is complete (a process that exits joins them anyway)."""
-    for key in list(_savers):
-        th = _savers.pop(key, None)
-        if th is not None:
-            th.join()
+    with _state_lock:
+        ths = list(_savers.values())
+        _savers.clear()
+    for th in ths:
+        th.join()
 
 
 def _join_saver(key):
-    th = _savers.pop(key, None)
+    with _state_lock:
+        th = _savers.pop(key, None)
     if th is not None:
         th.join()
 
@@ -101,8 +117,18 @@ def get_gallery(train, dataset=None, ifgenerate=False, norm_mode=NORM_L2, device
         path = _gallery_path(dataset, norm_mode)
         t0 = time.time()
         if not ifgenerate and os.path.exists(path):
-            g = Gallery.load(path, device=device)
-            if (g.n, g.d) != shape or g.norm_mode != norm_mode:
+            try:
+                g = Gallery.load(path, device=device)
+            except RuntimeError as e:
+                # a file that does not load -- truncated, a checksum that does not match, an older layout -- is a cache miss:
+                # the gallery is rebuilt from `train` and the file replaced (MI_ERR_IO = 4; anything else is a real failure)
+                if "error 4" not in str(e):
+                    raise
+                last_timing.update(file_rejected=str(e))
+                g = None
+            if g is None:
+                pass
+            elif (g.n, g.d) != shape or g.norm_mode != norm_mode:
                 g.close()
                 g = None
             else:
@@ -139,11 +165,14 @@ def _build_gallery(train, norm_mode, device):
 
 
 def drop_cached_galleries():
+    """Closes every cached gallery and gives the library's spare-buffer slots back too (mi_set_global_option "release_spares":
+    up to 16 GiB + ~200 MB that would otherwise stay with the process for the next gallery of the same sizes)."""
     with _cache_lock:
         wait_for_saves()
         for g in _cache.values():
             g.close()
         _cache.clear()
+        _lib.set_global_option("release_spares", 1)
 
 
 def matching_HIP(K, embedded_features_train, embedded_features_test, dataset=None, ifgenerate=False,

@@ -88,7 +88,7 @@ class ShardedGallery:
         """One error margin for all shards: the certificate's eps must cover the rows of EVERY shard (a row at the
         K-th approximate score L may sit on a shard with larger rounding norms than mine), so the norm maxima are
         all-reduced (MAX) and the image element type is the coarsest any shard chose (MIN: a raw shard with large rows
-        falls back to bf16 on its own, csrc/api.hip mi_gallery_create)."""
+        falls back to bf16 on its own, csrc/api_gallery.hip mi_gallery_create)."""
         import torch
         import torch.distributed as dist
         dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
@@ -159,8 +159,19 @@ class ShardedGallery:
                     if not bad:
                         break
                 else:
-                    raise RuntimeError("sharded search: candidate buffers overflow even with the f32 scorer "
-                                       "(massive ties: use the dense path)")
+                    if self._protocol:
+                        raise RuntimeError("sharded search: candidate buffers overflow even with the f32 scorer "
+                                           "(massive ties: use the dense path)")
+                    # one shard: the last resort of the host entry point -- every score in float64, exact top-k of the dense
+                    # rows (mi_knn_dense64_search); any data, slow
+                    qh = q.detach().cpu().numpy()
+                    if query_norm_none:
+                        raise RuntimeError("sharded search: candidate buffers overflow even with the f32 scorer (expanded "
+                                           "queries: call Gallery.dense64_search on a MI_NORM_NONE gallery)")
+                    di, ds, _, _ = self.g.dense64_search(qh, k)
+                    import torch
+                    out[0].copy_(torch.from_numpy(di).to(out[0].device))
+                    out[1].copy_(torch.from_numpy(ds).to(out[1].device))
             return out
         finally:
             if query_norm_none:

@@ -354,6 +354,12 @@ int mi_search_flags(mi_gallery* g, uint32_t* out_flags);
  * matching_<method>, src/utils/nnsearch.py:687-706) stops paying 1-6 ms of hipMalloc / hipFree per 12 GB and ~4 ms for the
  * workspace; 0 = free the spares now and keep nothing. */
 int mi_set_global_option(const char* name, double value);
+/* "release_spares" (any value) gives the spare slots back now and leaves "keep_buffers" as it is.  An allocation of the library
+ * that fails with out-of-memory releases them by itself and is tried once more; a gallery of other sizes than the spare releases
+ * it when the device could not hold both.  mi_get_global_option reads "image_dtype", "host_ingest", "keep_buffers" and
+ * "spare_bytes": the device memory the process holds in the spare slots right now -- what a co-tenant of the GPU (the
+ * extractor's PyTorch allocator) cannot see otherwise. */
+int mi_get_global_option(const char* name, double* out_value);
 
 /* The XCD shares of the tile kernel (relative speeds of the eight XCD labels, summing to 1) as the handle's launches have left
  * them, and how many launches have updated them since the workspace was created (-1: no workspace yet; the values are then what

@@ -36,7 +36,7 @@ CASES = [
     ("n1_d2048_f32_l2_f16", 21, 1, 2048, "f32", 1, 1, False),
 ]
 
-HEADER = struct.Struct("<8s4q4i3fI3QQ")   # csrc/api.hip FileHeader
+HEADER = struct.Struct("<8s4q4i3fI3QQ")   # csrc/api_file.hip FileHeader
 
 
 def case_rows(seed, n, d, dtype, special):

@@ -1,4 +1,4 @@
-// How fast can a 12 GB file that sits in the page cache reach the device?  (The prepared-gallery loader of csrc/api.hip went
+// How fast can a 12 GB file that sits in the page cache reach the device?  (The prepared-gallery loader of csrc/api_file.hip went
 // through a mapping until round 5: 25 GB/s against 55 GB/s of pinned H2D; it is variant d now.)  Same file, same device buffer:
 //   a  mmap(MAP_POPULATE) of everything, then hipMemcpy in 256 MiB pieces            (the loader as it was)
 //   b  mmap without populate, T threads populate pieces ahead (MADV_POPULATE_READ), hipMemcpy of a piece when it is populated

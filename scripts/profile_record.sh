@@ -96,3 +96,27 @@ python scripts/ingest_pmc_report.py $tag > $o/${tag}_ingest_pmc.txt 2>&1 || true
 echo "ingest done"
 fi
 echo "all done"
+# 9. round 6: the whitening kernel (f64 MFMA) -- kernel statistics and, in separate passes, matrix-pipe busy cycles and fabric traffic
+if st 9; then
+W="--steps 10 --warmup 2 --scale-10m off --no-cpu-baseline --blocks whiten"
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_whiten_trace -- python3 bench.py $W > $o/${tag}_whiten_bench.json 2> $o/${tag}_whiten.err || true
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $o/${tag}_whiten_pmc_sq -- python3 bench.py $W > $o/${tag}_whiten_pmc_sq.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/${tag}_whiten_pmc_fetch -- python3 bench.py $W > $o/${tag}_whiten_pmc_fetch.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/${tag}_whiten_pmc_write -- python3 bench.py $W > $o/${tag}_whiten_pmc_write.log 2>&1 || true
+python3 - <<PY > $o/${tag}_whiten_pmc.txt 2>&1 || true
+import csv, glob
+def per_kernel(d, counter):
+    acc = {}
+    for f in glob.glob("gpurun_out/${tag}_whiten_pmc_%s/*/*counter_collection.csv" % d):
+        for r in csv.DictReader(open(f)):
+            if "whiten_mfma" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                acc.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+    return acc
+for d, c, note in (("sq", "SQ_VALU_MFMA_BUSY_CYCLES", ""), ("sq", "SQ_BUSY_CYCLES", ""), ("sq", "GRBM_GUI_ACTIVE", ""),
+                   ("fetch", "FETCH_SIZE", " (KiB; x 2 for a wide read stream on gfx950)"), ("write", "WRITE_SIZE", " (KiB)")):
+    for k, v in per_kernel(d, c).items():
+        big = [x for x in v if x >= 0.5 * max(v)]          # the launches at dims = 2048 (the dims = 128 ones are 1/16 of the work)
+        print("%s %s: max %.4e, mean of the large launches %.4e (%d of %d launches)%s" % (k[:60], c, max(v), sum(big) / len(big), len(big), len(v), note))
+PY
+echo "whiten done"
+fi

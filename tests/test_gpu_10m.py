@@ -11,7 +11,7 @@ from _fullsize import assert_oracle_parity, host_f64_scores_and_topk
 
 pytestmark = pytest.mark.gpu
 N, D, K = 10_000_000, 2048, 100
-# chunk schedule at this size (csrc/api.hip phase1_batch): tiles [0, 32), [32, 256), [256, 39063) -> seams at rows 8192, 65536
+# chunk schedule at this size (csrc/api_schedule.hip phase1_batch): tiles [0, 32), [32, 256), [256, 39063) -> seams at rows 8192, 65536
 PLANTS = {0: 11, 1: 8191, 2: 8192, 3: 65535, 4: 65536, 5: 5_000_000, 6: N - 1}
 
 

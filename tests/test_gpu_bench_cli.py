@@ -24,7 +24,10 @@ def _bench(args, env_extra=None, timeout=600):
     # complete, at the end -- possibly refreshed in between; the driver parses the LAST line
     recs = [json.loads(ln) for ln in lines]
     assert len(recs) >= 2 and recs[0]["complete"] is False and recs[-1]["complete"] is True, lines
-    assert all(rc["value"] == recs[0]["value"] for rc in recs)         # the headline never changes once it is out
+    # the headline never changes once it is out -- except that the one-GPU default line takes the faster of its two tail modes
+    # (the same K steps, measured behind the first line: `value_synchronous` / `value_pipelined`)
+    assert all(rc["value"] in (recs[0]["value"], rc.get("value_synchronous")) for rc in recs)
+    assert recs[-1].get("value_pipelined", recs[0]["value"]) == recs[0]["value"]
     return recs[-1]
 
 
@@ -79,7 +82,10 @@ def test_default_shape_line_carries_the_secondary_blocks():
     out = _bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--scale-10m", "on", "--scale-10m-rows", "400000",
                   "--scale-10m-steps", "2", "--extra-blocks", "off"])
     assert out["config"]["gallery_rows"] == 1005994 and out["config"]["tail"].startswith("deferred")
-    assert out["config"]["value_mode"].startswith("pipelined") and "mi_knn_dense64_search" in out["config"]["score_check"]
+    # (round 6: the headline is the faster of the two tail modes of the box; both are in the line)
+    assert out["config"]["value_mode"].startswith(("pipelined", "synchronous (faster than the deferred tail"))
+    assert out["value"] == max(out["value_pipelined"], out["value_synchronous"])
+    assert "mi_knn_dense64_search" in out["config"]["score_check"]
     d = out["synchronous"]
     assert d["equals_pipelined_answer"] is True and d["flagged_batches"] == 0
     assert d["value"] > 0 and 0 < d["kernel_share_of_step"] < 1 and d["steps"] == 6
@@ -108,6 +114,24 @@ def test_default_line_gives_every_baseline_config_a_number():
         assert b["value"] > 0 and b["roofline"]["kernel"] == "stream_select_kernel"
     o = out["online"]
     assert o["online_query_ms"] > 0 and o["gallery_rows"] == 1005994 and "one D2H" in o["stages"]
+    # round 6: 64 concurrent client threads coalesced into a few chains, same answers as their sequential calls
+    oc = o["online_concurrent"]
+    assert oc["equals_sequential_answers"] is True and oc["coalesced"]["mean_requests_per_chain"] > 4
+    assert o["online_concurrent_qps"] > 4 * oc["sequential_calls_same_threads"]["value"]
+    # round 6: the batch-size staircase, the headline's shape on structured data, learned whitening
+    qs = out["qsweep"]
+    assert [p["queries"] for p in qs["points"]] == [128, 129, 192, 256, 257, 384, 512, 768, 1024]
+    assert all(p["flagged_batches"] == 0 and 0.2 < p["frac_at_launch"] < 1 for p in qs["points"])
+    hd = out["hard_data"]
+    assert set(hd["cases"]) == {"nonneg", "clustered", "near_duplicates"}
+    for rec in hd["cases"].values():
+        for q in ("q1024", "q70", "q1"):
+            assert rec[q]["value"] > 0 and rec[q]["score_check"]["ids_equal_dense_f64"] is True
+            assert rec[q]["flagged"] is False                          # no case leaves the primary path (spill path, hashed sample)
+    assert hd["min_vs_gaussian_headline"] > 0.5
+    w = out["whiten"]
+    assert w["dims_2048"]["frac_of_f64_matrix_peak"] > 0.4 and w["dims_2048"]["max_abs_diff_vs_float64_numpy_16_rows"] < 1e-12
+    assert w["into_gallery"]["rows_per_s"] > 1e6 and w["into_gallery"]["max_abs_diff_of_stored_f32_rows"] < 2e-7
     a = out["aqe_rparis_1m"]
     assert a["gallery_rows"] == 1007323 and a["q1024"]["value"] > 0 and a["q70"]["value"] > 0
     assert a["q1024"]["flagged_batches"] == 0 and "dense float64" in a["q70"]["score_check"]
@@ -144,6 +168,8 @@ def test_bare_gpus_2_line_answers_layout_overlap_and_collective_cost():
                  {"ISEHR_DIST_BACKEND": "gloo", "ISEHR_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2
     assert out["config"]["collectives"] is None                         # auto layout at N = 2: two query groups, no exchange
+    mg = out["multi_gpu"]                                               # round 6: what the first hardware run is read by
+    assert mg["layout"] == "2x1" and mg["layout_requested"] == "auto" and mg["rank_step_ms"] > 0 and "expectation" in mg
     for blk in (out["row_shard_1xN"], out["scale_10m"]):
         assert blk["value"] > 0 and blk["pipelined_collectives"]["value"] > 0
         assert blk["pipelined_collectives"]["equals_synchronous_answer"] is True

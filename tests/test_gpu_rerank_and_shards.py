@@ -727,3 +727,18 @@ def test_multi_device_gallery_on_two_distinct_devices():
     assert np.array_equal(idx, ref_idx) and np.array_equal(sc, ref_sc)
     idx, _, sc = nnsearch.matching_HIP(k, g, qv, devices=[1, 0], return_scores=True)
     assert np.array_equal(idx, ref_idx) and np.array_equal(sc, ref_sc)
+    # alpha-QE over the two devices: rows gathered per device, summed on device 0, re-search on both --
+    # the expanded queries and the answers of ONE handle, bit for bit
+    from isehr_amd.sharded import MultiDeviceGallery
+    gn = g / np.linalg.norm(g, axis=1, keepdims=True)
+    single = _lib.Gallery.from_host(gn, norm_mode=_lib.NORM_NONE, device=1)
+    base, _, _ = single.search(qv[:300] / np.linalg.norm(qv[:300], axis=1, keepdims=True), 10)
+    ranks = np.ascontiguousarray(base.T)
+    ref_i, ref_s, ref_q, _ = single.aqe_search(ranks, 3, 4.0, k, return_qexp=True)
+    single.close()
+    mg = MultiDeviceGallery.from_host(gn, [0, 1], norm_mode=_lib.NORM_NONE)
+    try:
+        mi, ms, mq = mg.aqe_search(ranks, 3, 4.0, k)
+        assert np.array_equal(mi, ref_i) and np.array_equal(ms, ref_s) and np.array_equal(mq, ref_q.astype(np.float32))
+    finally:
+        mg.close()

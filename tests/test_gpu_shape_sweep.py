@@ -117,7 +117,7 @@ def test_structured_data_on_the_sample_schedule(lib, kind, ladder):
 @pytest.mark.parametrize("k", [100, 1000])
 def test_massive_ties_take_the_dense_f64_path(lib, k):
     """Thousands of rows within 1e-7 of the K-th score: no candidate buffer holds them, the filtered passes overflow and the
-    search falls through to dense f64 scores + exact selection (csrc/api.hip search_sync).  The contract does not change:
+    search falls through to dense f64 scores + exact selection (csrc/api_schedule.hip search_sync).  The contract does not change:
     the order is that of the exact scores of the stored rows, so against the float64 truth only the f32 rounding of the
     stored rows remains (a few 1e-8 here)."""
     from isehr_amd._lib import Gallery
