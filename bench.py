@@ -829,7 +829,8 @@ def _hard_rows(kind, n, d, dev, seed):
             return randn(nq, d).abs_()
         desc = "|N(0,1)| rows and queries (pre-whitening GeM descriptors are non-negative): mean pairwise cosine 2/pi = 0.64"
     elif kind == "clustered":
-        ncl, per = 2000, 500
+        per = 500
+        ncl = max(16, (n - 5994) // per)                               # 2000 clusters at the benchmarked 1 005 994 rows
         centres = unit(randn(ncl, d))
         for r0 in range(0, n, blk):
             m = min(blk, n - r0)
@@ -845,8 +846,8 @@ def _hard_rows(kind, n, d, dev, seed):
             # K-th (100th) best score lies INSIDE a cluster of 500 rows at cosine 0.855 .. 0.94 to the query
             cl = (torch.arange(nq, device=dev) // 5 * 37) % ncl
             return 0.95 * centres[cl] + (1 - 0.95 ** 2) ** 0.5 * unit(randn(nq, d))
-        desc = "2000 clusters x 500 rows at cosine 0.90-0.99 to their centre (+ %d Gaussian rows); queries at cosine 0.95 to a " \
-               "centre, five per cluster" % (n - ncl * per)
+        desc = "%d clusters x 500 rows at cosine 0.90-0.99 to their centre (+ %d Gaussian rows); queries at cosine 0.95 to a " \
+               "centre, five per cluster" % (ncl, n - ncl * per)
     elif kind == "near_duplicates":
         nbase, copies = 125000, 8
         base = unit(randn(nbase, d))

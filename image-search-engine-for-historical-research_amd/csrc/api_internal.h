@@ -132,6 +132,7 @@ struct P1Plan {
   bool thr_kernel = false;         // sample_threshold_kernel takes the thresholds (else select_maintain mode 0)
   int32_t lad_r = 0;               // ladder level (sample rank), 0 = off
   bool zero_scores = false;        // the query ingest writes zeros for the K-split bootstrap to add onto
+  bool samp_ext = false;           // the sample's scores go to the handle's own buffer (mi_gallery::samp_scores), not into survivor rows
 };
 
 struct mi_gallery {
@@ -147,6 +148,8 @@ struct mi_gallery {
   // bootstrap sample image of the speculative schedule (built lazily, rebuilt when rows were appended)
   void* samp_img = nullptr;
   int64_t samp_tiles = 0, samp_for_n = -1;
+  float* samp_scores = nullptr;    // [QB][samp_tiles * 256] scores of a sample too large for a survivor row (shards beyond 3.9 M rows)
+  int64_t samp_scores_tiles = 0;
   int64_t hbm_bytes = 0;
   size_t buf_bytes[3] = {0, 0, 0};                 // gal_f32 / gal_img / rowstat as allocated (what a spare slot is matched by)
   // XCD shares read from the prepared-gallery file (MI355GAL trailer) / snapshotted for the next save

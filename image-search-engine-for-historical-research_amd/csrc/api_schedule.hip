@@ -74,14 +74,25 @@ static int32_t spec_rank(double lambda) {
 // in its filter); 4096 and 8192 rows tie.  So the size does not follow the shard size.
 int64_t bootstrap_tiles(const mi_gallery* g) { return g->chunk0_tiles > 0 ? g->chunk0_tiles : 32; }
 
+constexpr int64_t BIG_SAMPLE_TILES = 96;      // threshold sample of shards too large for the 32-tile one (plan_phase1)
+constexpr int64_t HUGE_SAMPLE_TILES = 256;    // ... and for the 96-tile one: 65 536 rows, scores in a buffer of the handle's own
+
 // (re)build the bootstrap sample image for the current number of rows
 static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
-  if (g->samp_img && g->samp_tiles == tiles && g->samp_for_n == g->n) return MI_OK;
+  if (g->samp_img && g->samp_tiles == tiles && g->samp_for_n == g->n && (tiles <= BIG_SAMPLE_TILES || g->samp_scores_tiles == tiles))
+    return MI_OK;
   if (!g->samp_img || g->samp_tiles != tiles) {
     (void)hipFree(g->samp_img);
     g->samp_img = nullptr;
     HIPC(device_malloc(&g->samp_img, (size_t)tiles * TILE * g->dp * 2 + 256));
     g->samp_tiles = tiles;
+  }
+  if (tiles > BIG_SAMPLE_TILES && g->samp_scores_tiles != tiles) {      // the sample's scores do not fit the survivor rows
+    (void)hipFree(g->samp_scores);
+    g->samp_scores = nullptr;
+    g->samp_scores_tiles = 0;
+    HIPC(device_malloc((void**)&g->samp_scores, (size_t)QB * tiles * TILE * sizeof(float)));
+    g->samp_scores_tiles = tiles;
   }
   launch_build_sample(g->gal_img, g->samp_img, g->n, tiles * TILE, g->dp, s);
   HIPC(hipGetLastError());
@@ -96,7 +107,6 @@ static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
 // the main part of batch i -- "lookahead": measured at no gain, profiles/r04*_lookahead*; removed in round 5.)
 
 
-constexpr int64_t BIG_SAMPLE_TILES = 96;      // threshold sample of shards too large for the 32-tile one (plan_phase1)
 
 static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, int32_t k, bool exact) {
   P1Plan pl;
@@ -122,14 +132,15 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
     if (r < k) pl.samp_r = r;
   } else if (g->speculative && !exact && g->chunk0_tiles <= 0 && g->small_batch_kernel &&
              (int64_t)2 * ws.cap >= BIG_SAMPLE_TILES * TILE && pl.ntiles >= 2 * BIG_SAMPLE_TILES &&
-             g->n / (BIG_SAMPLE_TILES * TILE) <= (int64_t)g->spec_max_ratio * 21 / 8) {
-    // Round 6: shards beyond spec_max_ratio x 8192 rows (the 10 M-row gallery of BASELINE configs[3] on one GPU) used to take
-    // the chunk schedule, whose speculative last launch reads "the rows seen so far" -- the FIRST rows of the shard -- as its
-    // sample: on a gallery stored cluster by cluster that sample is a handful of clusters (bench.py `hard_data`, DESIGN
-    // section 4).  They get a hashed sample of their own now: 96 tiles = 24 576 rows, whose scores fit a survivor row as
-    // 4-byte floats (2 x survivor_cap), up to 2.625 x spec_max_ratio rows per sample row (420: 10.3 M rows) -- r x N / n_s
-    // survivors per query stay a few thousand -- and with it the single filtered launch, the ladder and the repair pass of
-    // every other shard.  Larger shards still: the chunk schedule, as before.
+             g->n / (BIG_SAMPLE_TILES * TILE) <= g->spec_max_ratio) {
+    // Round 6: shards beyond spec_max_ratio x 8192 = 1.31 M rows used to take the chunk schedule, whose speculative last launch
+    // reads "the rows seen so far" -- the FIRST rows of the shard -- as its sample: on a gallery stored cluster by cluster that
+    // sample is a handful of clusters (bench.py `hard_data`).  Up to spec_max_ratio x 24 576 = 3.93 M rows
+    // they get a hashed sample of their own now: 96 tiles, whose scores fit a survivor row as 4-byte floats (2 x
+    // survivor_cap) -- the same rows per sample row, so the same survivors per query, the single filtered launch, the ladder
+    // and the repair pass of every smaller shard.  (At 2.6 x that ratio -- the 10 M-row gallery on ONE GPU with its bf16
+    // margin -- some queries kept more than survivor_cap rows: measured, profiles/r06l_big_sample_10m.txt.)  Larger shards
+    // still take the chunk schedule: the 8-way split of BASELINE configs[3] has 1.25 M rows per GPU and is on the sample path.
     const double lambda = (double)k * (double)(BIG_SAMPLE_TILES * TILE) / (double)g->n;
     const int32_t r = spec_rank(lambda);
     if (r < k && sample_threshold_applies((uint32_t)(BIG_SAMPLE_TILES * TILE), k, r)) {
@@ -138,9 +149,23 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
       pl.t0 = t0;
     }
   }
+  else if (g->speculative && !exact && g->chunk0_tiles <= 0 && g->small_batch_kernel && pl.ntiles >= 2 * HUGE_SAMPLE_TILES &&
+           g->n / (HUGE_SAMPLE_TILES * TILE) <= g->spec_max_ratio) {
+    // ... and up to spec_max_ratio x 65 536 = 10.5 M rows (BASELINE configs[3] on ONE GPU: 10 M rows) a 256-tile sample whose
+    // scores live in a buffer of the handle's own (256 MB, allocated with the sample image) and are ranked by
+    // sample_threshold_big_kernel.  Beyond that: the chunk schedule.
+    const double lambda = (double)k * (double)(HUGE_SAMPLE_TILES * TILE) / (double)g->n;
+    const int32_t r = spec_rank(lambda);
+    if (r < k && 4 * r <= 256) {
+      pl.samp_r = r;
+      pl.samp_ext = true;
+      t0 = HUGE_SAMPLE_TILES;
+      pl.t0 = t0;
+    }
+  }
   pl.first_cnt = (uint32_t)(pl.samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
   pl.gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
-  pl.thr_kernel = pl.samp_r > 0 && sample_threshold_applies(pl.first_cnt, k, pl.samp_r);
+  pl.thr_kernel = pl.samp_r > 0 && (pl.samp_ext || sample_threshold_applies(pl.first_cnt, k, pl.samp_r));
   // small batches on the sample schedule: the bootstrap launch splits K over several workgroups per (sample tile, query
   // group) and adds its partial scores onto zeros that the query ingest writes (ScoreArgs::ksplit)
   if (pl.samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && pl.thr_kernel && g->dp <= 4096) {
@@ -198,7 +223,10 @@ static int p1_pre(mi_gallery* g, Workspace& ws, const P1Plan& pl, const void* q_
     P1Plan p2 = pl;
     p2.boot_ksplit = boot_ksplit;
     p1_score_launch(g, ws, st, p2, 0, pl.t0, true, nullptr, false, true, false, s);     // bootstrap on the sample image
-    if (pl.thr_kernel)
+    if (pl.thr_kernel && pl.samp_ext)
+      launch_sample_threshold_big(st, g->samp_scores, (uint32_t)(pl.t0 * TILE), pl.first_cnt, pl.nq, pl.k, pl.samp_r, pl.lad_r,
+                                  0.f, s);
+    else if (pl.thr_kernel)
       launch_sample_threshold(st, pl.nq, pl.k, pl.samp_r, pl.first_cnt, s, pl.lad_r, pl.sample_f32 ? 1 : 0,
                               (pl.sample_f32 && boot_ksplit > 1) ? 0.5f : 0.f);
     else
@@ -243,6 +271,10 @@ static void p1_score_launch(mi_gallery* g, Workspace& ws, const QueryState& st, 
   a.bal = g->xcc_balance ? ws.bal : nullptr;
   a.lad_k = ladder_on ? pl.k : 0;
   a.scores_only = (on_sample && first_chunk && pl.sample_f32) ? 1 : 0;
+  if (a.scores_only && pl.samp_ext) {
+    a.samp_out = g->samp_scores;
+    a.samp_ld = (uint32_t)(pl.t0 * TILE);
+  }
   a.ksplit = a.scores_only ? pl.boot_ksplit : 1;
   a.dbg = ws.dbg;
   a.st = st;

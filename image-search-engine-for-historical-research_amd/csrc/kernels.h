@@ -48,6 +48,8 @@ struct ScoreArgs {
   int32_t scores_only = 0;           // bootstrap launch on the sample image (stream_select MODE 2): store the scores as 4-byte
                                      // floats at ((float*)(surv + q * cap))[sample row] instead of 8-byte (score, row) entries --
                                      // sample_threshold_kernel reads nothing but the scores, and the entries are dropped afterwards
+  float* samp_out = nullptr;         // scores_only: non-null -> the scores go to samp_out[q * samp_ld + sample row] instead of the
+  uint32_t samp_ld = 0;              // survivor rows (the 65 536-row sample of shards beyond 3.9 M rows does not fit one)
   int32_t ksplit = 1;                // bootstrap launch with scores_only: workgroups per (sample tile, query group), each taking
                                      // nslices / ksplit K-slices and ADDING its partial scores (atomic f32 adds onto zeros
                                      // written by the query ingest): small batches have 32 .. 64 bootstrap workgroups of 64
@@ -111,6 +113,9 @@ void launch_init_query_state(const RowStat* qstat, const float* gstat3, int32_t 
 // thresholds from the 2048 / 4096 / 8192-score bootstrap sample (single-launch schedule), cheaper than launch_select_maintain(mode 0)
 void set_tail_debug_phase(int phase);   // diagnostics only (scripts/tailbench.hip): selection kernels return after phase N; 0 = product
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r);
+// the r-th / (4 r)-th / lad_r-th largest of n sample scores per query read from scores[q * ld + i] (samples too large for a survivor row)
+void launch_sample_threshold_big(QueryState st, const float* scores, uint32_t ld, uint32_t n, int32_t nq, int32_t k,
+                                 int32_t spec_r, int32_t lad_r, float order_slack, hipStream_t stream);
 void launch_sample_threshold(QueryState st, int32_t nq, int32_t k, int32_t spec_r, uint32_t first_cnt, hipStream_t stream,
                              int32_t lad_r = 0, int32_t f32_scores = 0, float order_slack = 0.f);   // f32_scores: see ScoreArgs::scores_only
 // what the in-kernel repair of a failed query scans (repair == 3): the shard's stored f32 rows and the batch's f32 queries

@@ -458,6 +458,35 @@ void launch_select_maintain(QueryState st, int32_t nq, int32_t k, int mode, floa
 // of the 512 maxima (W = 4r) is a lower bound of the W-th largest overall, so the values >= it (W plus a few) are
 // gathered and ranked exactly by counting.  Falls back to the plain select if more than 256 values qualify (ties).
 // The sample entries are dropped afterwards (cnt = 0), like select_maintain_kernel<0> with spec != 0.
+// what a sample-threshold kernel leaves for its query: thr / thr2 from the r-th / (4 r)-th largest sample score, the ladder level
+__device__ __forceinline__ void store_sample_thresholds(const QueryState& st, uint32_t q, uint32_t key1, uint32_t key2,
+                                                        uint32_t key3, int32_t lad_r, float margin_q, float thr_in,
+                                                        float order_slack) {
+  {
+    // order_slack: the sample scores were summed in another order than the scoring launch sums (K-split bootstrap,
+    // ScoreArgs::ksplit).  Two f32 summation orders of the same products differ by at most gamma |q^| |g^| <= eps = margin / 2
+    // (DESIGN section 4), and the verification below has no slack of its own: with exact duplicates at rank r the threshold
+    // would sit an ulp above the scores the scoring launch gives those very rows.  Half a margin more keeps them.
+    const float margin = margin_q * (1.0f + order_slack);
+    // thr = score(r) - margin (>= the rigorous L_sample - margin since r < K); thr2 = score(min(4r, K)) - margin
+    // minus the margin: the verification asks for L - margin >= thr, and L >= score(r) is what the rank guarantees
+    const float thr = key2f(key1) - margin, thr2 = key2f(key2) - margin;
+    const bool excluded = thr_in == INFINITY;                          // query excluded at init (range overflow)
+    st.thr[q] = excluded ? INFINITY : thr;
+    st.thr2[q] = excluded ? INFINITY : thr2;
+    st.cnt[q * CNT_STRIDE] = 0;
+    if (st.lad_tc) {
+      // ladder level: t_c = score(lad_r), lad_r < r, so t_c >= score(r) >= every threshold a wave applies and every row
+      // with approx >= t_c is emitted and counted; once K are counted, L >= t_c and t_c - margin is a rigorous threshold
+      const bool on = lad_r > 0 && !excluded;
+      const float tc = on ? key2f(key3) : INFINITY;
+      st.lad_tc[q] = tc;
+      st.lad_pack[q] = bf16_down(excluded ? INFINITY : thr) | (bf16_down(on ? tc - margin : INFINITY) << 16);
+      st.lad_cnt[q] = 0;
+    }
+  }
+}
+
 constexpr int SAMP_THREADS = 512;                          // x SAMP_PER_THREAD (2, 4, 8, 16) = 1024 ... 8192 sample scores; 48 = 24 576
                                                            // (round 6: the sample of shards beyond 160 x 8192 rows; 4-byte scores only)
 template <int SAMP_PER_THREAD>
@@ -524,29 +553,68 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_kernel(QuerySta
     key2 = block_kth_largest_f(keys, (uint32_t)(SAMP_THREADS * LDS_PER), rest_at, n, w2, hist);
     if (lad_r > 0) key3 = block_kth_largest_f(keys, (uint32_t)(SAMP_THREADS * LDS_PER), rest_at, n, (uint32_t)lad_r, hist);
   }
-  if (threadIdx.x == 0) {
-    // order_slack: the sample scores were summed in another order than the scoring launch sums (K-split bootstrap,
-    // ScoreArgs::ksplit).  Two f32 summation orders of the same products differ by at most gamma |q^| |g^| <= eps = margin / 2
-    // (DESIGN section 4), and the verification below has no slack of its own: with exact duplicates at rank r the threshold
-    // would sit an ulp above the scores the scoring launch gives those very rows.  Half a margin more keeps them.
-    const float margin = margin_q * (1.0f + order_slack);
-    // thr = score(r) - margin (>= the rigorous L_sample - margin since r < K); thr2 = score(min(4r, K)) - margin
-    // minus the margin: the verification asks for L - margin >= thr, and L >= score(r) is what the rank guarantees
-    const float thr = key2f(key1) - margin, thr2 = key2f(key2) - margin;
-    const bool excluded = thr_in == INFINITY;                          // query excluded at init (range overflow)
-    st.thr[q] = excluded ? INFINITY : thr;
-    st.thr2[q] = excluded ? INFINITY : thr2;
-    st.cnt[q * CNT_STRIDE] = 0;
-    if (st.lad_tc) {
-      // ladder level: t_c = score(lad_r), lad_r < r, so t_c >= score(r) >= every threshold a wave applies and every row
-      // with approx >= t_c is emitted and counted; once K are counted, L >= t_c and t_c - margin is a rigorous threshold
-      const bool on = lad_r > 0 && !excluded;
-      const float tc = on ? key2f(key3) : INFINITY;
-      st.lad_tc[q] = tc;
-      st.lad_pack[q] = bf16_down(excluded ? INFINITY : thr) | (bf16_down(on ? tc - margin : INFINITY) << 16);
-      st.lad_cnt[q] = 0;
+  if (threadIdx.x == 0) store_sample_thresholds(st, q, key1, key2, key3, lad_r, margin_q, thr_in, order_slack);
+}
+
+// The same for the 65 536-row sample of shards beyond 160 x 24 576 rows (round 6: the 10 M-row gallery of BASELINE configs[3]
+// on one or two GPUs): the scores do not fit a survivor row, the bootstrap launch writes them to a buffer of their own
+// (ScoreArgs::samp_out, [queries][ld] floats), and they are read twice here instead of being held in registers -- once for the
+// per-thread maxima, once to gather the few dozen values at or above the (4 r)-th largest maximum.  Same answers' contract:
+// the r-th, (4 r)-th and lad_r-th largest of the n sample scores, exactly.
+__global__ __launch_bounds__(SAMP_THREADS) void sample_threshold_big_kernel(QueryState st, const float* __restrict__ scores,
+                                                                            uint32_t ld, uint32_t n, int32_t k, int32_t spec_r,
+                                                                            int32_t lad_r, float order_slack) {
+  __shared__ uint32_t keys[SAMP_THREADS];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[1024];
+  __shared__ uint32_t sh[8];
+  const uint32_t q = blockIdx.x;
+  const float margin_q = st.margin[q], thr_in = st.thr[q];
+  const float* sc = scores + (uint64_t)q * ld;
+  uint32_t kmax = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += SAMP_THREADS) kmax = max(kmax, f2key(sc[i]));
+  const uint32_t w1 = (uint32_t)spec_r, w2 = (uint32_t)min(4 * spec_r, k);
+  keys[threadIdx.x] = kmax;
+  if (threadIdx.x == 0) { sh[3] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
+  __syncthreads();
+  const uint32_t t0 = block_kth_largest(keys, SAMP_THREADS, w2, hist);      // <= the w2-th largest score overall
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += SAMP_THREADS) {
+    const uint32_t kv = f2key(sc[i]);
+    if (kv >= t0 && kv != 0u) {
+      const uint32_t pos = atomicAdd(&sh[3], 1u);
+      if (pos < 256) hist[pos] = kv;
     }
   }
+  __syncthreads();
+  const uint32_t m = sh[3];
+  uint32_t key1, key2, key3 = 0;
+  if (m <= 256) {
+    if (threadIdx.x < m) {
+      const uint32_t me = hist[threadIdx.x];
+      uint32_t gt = 0, ge = 0;
+      for (uint32_t j = 0; j < m; ++j) { gt += hist[j] > me; ge += hist[j] >= me; }
+      if (gt < w1 && w1 <= ge) sh[4] = me;
+      if (gt < w2 && w2 <= ge) sh[5] = me;
+      if (lad_r > 0 && gt < (uint32_t)lad_r && (uint32_t)lad_r <= ge) sh[6] = me;
+    }
+    __syncthreads();
+    key1 = sh[4];
+    key2 = sh[5];
+    key3 = sh[6];
+  } else {                                                  // a crowd of ties: plain selects over all keys, from memory
+    __syncthreads();
+    auto rest_at = [&](uint32_t i) -> uint32_t { return f2key(sc[i]); };
+    key1 = block_kth_largest_f(keys, 0u, rest_at, n, w1, hist);
+    key2 = block_kth_largest_f(keys, 0u, rest_at, n, w2, hist);
+    if (lad_r > 0) key3 = block_kth_largest_f(keys, 0u, rest_at, n, (uint32_t)lad_r, hist);
+  }
+  if (threadIdx.x == 0) store_sample_thresholds(st, q, key1, key2, key3, lad_r, margin_q, thr_in, order_slack);
+}
+
+void launch_sample_threshold_big(QueryState st, const float* scores, uint32_t ld, uint32_t n, int32_t nq, int32_t k,
+                                 int32_t spec_r, int32_t lad_r, float order_slack, hipStream_t stream) {
+  hipLaunchKernelGGL(sample_threshold_big_kernel, dim3(nq), dim3(SAMP_THREADS), 0, stream, st, scores, ld, n, k, spec_r, lad_r,
+                     order_slack);
 }
 
 bool sample_threshold_applies(uint32_t first_cnt, int32_t k, int32_t spec_r) {

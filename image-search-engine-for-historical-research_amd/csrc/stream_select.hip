@@ -172,7 +172,8 @@ __global__ __launch_bounds__(512) void stream_select_kernel(ScoreArgs p) {
           const uint32_t q = q0 + qi;
           if (q >= (uint32_t)p.nq) break;
           uint64_t* dst = p.st.surv + (uint64_t)q * p.st.cap + row0;
-          float* dstf = reinterpret_cast<float*>(p.st.surv + (uint64_t)q * p.st.cap) + row0;
+          float* dstf = p.samp_out ? p.samp_out + (uint64_t)q * p.samp_ld + row0
+                                   : reinterpret_cast<float*>(p.st.surv + (uint64_t)q * p.st.cap) + row0;
 #pragma unroll
           for (int it = 0; it < TILE / 64; ++it) {
             const uint32_t rl = it * 64 + lane;

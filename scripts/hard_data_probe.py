@@ -28,7 +28,11 @@ for ci, kind in enumerate(("nonneg", "clustered", "near_duplicates")):
     sg = ShardedGallery(gal)
     for nq in (1024, 70, 1):
         q = queries(nq).contiguous()
-        for name, opts in (("speculative", {}), ("chunks", {"speculative": 0}), ("f32", {"force_exact": 1})):
+        stages = (("speculative", {}), ("chunks", {"speculative": 0}), ("f32", {"force_exact": 1}))
+        if os.environ.get("PROBE_STAGES") == "sample_vs_chunk":
+            # large shards (PROBE_ROWS > 1.3 M): the 24 576-row hashed sample against the chunk schedule (first rows as the sample)
+            stages = (("hashed_sample", {}), ("chunk_schedule", {"spec_max_ratio": 20}))
+        for name, opts in stages:
             for o, v in opts.items():
                 gal.set_option(o, v)
             gal.flags()
@@ -38,10 +42,10 @@ for ci, kind in enumerate(("nonneg", "clustered", "near_duplicates")):
             fl = gal.flags()
             st = gal.status(reset=True)
             for o in opts:
-                gal.set_option(o, {"speculative": 1, "force_exact": 0}[o])
+                gal.set_option(o, {"speculative": 1, "force_exact": 0, "spec_max_ratio": 160}[o])
             print("  q%-5d %-12s flags=%2d survivors/q=%9.1f candidates/q=%8.1f" %
                   (nq, name, fl, st["survivors"] / max(1, st["queries"]), st["candidates"] / max(1, st["queries"])), flush=True)
-            if name == "speculative" and nq > 128:
+            if name in ("speculative", "hashed_sample") and nq > 128:
                 import numpy as np
                 cyc = gal.debug_cycles(2048)
                 rec = cyc[:, 3].astype(np.int64)

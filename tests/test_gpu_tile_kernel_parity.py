@@ -94,7 +94,7 @@ def test_large_shard_chunk_schedule_equals_exact_path(lib, img):
     1.25 M) is too large for the 8192-row sample.  Round 6: it gets a hashed sample of 24 576 rows and the single filtered
     launch of every other shard; with `spec_max_ratio` lowered the geometric chunk schedule of csrc/api_schedule.hip
     phase1_batch (rigorous thresholds from the rows seen so far, then one speculative launch for the rest) answers it, as it
-    does shards beyond 10.3 M rows.  All must equal the f32-scored path bit for bit; bf16 is the image type configs[3] names."""
+    does shards beyond 160 x 24 576 = 3.93 M rows.  All must equal the f32-scored path bit for bit; bf16 is the image type configs[3] names."""
     n, d, nq, k = 1600000, 256, 300, 100
     raw = _device_rows(lib, 51, n, d)
     q = _device_rows(lib, 52, nq, d)
@@ -113,7 +113,7 @@ def test_large_shard_chunk_schedule_equals_exact_path(lib, img):
         st = g.status()
         assert st["overflow_batches"] == 0 and st["spec_retries"] == 0
         assert idx[5, 0] == 1234567 and abs(sc[5, 0] - 1.0) < 1e-6
-        g.set_option("spec_max_ratio", 20)                        # 1.6 M / 24 576 = 65 > 20 x 2.625: the chunk schedule
+        g.set_option("spec_max_ratio", 20)                        # 1.6 M / 24 576 = 65 > 20: the chunk schedule
         assert g.get_option("sample_rows") == 8192
         idx_c, sc_c = _search(g, q, k)
         assert np.array_equal(idx, idx_c) and np.array_equal(sc, sc_c)
