@@ -40,6 +40,7 @@ int mi_gallery_destroy(mi_gallery* g) {
   }
   (void)hipFree(g->samp_img);
   (void)hipFree(g->samp_scores);
+  (void)hipFree(g->samp_f32);
   for (void* b : g->io_buf) (void)hipFree(b);
   (void)hipFree(g->dif_ids);
   (void)hipFree(g->dif_vals);

@@ -148,6 +148,8 @@ struct mi_gallery {
   // bootstrap sample image of the speculative schedule (built lazily, rebuilt when rows were appended)
   void* samp_img = nullptr;
   int64_t samp_tiles = 0, samp_for_n = -1;
+  float* samp_f32 = nullptr;       // the 8192-row sample as stored f32 rows (built when the f32 scorer first needs its thresholds)
+  int64_t samp_f32_for_n = -1, samp_f32_tiles = 0;
   float* samp_scores = nullptr;    // [QB][samp_tiles * 256] scores of a sample too large for a survivor row (shards beyond 3.9 M rows)
   int64_t samp_scores_tiles = 0;
   int64_t hbm_bytes = 0;

@@ -77,6 +77,21 @@ int64_t bootstrap_tiles(const mi_gallery* g) { return g->chunk0_tiles > 0 ? g->c
 constexpr int64_t BIG_SAMPLE_TILES = 96;      // threshold sample of shards too large for the 32-tile one (plan_phase1)
 constexpr int64_t HUGE_SAMPLE_TILES = 256;    // ... and for the 96-tile one: 65 536 rows, scores in a buffer of the handle's own
 
+// the sample as f32 rows (f32 scorer on the sample schedule)
+static int ensure_sample_f32(mi_gallery* g, int64_t tiles, hipStream_t s) {
+  if (g->samp_f32 && g->samp_f32_tiles == tiles && g->samp_f32_for_n == g->n) return MI_OK;
+  if (!g->samp_f32 || g->samp_f32_tiles != tiles) {
+    (void)hipFree(g->samp_f32);
+    g->samp_f32 = nullptr;
+    HIPC(device_malloc((void**)&g->samp_f32, (size_t)tiles * TILE * g->dp * sizeof(float)));
+    g->samp_f32_tiles = tiles;
+  }
+  launch_build_sample_f32(g->gal_f32, g->samp_f32, g->n, tiles * TILE, g->dp, s);
+  HIPC(hipGetLastError());
+  g->samp_f32_for_n = g->n;
+  return MI_OK;
+}
+
 // (re)build the bootstrap sample image for the current number of rows
 static int ensure_sample(mi_gallery* g, int64_t tiles, hipStream_t s) {
   if (g->samp_img && g->samp_tiles == tiles && g->samp_for_n == g->n && (tiles <= BIG_SAMPLE_TILES || g->samp_scores_tiles == tiles))
@@ -120,13 +135,18 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
   t0 = std::min<int64_t>(t0, ws.cap / TILE);
   t0 = std::min<int64_t>(t0, pl.ntiles);
   pl.t0 = t0;
+  // The f32 scorer (exact: `force_exact`, or the re-run of a batch whose buffers overflowed) takes its thresholds from the
+  // hashed sample too since round 6: its chunk schedule bootstrapped from the FIRST rows of the shard, which on a gallery
+  // stored cluster by cluster let the survivor buffers overflow.  Its sample is the 8192-row one as stored f32
+  // rows, scored by the f32 kernel itself -- no 16-bit margin enters (on raw galleries whose row norms differ 60 x the
+  // 16-bit margin is what sent the batch here) --, admitted up to 3 x spec_max_ratio rows per sample row (3.93 M rows).
   // Single-launch schedule?  The speculative threshold is an order statistic of the scores of a SAMPLE: t0 * 256
   // rows drawn evenly (one hashed draw per stratum) into their own small image, so that the order in which the shard
   // was ingested cannot bias it.  With n_s sampled rows the shard's K-th largest score sits near sample rank
   // lambda = K * n_s / N; the r-th largest sample score with r = spec_rank(lambda) lies below it except with
   // probability 1e-7 per query (Poisson tail) and keeps the expected survivors at r * N / n_s.  The sample entries
   // are dropped once the threshold is taken (the scoring launch visits every tile, sample rows included).
-  if (g->speculative && !exact && pl.ntiles >= 2 * t0 && g->n / (t0 * TILE) <= g->spec_max_ratio) {
+  if (g->speculative && pl.ntiles >= 2 * t0 && g->n / (t0 * TILE) <= (exact ? 3 : 1) * (int64_t)g->spec_max_ratio) {
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
     const int32_t r = spec_rank(lambda);
     if (r < k) pl.samp_r = r;
@@ -165,10 +185,10 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
   }
   pl.first_cnt = (uint32_t)(pl.samp_r > 0 ? t0 * TILE : std::min<int64_t>(g->n, t0 * TILE));
   pl.gamma = 2.0f * (float)g->dp * 5.9604645e-08f;  // 2 * dp * 2^-24 (f32 accumulation, doubled)
-  pl.thr_kernel = pl.samp_r > 0 && (pl.samp_ext || sample_threshold_applies(pl.first_cnt, k, pl.samp_r));
+  pl.thr_kernel = pl.samp_r > 0 && !exact && (pl.samp_ext || sample_threshold_applies(pl.first_cnt, k, pl.samp_r));
   // small batches on the sample schedule: the bootstrap launch splits K over several workgroups per (sample tile, query
   // group) and adds its partial scores onto zeros that the query ingest writes (ScoreArgs::ksplit)
-  if (pl.samp_r > 0 && !exact && g->boot_ksplit && g->small_batch_kernel && pl.thr_kernel && g->dp <= 4096) {
+  if (pl.samp_r > 0 && g->boot_ksplit && g->small_batch_kernel && pl.thr_kernel && g->dp <= 4096) {
     const int64_t wgs = t0 * ((nq + 63) / 64);                       // bootstrap workgroups of a batch of <= 512 queries
     if (nq <= 512)
       while (pl.boot_ksplit < 8 && wgs * pl.boot_ksplit * 2 <= 256 && (g->dp / SLICE_K) % (pl.boot_ksplit * 2) == 0)
@@ -181,7 +201,7 @@ static P1Plan plan_phase1(const mi_gallery* g, const Workspace& ws, int32_t nq, 
   // been counted during the launch.  In units of N / n_s rows: score(j) has expected rank j in the shard and is validated
   // after the fraction lambda / j of the rows (lambda = K n_s / N), so the survivors are ~ (lambda / j) r + (1 - lambda / j) j,
   // smallest at j = sqrt(lambda r) (3 at N = 1M, K = 100: 1500 -> 900 survivors per query)
-  if (g->ladder && pl.samp_r > 1 && pl.thr_kernel) {
+  if (g->ladder && !exact && pl.samp_r > 1 && pl.thr_kernel) {
     const double lambda = (double)k * (double)(t0 * TILE) / (double)g->n;
     int32_t lr = (int32_t)std::lround(std::sqrt(lambda * pl.samp_r));
     pl.lad_r = std::max<int32_t>(1, std::min<int32_t>(lr, pl.samp_r - 1));
@@ -207,21 +227,34 @@ static int p1_pre(mi_gallery* g, Workspace& ws, const P1Plan& pl, const void* q_
                   int q_norm, hipStream_t s) {
   QueryState st = make_state(ws);
   if (pl.samp_r > 0) {
-    const int rc = ensure_sample(g, pl.t0, s);
+    const int rc = pl.exact ? ensure_sample_f32(g, pl.t0, s) : ensure_sample(g, pl.t0, s);
     if (rc != MI_OK) return rc;
   }
   int32_t boot_ksplit = pl.boot_ksplit;
+  const int use_img = pl.exact ? 0 : 1;
   // query ingest (normalise, f32 rows, 16-bit image, rounding norms) and the per-query search state in one launch
   if (!launch_ingest_queries(q_src, q_dtype, pl.nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp,
-                             pl.qpad, g->gstat3, pl.gamma, pl.exact ? 0 : 1, pl.first_cnt, st, s,
+                             pl.qpad, g->gstat3, pl.gamma, use_img, pl.first_cnt, st, s,
                              boot_ksplit > 1 ? pl.first_cnt : 0u)) {
     boot_ksplit = 1;
     launch_ingest(q_src, q_dtype, pl.nq, g->d, q_rs, q_cs, q_norm, ws.q_f32, ws.q_img, g->img_f16, ws.q_stat, g->dp, pl.qpad, s);
-    launch_init_query_state(ws.q_stat, g->gstat3, pl.nq, pl.qpad, pl.gamma, pl.exact ? 0 : 1, pl.first_cnt, st, s);
+    launch_init_query_state(ws.q_stat, g->gstat3, pl.nq, pl.qpad, pl.gamma, use_img, pl.first_cnt, st, s);
   }
   if (pl.samp_r > 0) {
     P1Plan p2 = pl;
     p2.boot_ksplit = boot_ksplit;
+    if (pl.exact) {                                    // f32 scorer: the sample's f32 rows, every exact score stored
+      ExactArgs a;
+      a.gal_f32 = g->samp_f32;
+      a.qry_f32 = ws.q_f32;
+      a.dp = g->dp;
+      a.row0 = 0;
+      a.row1 = pl.t0 * TILE;
+      a.n = pl.t0 * TILE;
+      a.nq = pl.nq;
+      a.st = st;
+      launch_exact_select(a, true, s);
+    } else
     p1_score_launch(g, ws, st, p2, 0, pl.t0, true, nullptr, false, true, false, s);     // bootstrap on the sample image
     if (pl.thr_kernel && pl.samp_ext)
       launch_sample_threshold_big(st, g->samp_scores, (uint32_t)(pl.t0 * TILE), pl.first_cnt, pl.nq, pl.k, pl.samp_r, pl.lad_r,
@@ -328,8 +361,10 @@ static int p1_main(mi_gallery* g, Workspace& ws, const P1Plan& pl, hipStream_t s
     // of a failed query repairs it inside the maintain launch (repair mode 3, select.hip SCAN: a scan of the shard's stored
     // rows by that one workgroup, ~0.1 s per 1 M rows, once per 10^7 queries).  "device_repair" = 1 still forces the launches.
     const bool small = nq <= STREAM_MAX_QUERIES;     // (in-kernel repair up to 1024 queries: measured slower, profiles/r04q_*)
-    const bool repair_pass = g->device_repair < 0 ? !small : g->device_repair != 0;
-    const int rep_mode = repair_pass ? 0 : ((small && !caller_checks_flags && g->device_repair < 0) ? 3 : 2);
+    // (the f32 scorer has no conditional launch: a failed threshold is final there, FLAG_SPEC_FAIL, and the caller goes on to
+    // the dense path)
+    const bool repair_pass = !exact && (g->device_repair < 0 ? !small : g->device_repair != 0);
+    const int rep_mode = repair_pass ? 0 : ((small && !caller_checks_flags && g->device_repair < 0 && !exact) ? 3 : 2);
     const RepairScan scan{g->gal_f32, ws.q_f32, g->dp, g->n, ws.stats2 + 2 * (size_t)QB};
     launch_select_maintain(st, nq, k, 1, ws.topvals, ws.L, ws.stats2, 0, 1, rep_mode, nullptr, s, fc_rows, fc_cnt, ws.rcap,
                            rep_mode == 3 ? &scan : nullptr);

@@ -1144,6 +1144,19 @@ void launch_build_sample(const void* gal_img, void* samp_img, int64_t n, int64_t
                      dp / SLICE_K);
 }
 
+// the same sample as stored f32 rows (the f32 scorer takes its thresholds from exact scores of the sample rows, round 6)
+__global__ __launch_bounds__(256) void build_sample_f32_kernel(const float* __restrict__ gal_f32, float* __restrict__ samp_f32,
+                                                               int64_t n, int64_t n_s, int32_t dp) {
+  const int64_t i = blockIdx.x;
+  const float4* src = reinterpret_cast<const float4*>(gal_f32 + sample_source_row(i, n, n_s) * dp);
+  float4* dst = reinterpret_cast<float4*>(samp_f32 + i * dp);
+  for (int j = threadIdx.x; j < dp / 4; j += blockDim.x) dst[j] = src[j];
+}
+
+void launch_build_sample_f32(const float* gal_f32, float* samp_f32, int64_t n, int64_t n_s, int32_t dp, hipStream_t stream) {
+  hipLaunchKernelGGL(build_sample_f32_kernel, dim3((uint32_t)n_s), dim3(256), 0, stream, gal_f32, samp_f32, n, n_s, dp);
+}
+
 int64_t sample_source_row_host(int64_t i, int64_t n, int64_t n_s) { return sample_source_row(i, n, n_s); }
 
 }  // namespace mi

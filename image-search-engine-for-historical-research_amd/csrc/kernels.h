@@ -19,6 +19,7 @@ bool launch_ingest_queries(const void* src, int dtype, int32_t nq, int32_t d, in
                            hipStream_t stream, uint32_t zero_scores = 0);
 // bootstrap sample image (n_s = multiple of TILE rows, one hashed draw per stratum of the shard)
 void launch_build_sample(const void* gal_img, void* samp_img, int64_t n, int64_t n_s, int32_t dp, hipStream_t stream);
+void launch_build_sample_f32(const float* gal_f32, float* samp_f32, int64_t n, int64_t n_s, int32_t dp, hipStream_t stream);
 int64_t sample_source_row_host(int64_t i, int64_t n, int64_t n_s);   // row_base: output rows start here (gallery append); src row 0 <-> row_base
 void launch_checksum(const void* data, size_t bytes, unsigned long long* out_dev, hipStream_t stream);   // bytes % 8 == 0
 void launch_rowstat_max(const RowStat* rowstat, int64_t n, float* out3, hipStream_t stream, bool reset = true);
