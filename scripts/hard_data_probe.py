@@ -22,6 +22,7 @@ for ci, kind in enumerate(("nonneg", "clustered", "near_duplicates")):
     if kind not in kinds:
         continue
     raw, queries, desc = bench._hard_rows(kind, n, d, dev, 1234 + 500 + ci)
+    torch.cuda.synchronize()
     gal = _lib.Gallery.from_device_ptr(raw.data_ptr(), n, d, norm_mode=_lib.NORM_L2, device=0)
     del raw
     print("==", kind, desc, "norm bounds", gal.norm_bounds(), "f16", gal.get_option("image_dtype"), flush=True)

@@ -92,6 +92,10 @@ def test_workspace_is_not_recycled_under_a_search_in_flight():
     by launches on a caller's non-blocking stream when the next handle took and cleared it.  tests/_hazard.py is the scenario;
     scripts/recycle_hazard_ab.sh runs the same function against a build without the synchronisation in ws_free, where it
     fails (profiles/r06_recycle_hazard_ab.txt)."""
+    from isehr_amd import _lib
     from _hazard import recycle_scenario
-    bad, rounds = recycle_scenario()
+    try:
+        bad, rounds = recycle_scenario()               # (the scenario needs the spare slots: it switches them on)
+    finally:
+        _lib.set_global_option("keep_buffers", _session_mode())
     assert bad == 0, "a search in flight was disturbed in %d of %d rounds" % (bad, rounds)

@@ -34,6 +34,7 @@ def test_clustered_gallery_against_the_oracle_itself():
     import bench                                     # the generator of the `hard_data` block (data only)
     dev = torch.device("cuda", 0)
     raw, queries, _ = bench._hard_rows("clustered", N, D, dev, 1234 + 501)
+    torch.cuda.synchronize()                         # torch wrote the rows on ITS stream; the ingest runs on the handle's own
     g = _lib.Gallery.from_device_ptr(raw.data_ptr(), N, D)
     del raw
     torch.cuda.empty_cache()
