@@ -198,6 +198,8 @@ class Gallery:
     @classmethod
     def from_device_ptr(cls, ptr, n, d, norm_mode=NORM_L2, device=0, row_offset=0, dtype=MI_F32, row_stride=None,
                         col_stride=1):
+        """Device rows -> gallery, synchronous.  The ingest runs on a stream of the handle's own: the producer of `ptr` must
+        have completed (torch.cuda.synchronize() / stream.synchronize()) before the call; `ptr` may be freed after it."""
         h = C.c_void_p()
         check(load().mi_gallery_create(C.c_void_p(ptr), n, d, dtype, d if row_stride is None else row_stride,
                                        col_stride, MI_DEVICE, norm_mode, device, row_offset, C.byref(h)))

@@ -38,8 +38,12 @@ __global__ __launch_bounds__(256, 2) void whiten_mfma_kernel(const InT* __restri
                                                              const double* __restrict__ P /*[dims][d]*/, int32_t dims,
                                                              double* __restrict__ Y /*[n][ldy]*/, int64_t ldy, uint32_t ncb,
                                                              uint32_t nrb) {
-  __shared__ double Xs[W_TILE * W_LD];
-  __shared__ double Ps[W_TILE * W_LD];
+  // two buffers per operand (73.7 KB of dynamic LDS per workgroup, two workgroups per CU): chunk c + 1 is written into the other
+  // buffer while chunk c is multiplied, ONE barrier per chunk (the first version had one buffer and two barriers per 64 MFMAs:
+  // matrix pipe busy 0.69, profiles/r06z_whiten_pmc.txt)
+  extern __shared__ __attribute__((aligned(16))) double w_lds[];
+  double* const Xs0 = w_lds;
+  double* const Ps0 = w_lds + 2 * W_TILE * W_LD;
   const uint32_t b = blockIdx.x;
   uint32_t cb, rt;
   if ((ncb & 7u) == 0) {
@@ -54,48 +58,59 @@ __global__ __launch_bounds__(256, 2) void whiten_mfma_kernel(const InT* __restri
   const int wr = w >> 1, wc = w & 1, l15 = lane & 15, lq = lane >> 4;
   const int64_t row0 = (int64_t)rt * W_TILE;
   const int32_t col0 = (int32_t)cb * W_TILE;
-  // element i of this thread in an operand chunk: X (r, kk) = (xr0 + xdr * i, xk0 + xdk * i), P (pj0 + 16 i, pk)
-  const int xr0 = ROWS ? t / W_KC : t % W_TILE, xdr = ROWS ? 256 / W_KC : 0;
-  const int xk0 = ROWS ? t % W_KC : t / W_TILE, xdk = ROWS ? 0 : 256 / W_TILE;
+  // element i of this thread in an operand chunk: X (r, kk) = (xr0 + xdr * (i & 1 | rows: i), xk0 + xdk * (i >> 1)),
+  // P (pj0 + 16 i, pk).  ROWS: 16 consecutive k of 16 rows per instruction and thread-constant k (one mean per thread and
+  // chunk); otherwise 64 consecutive rows of one k per wave and instruction, k = wave + 4 j: four means per thread and chunk
+  constexpr int NM = ROWS ? 1 : W_PER / 2;
+  const int xr0 = ROWS ? t / W_KC : t % 64, xk0 = ROWS ? t % W_KC : t / 64;
+  auto x_r = [&](int i) { return ROWS ? xr0 + (256 / W_KC) * i : xr0 + 64 * (i & 1); };
+  auto x_k = [&](int i) { return ROWS ? xk0 : xk0 + 4 * (i >> 1); };
   const int pj0 = t / W_KC, pk = t % W_KC;
   const bool interior = row0 + W_TILE <= n && col0 + W_TILE <= dims;
   const InT* xp0 = X + (row0 + xr0) * rs + (int64_t)xk0 * cs;
   const double* pp0 = P + (int64_t)(col0 + pj0) * d + pk;
-  const int64_t xstep = (int64_t)xdr * rs + (int64_t)xdk * cs;
 
   InT xr[W_PER];
-  double pr[W_PER];
+  double pr[W_PER], mr[NM];
+  bool fast = false;                                        // the chunk in the registers lies inside X and P: no masking
   auto load_chunk = [&](int32_t k0) {
-    if (interior && k0 + W_KC <= d) {
+    fast = interior && k0 + W_KC <= d;
+    // the means of this thread's k: fetched with the chunk (a load at the point of use stalls the store phase on its round
+    // trip, once per element -- the first version of this kernel did), clamped index, no branch
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const int32_t k = k0 + xk0 + 4 * j;
+      mr[j] = m[k < d ? k : d - 1];
+    }
+    if (fast) {
       const InT* xp = xp0 + (int64_t)k0 * cs;
       const double* pp = pp0 + k0;
 #pragma unroll
       for (int i = 0; i < W_PER; ++i) {
-        xr[i] = *xp;
-        pr[i] = *pp;
-        xp += xstep;
-        pp += (int64_t)(256 / W_KC) * d;
+        xr[i] = ROWS ? xp[(int64_t)(256 / W_KC) * i * rs] : xp[(int64_t)(64 * (i & 1)) * rs + (int64_t)(4 * (i >> 1)) * cs];
+        pr[i] = pp[(int64_t)(256 / W_KC) * i * d];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < W_PER; ++i) {
-        const int64_t row = row0 + xr0 + xdr * i;
-        const int32_t k = k0 + xk0 + xdk * i;
+        const int64_t row = row0 + x_r(i);
+        const int32_t k = k0 + x_k(i);
         xr[i] = (row < n && k < d) ? X[row * rs + (int64_t)k * cs] : (InT)0;
         const int32_t pj = col0 + pj0 + (256 / W_KC) * i;
         pr[i] = (pj < dims && k0 + pk < d) ? P[(int64_t)pj * d + k0 + pk] : 0.0;
       }
     }
   };
-  auto store_chunk = [&](int32_t k0) {
+  auto store_chunk = [&](int32_t k0, int buf) {
+    double* const Xs = Xs0 + buf * W_TILE * W_LD;
+    double* const Ps = Ps0 + buf * W_TILE * W_LD;
 #pragma unroll
     for (int i = 0; i < W_PER; ++i) {
-      const int r = xr0 + xdr * i, kk = xk0 + xdk * i;
-      const int32_t k = k0 + kk;
-      // padded rows / k: zero; a valid element is centred in float64 exactly like `X - m` promotes in the reference
-      // (the mean is fetched unconditionally at a clamped index: no branch per element)
-      const double mk = m[k < d ? k : d - 1];
-      Xs[r * W_LD + kk] = (row0 + r < n && k < d) ? (double)xr[i] - mk : 0.0;
+      const int r = x_r(i), kk = x_k(i);
+      // centred in float64 exactly like `X - m` promotes in the reference; padded rows / k: zero
+      double v = (double)xr[i] - mr[ROWS ? 0 : i >> 1];
+      if (!fast) v = (row0 + r < n && k0 + kk < d) ? v : 0.0;
+      Xs[r * W_LD + kk] = v;
       Ps[(pj0 + (256 / W_KC) * i) * W_LD + pk] = pr[i];
     }
   };
@@ -106,16 +121,13 @@ __global__ __launch_bounds__(256, 2) void whiten_mfma_kernel(const InT* __restri
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-  const double* xa = Xs + (wr * 64 + l15) * W_LD + lq;     // A[i = lane & 15][k = lane >> 4]
-  const double* pb = Ps + (wc * 64 + l15) * W_LD + lq;     // B[k = lane >> 4][j = lane & 15] = P[j][k]
-  load_chunk(0);
-  for (int32_t k0 = 0; k0 < d; k0 += W_KC) {
-    __syncthreads();                                       // every wave is done with the previous chunk's fragments
-    store_chunk(k0);
-    __syncthreads();
-    if (k0 + W_KC < d) load_chunk(k0 + W_KC);              // in flight under this chunk's MFMAs
+  const int xa_off = (wr * 64 + l15) * W_LD + lq;          // A[i = lane & 15][k = lane >> 4]
+  const int pb_off = (wc * 64 + l15) * W_LD + lq;          // B[k = lane >> 4][j = lane & 15] = P[j][k]
+  auto mfma_steps = [&](int buf, int ks0, int ks1) {
+    const double* xa = Xs0 + buf * W_TILE * W_LD + xa_off;
+    const double* pb = Ps0 + buf * W_TILE * W_LD + pb_off;
 #pragma unroll
-    for (int ks = 0; ks < W_KC / 4; ++ks) {
+    for (int ks = ks0; ks < ks1; ++ks) {
       double a[4], bb[4];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) a[mi] = xa[mi * 16 * W_LD + ks * 4];
@@ -126,6 +138,18 @@ __global__ __launch_bounds__(256, 2) void whiten_mfma_kernel(const InT* __restri
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
     }
+  };
+  load_chunk(0);
+  store_chunk(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int32_t k0 = 0; k0 < d; k0 += W_KC, buf ^= 1) {
+    const bool more = k0 + W_KC < d;
+    if (more) load_chunk(k0 + W_KC);                       // in flight under the first three quarters of this chunk's MFMAs
+    mfma_steps(buf, 0, 3);
+    if (more) store_chunk(k0 + W_KC, buf ^ 1);             // the other buffer: nobody reads it before the barrier below
+    mfma_steps(buf, 3, W_KC / 4);
+    __syncthreads();                                       // chunk c + 1 is complete, chunk c's fragments are done with
   }
   // C layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * register
 #pragma unroll
@@ -184,9 +208,13 @@ void launch_whiten(const void* X, int dtype, int64_t n, int32_t d, int64_t rs, i
   const uint32_t ncb = (uint32_t)((dims + W_TILE - 1) / W_TILE), nrb = (uint32_t)((n + W_TILE - 1) / W_TILE);
   const dim3 grid(ncb * nrb), block(256);
   const int64_t ldy = dims;
+  const int lds = 4 * W_TILE * W_LD * (int)sizeof(double);          // X and P, two buffers each
 #define MI_W_LAUNCH(T, ROWS)                                                                                            \
-  hipLaunchKernelGGL((whiten_mfma_kernel<T, ROWS>), grid, block, 0, stream, (const T*)X, n, d, rs, cs, m, P, dims, Y, ldy, \
-                     ncb, nrb)
+  do {                                                                                                                  \
+    ensure_dynamic_lds((const void*)whiten_mfma_kernel<T, ROWS>, lds);                                                  \
+    hipLaunchKernelGGL((whiten_mfma_kernel<T, ROWS>), grid, block, lds, stream, (const T*)X, n, d, rs, cs, m, P, dims, Y, \
+                       ldy, ncb, nrb);                                                                                  \
+  } while (0)
   if (dtype == 0) { if (cs == 1) MI_W_LAUNCH(float, true); else MI_W_LAUNCH(float, false); }
   else { if (cs == 1) MI_W_LAUNCH(double, true); else MI_W_LAUNCH(double, false); }
 #undef MI_W_LAUNCH

@@ -56,7 +56,10 @@ int mi_device_count(int* count);
  * (src/utils/nnsearch.py:693-698) and faiss index.add (src/utils/knn.py:17-23).
  * data: element (i,j) at data[i*row_stride + j*col_stride] (strides in elements), n rows, d cols.
  * Builds, resident in HBM: normalised f32 rows [n][d64], the tile-blocked bf16 copy the MFMA
- * kernel streams, and per-row rounding-error norms used for the exactness certificate. */
+ * kernel streams, and per-row rounding-error norms used for the exactness certificate.
+ * Synchronous.  MI_DEVICE data is read on a stream of the handle's own (non-blocking, NOT ordered against any stream of the
+ * caller): whatever produced `data` must have completed -- synchronise the producing stream first -- and the pointer may be
+ * freed as soon as the call returns.  mi_gallery_append_device is the stream-ordered way in. */
 int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t row_stride,
                       int64_t col_stride, int memspace, int norm_mode, int device,
                       int64_t row_offset, mi_gallery** out);
@@ -66,7 +69,7 @@ int mi_gallery_create(const void* data, int64_t n, int32_t d, int dtype, int64_t
 int mi_gallery_create_empty(int64_t capacity, int32_t d, int norm_mode, int device, int64_t row_offset,
                             mi_gallery** out);
 int mi_gallery_append_device(mi_gallery* g, const float* rows_dev /*[m][d] f32*/, int64_t m, void* stream);
-/* Strided append of m rows (f32 | f64, host or device memory; synchronous).  A host column block of a [D, N] array --
+/* Strided append of m rows (f32 | f64, host or device memory; synchronous, device rows must be complete as for create).  A host column block of a [D, N] array --
  * row_stride 1, col_stride N, the layout of the reference's feature pickles and of its 1M-distractor tensor
  * (src/utils/general.py:67-92, src/extract_1m.py:97-98, src/test_rOP1m.py:136-139) -- is packed by one 2-D copy and read
  * with strides on the device: no host transpose, no concatenated host copy, no float64 promotion. */
