@@ -1097,13 +1097,18 @@ def online_block(job, gal, args):
         # through entry/online.py Searcher.query_device, whose worker coalesces the waiting descriptors into one chain
         import threading
         from isehr_amd.entry.online import Searcher
-        nthr, per = 64, 20
+        nthr = 64
         qc = torch.empty((nthr, d), dtype=torch.float32, device=dev)
         _lib.synth_fill_device(qc.data_ptr(), args.seed + 78, 0, nthr, d, stream)
         torch.cuda.synchronize()
+        rows_c = [qc[j] for j in range(nthr)]                         # the requests' descriptors exist before the requests do
         conc = {}
-        for mode, coalesce in (("sequential_calls_same_threads", False), ("coalesced", True)):
-            srv = Searcher.from_galleries(gal, g_raw, k, device=job.dev_index, coalesce=coalesce)
+        # queries per thread: 20 / 84 / 148 (the same last query of every thread, 19 mod 64: the answers are compared), so
+        # that each mode runs for a good fraction of a second
+        for mode, coalesce, native, per in (("sequential_calls_same_threads", False, False, 20),
+                                            ("coalesced_python_worker", True, False, 84), ("coalesced", True, True, 148)):
+            kw = {"max_wait_s": float(os.environ["ISEHR_ONLINE_WAIT_US"]) * 1e-6} if "ISEHR_ONLINE_WAIT_US" in os.environ else {}
+            srv = Searcher.from_galleries(gal, g_raw, k, device=job.dev_index, coalesce=coalesce, native=native, **kw)
             got = [None] * nthr
             errs = []
 
@@ -1111,7 +1116,7 @@ def online_block(job, gal, args):
                 try:
                     torch.cuda.set_device(job.dev_index)
                     for i in range(per):
-                        got[t] = srv.query_device(qc[(t + i) % nthr], return_indices=True)
+                        got[t] = srv.query_device(rows_c[(t + i) % nthr], return_indices=True)
                 except Exception as e:                                # noqa: BLE001
                     errs.append(e)
             srv.query_device(qc[0], return_indices=True)                                        # warm
@@ -1124,17 +1129,34 @@ def online_block(job, gal, args):
             elc = time.perf_counter() - t0
             if errs:
                 raise errs[0]
-            conc[mode] = {"value": nthr * per / elc, "unit": "queries/s", "seconds": elc,
-                          "chains_launched": srv.batches if coalesce else nthr * per,
-                          "mean_requests_per_chain": (srv.batched_requests / max(1, srv.batches)) if coalesce else 1.0}
+            chains, answered = srv.chain_stats if coalesce else (nthr * per, nthr * per)
+            conc[mode] = {"value": nthr * per / elc, "unit": "queries/s", "seconds": elc, "queries_per_thread": per,
+                          "worker": ("library (mi_online_*)" if native else "python thread") if coalesce else None,
+                          "chains_launched": chains, "mean_requests_per_chain": answered / max(1, chains)}
             conc[mode + "_answers"] = np.concatenate(got)
+            if native:
+                # the same front driven by 64 request threads of the library itself (mi_debug_online_clients): what is left
+                # when the clients' interpreter time is taken out -- the figure a compiled host, or a Python host whose
+                # request threads do nothing else under the interpreter lock, sees
+                sec, last = srv._native().native_clients(qc.data_ptr(), nthr, nthr, 148 + 128)
+                c0, a0 = chains, answered
+                chains, answered = srv.chain_stats
+                conc["coalesced_native_clients"] = {
+                    "value": nthr * (148 + 128) / sec, "unit": "queries/s", "seconds": sec, "queries_per_thread": 148 + 128,
+                    "worker": "library (mi_online_*)", "clients": "threads of the library (mi_debug_online_clients)",
+                    "chains_launched": chains - c0, "mean_requests_per_chain": (answered - a0) / max(1, chains - c0),
+                    "equals_sequential_answers": bool(np.array_equal(last, conc["sequential_calls_same_threads_answers"]))}
+                assert conc["coalesced_native_clients"]["equals_sequential_answers"]
             srv.close()
-        same = bool(np.array_equal(conc.pop("sequential_calls_same_threads_answers"), conc.pop("coalesced_answers")))
+        want_c = conc.pop("sequential_calls_same_threads_answers")
+        same = bool(np.array_equal(want_c, conc.pop("coalesced_answers")) and
+                    np.array_equal(want_c, conc.pop("coalesced_python_worker_answers")))
         assert same, "coalesced answers differ from the sequential calls'"
-        conc.update({"client_threads": nthr, "queries_per_thread": per, "equals_sequential_answers": same})
+        conc.update({"client_threads": nthr, "equals_sequential_answers": same})
         return {"gallery_rows": n, "topk": k, "steps": steps, "online_query_ms": el / steps * 1e3, "value": steps / el,
                 "online_query_ms_after_50ms_idle": idle_ms, "online_concurrent": conc,
                 "online_concurrent_qps": conc["coalesced"]["value"],
+                "online_concurrent_native_clients_qps": conc["coalesced_native_clients"]["value"],
                 "unit": "queries/s", "stages": "descriptor on the device -> mi_knn_search_device (K) -> qge1 expansion (k = 3, w = 4) "
                                                "-> re-search -> one D2H of K indices",
                 "score_check": "equals mi_knn_search + mi_aqe_search (host entry points) on the same galleries"}

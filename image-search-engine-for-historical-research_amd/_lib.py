@@ -115,6 +115,13 @@ SIGNATURES = {
     "mi_debug_sample_source_row": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "mi_set_global_option": (C.c_int, [C.c_char_p, C.c_double]),
     "mi_get_global_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
+    "mi_online_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_void_p)]),
+    "mi_online_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_online_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mi_online_destroy": (C.c_int, [C.c_void_p]),
+    "mi_debug_online_clients": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.POINTER(C.c_double)]),
     "mi_synth_fill_device": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
 }
 
@@ -643,3 +650,54 @@ def device_count():
     n = C.c_int()
     check(load().mi_device_count(C.byref(n)))
     return n.value
+
+
+class OnlineChain:
+    """mi_online_*: search -> qge1 expansion -> re-search (src/online.py:108-152) behind one coalescing worker thread of the
+    LIBRARY.  `query` blocks inside the C call -- ctypes releases the interpreter lock -- so the request threads of a Python
+    server cost the interpreter one foreign call each.  g_rows None: the plain search.  The galleries must outlive it."""
+
+    def __init__(self, g_search, g_rows, k, k_qe=3, w=4.0, eps=1e-6, max_batch=128, max_wait_us=500):
+        h = C.c_void_p()
+        check(load().mi_online_create(g_search._h, None if g_rows is None else g_rows._h, k, k_qe, w, eps, max_batch,
+                                      max_wait_us, C.byref(h)))
+        self._h, self.k, self.d = h.value, int(k), g_search.d
+        self._keep = (g_search, g_rows)
+        self._query = load().mi_online_query
+
+    def query(self, ptr, nq, memspace, pending=False, producer_stream=None, scores=False):
+        """ptr: [nq, d] float32 rows (host or device address); pending: device rows still being produced on producer_stream
+        (None = the null stream).  -> idx int64 [nq, k] (, score float32 [nq, k]), host arrays."""
+        if self._keep[0]._h is None or (self._keep[1] is not None and self._keep[1]._h is None):
+            raise RuntimeError("the galleries of this online chain have been closed")
+        idx = np.empty((nq, self.k), dtype=np.int64)
+        sc = np.empty((nq, self.k), dtype=np.float32) if scores else None
+        rc = self._query(self._h, ptr, nq, memspace, 1 if pending else 0, producer_stream,
+                         idx.__array_interface__["data"][0], None if sc is None else sc.__array_interface__["data"][0])
+        if rc:
+            check(rc)
+        return (idx, sc) if scores else idx
+
+    def native_clients(self, desc_ptr, n_desc, threads, per_thread):
+        """Diagnostics: `threads` request threads of the library in a closed loop (mi_debug_online_clients).
+        -> (seconds, last answer of every thread int64 [threads, k])."""
+        last = np.empty((threads, self.k), dtype=np.int64)
+        sec = C.c_double()
+        check(load().mi_debug_online_clients(self._h, desc_ptr, n_desc, threads, per_thread, last.ctypes.data, C.byref(sec)))
+        return sec.value, last
+
+    def stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(load().mi_online_stats(self._h, C.byref(a), C.byref(b)))
+        return {"chains": a.value, "requests": b.value}
+
+    def close(self):
+        if self._h:
+            check(load().mi_online_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355_retrieval.so")
 SOURCES = ["api_state.hip", "api_schedule.hip", "api_gallery.hip", "api_file.hip", "api_entry.hip", "api_aux.hip", "api_options.hip",
+           "api_online.hip",
            "ingest.hip", "gemm_select.hip", "stream_select.hip", "select.hip", "exact_score.hip", "aqe.hip",
            "synth.hip", "dense.hip", "diffusion.hip", "whiten.hip", "desc_tail.hip", "kr_rerank.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]

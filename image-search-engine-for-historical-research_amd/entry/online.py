@@ -37,16 +37,21 @@ class Searcher:
     its rows.  A 70-query launch costs what a single query does (bench.py `q1` / `q70`), so 64 clients cost one chain, not 64.
     The answers are those of sequential calls, bit for bit (the exact re-score defines them, not the batch).  max_wait_s: when
     the recent chains held several requests, the worker waits up to this long for as many to be queued again before the next
-    launch (the callers just answered are on their way back); a lone sequential caller never waits."""
+    launch (the callers just answered are on their way back); a lone sequential caller never waits.
+    native (default): the worker is the LIBRARY's (`mi_online_*`, csrc/api_online.hip): a request thread blocks inside one
+    foreign call, outside the interpreter lock, instead of handing its request to a Python thread under it -- with 64 client
+    threads the interpreter, not the GPU, bounded the Python worker (bench.py `online_concurrent`).  native=False keeps the
+    Python worker (the only one for a chain on sharded galleries of a process group)."""
 
     def __init__(self, vecs, img_paths, K, matching_method="HIP", ifgenerate=False, device=0, coalesce=True, max_batch=128,
-                 max_wait_s=5e-4):
+                 max_wait_s=5e-4, native=True):
         self.vecs, self.img_paths, self.K = vecs, img_paths, K
         self.method, self.ifgenerate, self.device = matching_method, ifgenerate, device
         self._lock = threading.Lock()
         self.coalesce, self.max_batch, self.max_wait_s = bool(coalesce), int(max_batch), float(max_wait_s)
         self._cv = threading.Condition()
         self._queue, self._worker, self._stop = [], None, False
+        self.native, self._native_chain = bool(native), None
         self.batches, self.batched_requests = 0, 0           # statistics: chains launched / requests they answered
 
     @classmethod
@@ -62,6 +67,9 @@ class Searcher:
         with self._cv:
             self._stop = True
             self._cv.notify_all()
+            chain, self._native_chain = self._native_chain, None
+        if chain is not None:
+            chain.close()
         if self._worker is not None:
             self._worker.join()
             self._worker = None
@@ -145,12 +153,51 @@ class Searcher:
             self._chain = (ShardedGallery(g1), ShardedGallery(g2))
         return self._chain
 
+    def _native(self):
+        """The library's coalescing front on the two galleries of the chain, or None (sharded chain / native=False)."""
+        if self._native_chain is None:
+            with self._lock:
+                if self._native_chain is None:
+                    from .. import _lib
+                    sg1, sg2 = self._device_chain()
+                    if sg1._protocol or sg2._protocol:
+                        self.native = False
+                        return None
+                    self._native_chain = _lib.OnlineChain(sg1.g, sg2.g, self.K, 3, 4.0, 1e-6, self.max_batch,
+                                                          int(round(self.max_wait_s * 1e6)))
+        return self._native_chain
+
+    @property
+    def chain_stats(self):
+        """(chains launched, requests they answered) of whichever worker serves this Searcher."""
+        if self._native_chain is not None:
+            st = self._native_chain.stats()
+            return st["chains"], st["requests"]
+        return self.batches, self.batched_requests
+
     def query_device(self, desc, return_indices=False):
         """The online chain WITHOUT a host round trip (src/online.py:121-152 copies the descriptor to the CPU,
         searches there and re-ranks there): `desc` is the extractor tail's output on the device (float32 cuda tensor [D] or
         [Q, D]: isehr_amd.extractor.DescriptorTail / extract_ms_device -> mi_desc_tail_device), the search (K nearest by cosine),
         the qge1 expansion from the top-3 rows (k = 3, w = 4, float64 sum, eps-normalised) and the re-search of the expanded
         query all run on the device through the asynchronous entry points; ONE device-to-host copy of Q x K indices ends it."""
+        import torch
+        nq = 1 if desc.dim() == 1 else desc.shape[0]
+        chain = None
+        if self.coalesce and self.native and nq <= self.max_batch:
+            chain = self._native_chain or self._native()
+        if chain is not None:
+            # the request thread's whole share of interpreter time: no view, no copy of a descriptor that is float32 and
+            # contiguous already, one foreign call (which releases the interpreter lock while the chain runs)
+            if desc.dtype is not torch.float32 or not desc.is_contiguous():
+                desc = desc.contiguous().float()
+            if desc.is_cuda:
+                out = chain.query(desc.data_ptr(), nq, 1, True, torch.cuda.current_stream(desc.device).cuda_stream or None)
+            else:
+                out = chain.query(desc.data_ptr(), nq, 0)
+            if return_indices:
+                return out
+            return [[self.img_paths[i] for i in row] for row in out]
         if desc.dim() == 1:
             desc = desc[None, :]
         desc = desc.contiguous().float()

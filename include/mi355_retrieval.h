@@ -364,11 +364,42 @@ int mi_set_global_option(const char* name, double value);
  * extractor's PyTorch allocator) cannot see otherwise. */
 int mi_get_global_option(const char* name, double* out_value);
 
+/* ---- the online chain behind one coalescing front: replaces the body of the Flask route of src/online.py:108-163 (threaded
+ * server, every request thread searches on module-level globals) minus the CNN: search (K nearest by cosine on g_search,
+ * src/online.py:124-131) -> qge1 expansion from the first k_qe rows as stored in g_rows (src/utils/Reranking.py:195-208; the
+ * route uses k_qe = 3, w = 4, src/online.py:148) -> re-search of g_rows with the expanded query as it is.  g_rows = NULL: the
+ * plain search.  A launch of <= 128 queries costs what a launch of one does, so concurrent callers of mi_online_query are
+ * answered TOGETHER: they block inside the call (a Python host's request threads: outside the interpreter lock) while one
+ * worker thread of the handle drains the waiting descriptors -- up to max_batch rows -- into one chain and hands every caller
+ * its rows.  The worker waits -- at most until max_wait_us after it handed out the previous chain -- for as many requests as
+ * callers were around then (answered + queued): the callers just answered are on their way back, and two half crowds taking
+ * turns are half the throughput of one; a lone sequential caller never waits, nor does anyone after an idle period.  Every chain runs the verified
+ * loop of the host entry points (sticky flags read, f32 scorer / dense float64 fallbacks), so the answers are those of
+ * sequential mi_knn_search + mi_aqe_search calls bit for bit.  The galleries must outlive the handle and share device,
+ * dimension and rows; other threads may keep using them (the chain takes their locks). */
+typedef struct mi_online mi_online;
+int mi_online_create(mi_gallery* g_search, mi_gallery* g_rows, int32_t k, int32_t k_qe, double w, double eps,
+                     int32_t max_batch /*1..1024, 128: the streaming kernel's limit*/, int32_t max_wait_us, mi_online** out);
+/* desc: nq <= max_batch descriptors [nq][d] f32, host or device memory.  pending != 0 (device descriptors only): they are still
+ * being produced on producer_stream (NULL = the null stream) -- an event is recorded there and the chain waits for it on the
+ * device; pending = 0: they are complete.  Blocks until the chain that carried the request is done; out_idx [nq][k] int64 (global row ids) and out_score [nq][k] f32 (may be NULL) are HOST arrays.
+ * A failed chain fails every request it carried, with the chain's message on each caller's thread (mi_last_error). */
+int mi_online_query(mi_online* o, const float* desc, int32_t nq, int memspace, int pending, void* producer_stream,
+                    int64_t* out_idx, float* out_score);
+int mi_online_stats(mi_online* o, int64_t* out_chains, int64_t* out_requests);
+/* Answers what is still queued, stops the worker, frees the handle (not the galleries). */
+int mi_online_destroy(mi_online* o);
+
 /* The XCD shares of the tile kernel (relative speeds of the eight XCD labels, summing to 1) as the handle's launches have left
  * them, and how many launches have updated them since the workspace was created (-1: no workspace yet; the values are then what
  * the first one will start from).  The shares are saved with the prepared-gallery file (optional trailer) and remembered per
  * device inside the process, so `load -> first search` and a second gallery of a process start calibrated. */
 int mi_debug_xcc_shares(mi_gallery* g, float* out_w8, int32_t* out_launches);
+/* Diagnostics / bench only: `threads` request threads of the library itself in a closed loop of per_thread requests each (request
+ * i of thread t = descriptor (t + i) mod n_desc of desc_dev [n_desc][d], complete) -- what the coalescing front sustains when
+ * the host's request threads are not serialised by an interpreter lock.  out_last_idx [threads][k] host: every thread's last answer. */
+int mi_debug_online_clients(mi_online* o, const float* desc_dev, int32_t n_desc, int32_t threads, int32_t per_thread,
+                            int64_t* out_last_idx, double* out_seconds);
 /* Diagnostics only: the per-wave words the tile kernel leaves behind, layout [workgroups * 8][8]: word 5 = K-slices done, word 6 =
  * shader cycles and word 7 = 10-ns ticks around the main loop (what kernel_clock_mhz and the XCD shares are computed from); words
  * 0-4 are written by the stamped build of scripts/kbench.hip only. */

@@ -118,6 +118,11 @@ def test_default_line_gives_every_baseline_config_a_number():
     oc = o["online_concurrent"]
     assert oc["equals_sequential_answers"] is True and oc["coalesced"]["mean_requests_per_chain"] > 4
     assert o["online_concurrent_qps"] > 4 * oc["sequential_calls_same_threads"]["value"]
+    # the library's worker (mi_online_*) serves the figure; the Python worker and the library's own client threads sit beside it
+    assert oc["coalesced"]["worker"].startswith("library") and oc["coalesced_python_worker"]["worker"] == "python thread"
+    nc = oc["coalesced_native_clients"]
+    assert nc["equals_sequential_answers"] is True and nc["mean_requests_per_chain"] > 16
+    assert o["online_concurrent_native_clients_qps"] == nc["value"] > oc["coalesced_python_worker"]["value"]
     # round 6: the batch-size staircase, the headline's shape on structured data, learned whitening
     qs = out["qsweep"]
     assert [p["queries"] for p in qs["points"]] == [128, 129, 192, 256, 257, 384, 512, 768, 1024]

@@ -95,11 +95,13 @@ def test_online_device_chain_vs_reference_qge1_golden(golden_dir, tmp_path, monk
         nnsearch.drop_cached_galleries()
 
 
-def test_online_concurrent_callers_are_coalesced_and_get_the_sequential_answers(tmp_path, monkeypatch):
+@pytest.mark.parametrize("native", [True, False])
+def test_online_concurrent_callers_are_coalesced_and_get_the_sequential_answers(tmp_path, monkeypatch, native):
     """src/online.py:163 runs Flask's threaded server: request threads call the route concurrently on module-level globals.
     `Searcher.query_device` hands concurrent descriptors to one worker that answers them in ONE search -> qge1 -> re-search
     chain.  64 threads x 20 queries: every answer equals the uncoalesced call's, and the requests really
-    were batched."""
+    were batched.  native: the worker thread of the library (mi_online_*, the callers block outside the interpreter lock);
+    otherwise the Python worker of entry/online.py."""
     import threading
     import torch
     from isehr_amd import nnsearch
@@ -111,13 +113,14 @@ def test_online_concurrent_callers_are_coalesced_and_get_the_sequential_answers(
     vecs = vecs / np.linalg.norm(vecs, axis=0, keepdims=True)
     qd = torch.from_numpy(synth_rows(92, 0, nthr * per, d)).cuda()
     plain = online.Searcher(vecs, list(range(n)), K, coalesce=False)
-    srv = online.Searcher(vecs, list(range(n)), K, coalesce=True)
+    srv = online.Searcher(vecs, list(range(n)), K, coalesce=True, native=native)
     try:
         want = plain.query_device(qd[:128], return_indices=True)
         want = np.concatenate([want] + [plain.query_device(qd[i:i + 128], return_indices=True)
                                         for i in range(128, nthr * per, 128)])
         # one sequential caller is not delayed and not batched
-        assert np.array_equal(srv.query_device(qd[5], return_indices=True)[0], want[5]) and srv.batches == 1
+        assert np.array_equal(srv.query_device(qd[5], return_indices=True)[0], want[5]) and srv.chain_stats == (1, 1)
+        assert (srv._native_chain is not None) == native
         got = np.full((nthr * per, K), -1, dtype=np.int64)
         errs = []
 
@@ -135,13 +138,80 @@ def test_online_concurrent_callers_are_coalesced_and_get_the_sequential_answers(
             th.join(timeout=120)
         assert not errs, errs[:1]
         assert np.array_equal(got, want)
-        assert srv.batched_requests == nthr * per + 1 and srv.batches < nthr * per / 4, (srv.batches, srv.batched_requests)
+        chains, answered = srv.chain_stats
+        assert answered == nthr * per + 1 and chains < nthr * per / 4, (chains, answered)
         # a request wider than the batch limit is answered directly, a [Q, D] request keeps its rows together
         assert np.array_equal(srv.query_device(qd[:200], return_indices=True), want[:200])
         assert np.array_equal(srv.query_device(qd[300:307], return_indices=True), want[300:307])
+        # descriptors still being produced on a stream of the caller's: the chain waits for them on the device
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            late = torch.zeros((3, d), device="cuda")
+            torch.cuda._sleep(20_000_000)                             # ~10 ms of device time in front of the producer
+            late.copy_(qd[40:43], non_blocking=True)
+            got_late = srv.query_device(late, return_indices=True)
+        assert np.array_equal(got_late, want[40:43])
+        # and host descriptors (a CPU tensor) take the same chain (the library's worker copies them into its pinned slots)
+        if native:
+            assert np.array_equal(srv.query_device(qd[50:52].cpu(), return_indices=True), want[50:52])
     finally:
         srv.close()
         nnsearch.drop_cached_galleries()
+
+
+def test_online_chain_of_the_library_alone():
+    """mi_online_* without the Searcher around it (include/mi355_retrieval.h): the plain-search mode (no second gallery) with
+    scores and host descriptors; a chain that fails fails EVERY request it carried, with the chain's message on each caller's
+    thread; the handle recovers; destroy answers what is queued; a closed gallery is refused on the Python side."""
+    import threading
+    from isehr_amd import _lib
+    from isehr_amd.synth import synth_rows
+    n, d, K = 20000, 128, 10
+    g = synth_rows(95, 0, n, d)
+    g[5000:5400] = g[4999]                                          # 401 identical rows: more candidates than a rescore_cap of 64
+    q = synth_rows(96, 0, 8, d)
+    G = _lib.Gallery.from_host(g)
+    chain = _lib.OnlineChain(G, None, K, max_batch=128, max_wait_us=500)
+    try:
+        want_i, want_s, _ = G.search(q, K)
+        for j in range(8):
+            idx, sc = chain.query(q[j:j + 1].ctypes.data, 1, _lib.MI_HOST, scores=True)
+            assert np.array_equal(idx[0], want_i[j]) and np.array_equal(sc[0], want_s[j])
+        idx = chain.query(q.ctypes.data, 8, _lib.MI_HOST)             # one request of eight rows
+        assert np.array_equal(idx, want_i) and chain.stats() == {"chains": 9, "requests": 9}
+        with pytest.raises(RuntimeError, match="max_batch"):
+            chain.query(np.zeros((129, d), np.float32).ctypes.data, 129, _lib.MI_HOST)
+        # a failing chain: the duplicated row as a query overflows the candidate buffer, and overflow is an error now
+        G.set_option("rescore_cap", 64)
+        G.set_option("exact_fallback", 0)
+        bad = np.ascontiguousarray(g[4999:5000])
+        with pytest.raises(RuntimeError, match="overflow"):
+            chain.query(bad.ctypes.data, 1, _lib.MI_HOST)
+        msgs = []
+
+        def client(j):
+            try:
+                chain.query((bad if j == 3 else q[j:j + 1]).ctypes.data, 1, _lib.MI_HOST)
+                msgs.append(None)
+            except RuntimeError as e:
+                msgs.append(str(e))
+        G.set_option("exact_fallback", 1)
+        G.set_option("rescore_cap", 1024)
+        # healthy again: the same requests, concurrently, all answered (the duplicated row's best rows are the 401 copies)
+        ths = [threading.Thread(target=client, args=(j,)) for j in range(8)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(timeout=60)
+        assert msgs == [None] * 8
+        idx = chain.query(bad.ctypes.data, 1, _lib.MI_HOST)
+        assert set(idx[0]) <= set(range(4999, 5400)) and np.array_equal(idx[0], np.arange(4999, 4999 + K))
+    finally:
+        chain.close()
+        chain.close()                                               # idempotent
+        G.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        _lib.OnlineChain.query(chain, q.ctypes.data, 1, _lib.MI_HOST)
 
 
 @pytest.mark.parametrize("mode,gpus", [("100", "0"), ("mAP", "0"), ("100", "0,0")])

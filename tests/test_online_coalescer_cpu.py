@@ -1,7 +1,8 @@
 """CPU: the coalescing worker of entry/online.py Searcher (src/online.py:163 runs Flask's threaded server: concurrent request
 threads) with the GPU chain replaced by a stand-in -- the queueing logic alone: every caller gets ITS rows back, requests are
 batched, a lone caller is never delayed by the straggler wait, oversized and multi-row requests keep their rows together, a
-failure inside a chain reaches every caller of that chain, close() drains."""
+failure inside a chain reaches every caller of that chain, close() drains.
+(native=False: the Python worker; the library's own, mi_online_*, needs the device: tests/test_gpu_entry_points.py.)"""
 import threading
 import time
 import types
@@ -33,7 +34,7 @@ def searcher_cls(monkeypatch):
 
 def test_concurrent_callers_get_their_own_rows_and_are_batched(searcher_cls):
     import torch
-    srv = searcher_cls(None, None, 7, coalesce=True)
+    srv = searcher_cls(None, None, 7, coalesce=True, native=False)
     nthr, per = 32, 12
     got = np.full((nthr * per,), -1, dtype=np.int64)
     errs = []
@@ -70,7 +71,7 @@ def test_concurrent_callers_get_their_own_rows_and_are_batched(searcher_cls):
 
 def test_a_lone_sequential_caller_never_waits_for_stragglers(searcher_cls):
     import torch
-    srv = searcher_cls(None, None, 3, coalesce=True, max_wait_s=0.05)        # a straggler wait that would be visible
+    srv = searcher_cls(None, None, 3, coalesce=True, native=False, max_wait_s=0.05)        # a straggler wait that would be visible
     srv.chain_s = 0.0005
     try:
         d = torch.zeros(8)
@@ -87,7 +88,7 @@ def test_a_lone_sequential_caller_never_waits_for_stragglers(searcher_cls):
 
 def test_a_failing_chain_reaches_its_callers_and_the_worker_lives_on(searcher_cls):
     import torch
-    srv = searcher_cls(None, None, 3, coalesce=True)
+    srv = searcher_cls(None, None, 3, coalesce=True, native=False)
     srv.fail_on = 13.0
     try:
         with pytest.raises(RuntimeError, match="chain failed"):
