@@ -98,19 +98,22 @@ class Searcher:
         import time
         import torch
         torch.cuda.set_device(self.device)
-        recent = [1, 1, 1, 1]                                         # requests of the last chains: how many callers are around
+        # the callers known to be around when the last chain was handed out: the ones it answered (on their way back) + the
+        # ones already queued behind it (csrc/api_online.hip has the same policy)
+        expect, t_done = 1, time.perf_counter()
         while True:
             with self._cv:
                 while not self._queue and not self._stop:
                     self._cv.wait()
                 if self._stop and not self._queue:
                     return
-                crowd = min(max(recent), self.max_batch)
+                crowd = min(expect, self.max_batch)
                 if crowd > 1 and self.max_wait_s > 0:
-                    # callers arrive concurrently: the ones the previous chain has just answered are on their way back (a chain
-                    # of 64 descriptors costs what a chain of one does).  Wait -- briefly -- until as many requests as the
-                    # recent chains held are queued; a lone sequential caller (crowd 1) never waits
-                    deadline = time.perf_counter() + self.max_wait_s
+                    # a chain of 64 descriptors costs what a chain of one does, so the chain worth launching holds every caller
+                    # that is around: wait -- until max_wait_s after the last hand-out at most -- for as many requests as that
+                    # (launching whatever is queued when a chain ends settles into two half crowds taking turns).  A lone
+                    # sequential caller (expect 1) never waits, nor does anyone after an idle period
+                    deadline = t_done + self.max_wait_s
                     while len(self._queue) < crowd:
                         left = deadline - time.perf_counter()
                         if left <= 0:
@@ -121,7 +124,6 @@ class Searcher:
                     r = self._queue.pop(0)
                     take.append(r)
                     rows += r.desc.shape[0]
-            recent = recent[1:] + [len(take)]
             try:
                 st = torch.cuda.current_stream()
                 for r in take:
@@ -138,8 +140,11 @@ class Searcher:
                     r.error = e
             self.batches += 1
             self.batched_requests += len(take)
+            with self._cv:
+                expect = len(take) + len(self._queue)
             for r in take:
                 r.done.release()
+            t_done = time.perf_counter()
 
     def _device_chain(self):
         """The two prepared galleries of the chain -- L2-normalised rows for the search (matching_L2's ranking), the rows as
