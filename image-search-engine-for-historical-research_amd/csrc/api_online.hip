@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <new>
 #include <thread>
 
 #include "api_internal.h"
@@ -191,7 +192,8 @@ int mi_online_create(mi_gallery* g_search, mi_gallery* g_rows, int32_t k, int32_
     if ((rc = check_k(g_rows, k)) != MI_OK) return rc;
   }
   HIPC(hipSetDevice(g_search->device));
-  mi_online* o = new mi_online();
+  mi_online* o = new (std::nothrow) mi_online();
+  if (!o) return fail(MI_ERR_NOMEM, "online handle");
   o->g1 = g_search;
   o->device = g_search->device;
   o->g2 = g_rows;
@@ -216,7 +218,13 @@ int mi_online_create(mi_gallery* g_search, mi_gallery* g_rows, int32_t k, int32_
     delete o;
     return fail(MI_ERR_NOMEM, "online chain buffers");
   }
-  o->worker = std::thread(online_serve, o);
+  try {
+    o->worker = std::thread(online_serve, o);
+  } catch (const std::exception& e) {                     // no exception crosses the C boundary
+    online_free(o);
+    delete o;
+    return fail(MI_ERR_NOMEM, std::string("could not start the worker thread: ") + e.what());
+  }
   *out = o;
   return MI_OK;
 }
@@ -291,7 +299,8 @@ int mi_debug_online_clients(mi_online* o, const float* desc_dev, int32_t n_desc,
   std::vector<std::string> errs((size_t)threads);
   std::vector<std::thread> th;
   const auto t0 = std::chrono::steady_clock::now();
-  for (int32_t t = 0; t < threads; ++t)
+  bool started = true;
+  for (int32_t t = 0; t < threads && started; ++t) try {
     th.emplace_back([&, t] {
       for (int32_t i = 0; i < per_thread; ++i) {
         const int rc = mi_online_query(o, desc_dev + (size_t)((t + i) % n_desc) * d, 1, MI_DEVICE, 0, nullptr,
@@ -303,7 +312,11 @@ int mi_debug_online_clients(mi_online* o, const float* desc_dev, int32_t n_desc,
         }
       }
     });
+  } catch (const std::exception&) {
+    started = false;
+  }
   for (auto& x : th) x.join();
+  if (!started) return fail(MI_ERR_NOMEM, "could not start the client threads");
   *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (int32_t t = 0; t < threads; ++t)
     if (rcs[t] != MI_OK) return fail(rcs[t], errs[t]);
