@@ -1011,7 +1011,34 @@ def whiten_block(job, args):
                 "TFLOPs_incl_normalise": flop / best["gemm_plus_normalise"] / 1e12,
                 "bytes_algorithmic": n * d * 4 + n * dims * 8 * (1 + 2), "rows_per_s": n / best["gemm_plus_normalise"],
                 "max_abs_diff_vs_float64_numpy_16_rows": err}
-        del out
+        # the layout whitenapply is CALLED with: X is [D, N], one image per column (src/utils/whiten.py:4-12; `vecs` of
+        # src/main_train.py:711-712) -- the same rows, transposed in device memory, read with strides (row stride 1, column
+        # stride N): the kernel's other loader (64 consecutive images of one k per wave instruction)
+        xt = torch.empty((d, n), dtype=torch.float32, device=dev)
+        for r0 in range(0, n, 131072):
+            xt[:, r0:r0 + 131072] = raw[r0:r0 + 131072].t()
+        best_t = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _lib.whiten_apply_device(xt.data_ptr(), n, d, m.data_ptr(), P.data_ptr(), d, out.data_ptr(), eps=-1.0,
+                                     row_stride=1, col_stride=n, stream=stream)
+            torch.cuda.synchronize()
+            best_t = min(best_t, time.perf_counter() - t0)
+        _lib.whiten_apply_device(xt.data_ptr(), n, d, m.data_ptr(), P.data_ptr(), d, out.data_ptr(), eps=1e-6,
+                                 row_stride=1, col_stride=n, stream=stream)
+        torch.cuda.synchronize()
+        got = out[picks].cpu().numpy()
+        ref = (xh - m.cpu().numpy()) @ P.cpu().numpy().T
+        ref /= (np.linalg.norm(ref, axis=1, keepdims=True) + 1e-6)
+        err = float(np.abs(got - ref).max())
+        assert err < 1e-12, "whitening of the [D, N] layout differs from the float64 recomputation: %g" % err
+        rec["dims_2048_from_DxN"] = {"gemm_seconds": round(best_t, 5), "TFLOPs_gemm": 2.0 * n * d * d / best_t / 1e12,
+                                     "frac_of_f64_matrix_peak": 2.0 * n * d * d / best_t / 1e12 / F64_MATRIX_PEAK_TFLOPS,
+                                     "vs_row_major": best_t / rec["dims_%d" % d]["gemm_seconds"],
+                                     "max_abs_diff_vs_float64_numpy_16_rows": err,
+                                     "layout": "X [D, N] float32 (the reference's), row stride 1, column stride N"}
+        del out, xt
         torch.cuda.empty_cache()
         # (ii) whitened rows straight into a gallery (MI_NORM_L2_EPS = whitenapply's tail): one call, 512 MiB of scratch
         gal = _lib.Gallery.empty(n, d, norm_mode=_lib.NORM_L2_EPS, device=job.dev_index)

@@ -136,6 +136,7 @@ def test_default_line_gives_every_baseline_config_a_number():
     assert hd["min_vs_gaussian_headline"] > 0.5
     w = out["whiten"]
     assert w["dims_2048"]["frac_of_f64_matrix_peak"] > 0.4 and w["dims_2048"]["max_abs_diff_vs_float64_numpy_16_rows"] < 1e-12
+    assert w["dims_2048_from_DxN"]["frac_of_f64_matrix_peak"] > 0.3 and w["dims_2048_from_DxN"]["max_abs_diff_vs_float64_numpy_16_rows"] < 1e-12
     assert w["into_gallery"]["rows_per_s"] > 1e6 and w["into_gallery"]["max_abs_diff_of_stored_f32_rows"] < 2e-7
     a = out["aqe_rparis_1m"]
     assert a["gallery_rows"] == 1007323 and a["q1024"]["value"] > 0 and a["q70"]["value"] > 0
