@@ -1136,45 +1136,47 @@ def online_block(job, gal, args):
                                             ("coalesced_python_worker", True, False, 84), ("coalesced", True, True, 148)):
             kw = {"max_wait_s": float(os.environ["ISEHR_ONLINE_WAIT_US"]) * 1e-6} if "ISEHR_ONLINE_WAIT_US" in os.environ else {}
             srv = Searcher.from_galleries(gal, g_raw, k, device=job.dev_index, coalesce=coalesce, native=native, **kw)
-            got = [None] * nthr
-            errs = []
+            try:
+                got = [None] * nthr
+                errs = []
 
-            def client(t):
-                try:
-                    torch.cuda.set_device(job.dev_index)
-                    for i in range(per):
-                        got[t] = srv.query_device(rows_c[(t + i) % nthr], return_indices=True)
-                except Exception as e:                                # noqa: BLE001
-                    errs.append(e)
-            srv.query_device(qc[0], return_indices=True)                                        # warm
-            ths = [threading.Thread(target=client, args=(t,)) for t in range(nthr)]
-            t0 = time.perf_counter()
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-            elc = time.perf_counter() - t0
-            if errs:
-                raise errs[0]
-            chains, answered = srv.chain_stats if coalesce else (nthr * per, nthr * per)
-            conc[mode] = {"value": nthr * per / elc, "unit": "queries/s", "seconds": elc, "queries_per_thread": per,
-                          "worker": ("library (mi_online_*)" if native else "python thread") if coalesce else None,
-                          "chains_launched": chains, "mean_requests_per_chain": answered / max(1, chains)}
-            conc[mode + "_answers"] = np.concatenate(got)
-            if native:
-                # the same front driven by 64 request threads of the library itself (mi_debug_online_clients): what is left
-                # when the clients' interpreter time is taken out -- the figure a compiled host, or a Python host whose
-                # request threads do nothing else under the interpreter lock, sees
-                sec, last = srv._native().native_clients(qc.data_ptr(), nthr, nthr, 148 + 128)
-                c0, a0 = chains, answered
-                chains, answered = srv.chain_stats
-                conc["coalesced_native_clients"] = {
-                    "value": nthr * (148 + 128) / sec, "unit": "queries/s", "seconds": sec, "queries_per_thread": 148 + 128,
-                    "worker": "library (mi_online_*)", "clients": "threads of the library (mi_debug_online_clients)",
-                    "chains_launched": chains - c0, "mean_requests_per_chain": (answered - a0) / max(1, chains - c0),
-                    "equals_sequential_answers": bool(np.array_equal(last, conc["sequential_calls_same_threads_answers"]))}
-                assert conc["coalesced_native_clients"]["equals_sequential_answers"]
-            srv.close()
+                def client(t):
+                    try:
+                        torch.cuda.set_device(job.dev_index)
+                        for i in range(per):
+                            got[t] = srv.query_device(rows_c[(t + i) % nthr], return_indices=True)
+                    except Exception as e:                                # noqa: BLE001
+                        errs.append(e)
+                srv.query_device(qc[0], return_indices=True)                                        # warm
+                ths = [threading.Thread(target=client, args=(t,)) for t in range(nthr)]
+                t0 = time.perf_counter()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                elc = time.perf_counter() - t0
+                if errs:
+                    raise errs[0]
+                chains, answered = srv.chain_stats if coalesce else (nthr * per, nthr * per)
+                conc[mode] = {"value": nthr * per / elc, "unit": "queries/s", "seconds": elc, "queries_per_thread": per,
+                              "worker": ("library (mi_online_*)" if native else "python thread") if coalesce else None,
+                              "chains_launched": chains, "mean_requests_per_chain": answered / max(1, chains)}
+                conc[mode + "_answers"] = np.concatenate(got)
+                if native:
+                    # the same front driven by 64 request threads of the library itself (mi_debug_online_clients): what is left
+                    # when the clients' interpreter time is taken out -- the figure a compiled host, or a Python host whose
+                    # request threads do nothing else under the interpreter lock, sees
+                    sec, last = srv._native().native_clients(qc.data_ptr(), nthr, nthr, 148 + 128)
+                    c0, a0 = chains, answered
+                    chains, answered = srv.chain_stats
+                    conc["coalesced_native_clients"] = {
+                        "value": nthr * (148 + 128) / sec, "unit": "queries/s", "seconds": sec, "queries_per_thread": 148 + 128,
+                        "worker": "library (mi_online_*)", "clients": "threads of the library (mi_debug_online_clients)",
+                        "chains_launched": chains - c0, "mean_requests_per_chain": (answered - a0) / max(1, chains - c0),
+                        "equals_sequential_answers": bool(np.array_equal(last, conc["sequential_calls_same_threads_answers"]))}
+                    assert conc["coalesced_native_clients"]["equals_sequential_answers"]
+            finally:
+                srv.close()
         want_c = conc.pop("sequential_calls_same_threads_answers")
         same = bool(np.array_equal(want_c, conc.pop("coalesced_answers")) and
                     np.array_equal(want_c, conc.pop("coalesced_python_worker_answers")))

@@ -275,8 +275,11 @@ class Gallery:
         check(load().mi_gallery_save(self._h, os.fsencode(path)))
 
     def close(self):
+        """mi_gallery_destroy.  Refused (RuntimeError, the handle stays valid) while an online chain is built on the gallery."""
         if self._h is not None and self._h.value:
-            load().mi_gallery_destroy(self._h)
+            rc = load().mi_gallery_destroy(self._h)
+            if rc:
+                check(rc)
             self._h = None
 
     def __del__(self):

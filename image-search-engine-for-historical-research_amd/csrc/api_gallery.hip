@@ -5,6 +5,8 @@ extern "C" {
 
 int mi_gallery_destroy(mi_gallery* g) {
   if (!g) return MI_OK;
+  // the worker thread of an online handle would search a freed gallery with the next request
+  REQUIRE(g->online_users.load() == 0, "the gallery is in use by an online handle: mi_online_destroy comes first");
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->tail_stream) (void)hipStreamSynchronize(g->tail_stream);

@@ -214,6 +214,7 @@ struct mi_gallery {
   float* dif_vals = nullptr;
   int32_t dif_T = 0;
   std::mutex mu;
+  std::atomic<int> online_users{0};   // mi_online handles built on this gallery: it cannot be destroyed under them
 };
 
 // ---- api_state.hip

@@ -225,6 +225,8 @@ int mi_online_create(mi_gallery* g_search, mi_gallery* g_rows, int32_t k, int32_
     delete o;
     return fail(MI_ERR_NOMEM, std::string("could not start the worker thread: ") + e.what());
   }
+  g_search->online_users.fetch_add(1);
+  if (g_rows) g_rows->online_users.fetch_add(1);
   *out = o;
   return MI_OK;
 }
@@ -331,6 +333,8 @@ int mi_online_destroy(mi_online* o) {
   }
   o->cv_work.notify_all();
   if (o->worker.joinable()) o->worker.join();          // answers what is still queued, then returns
+  o->g1->online_users.fetch_sub(1);
+  if (o->g2) o->g2->online_users.fetch_sub(1);
   online_free(o);
   delete o;
   return MI_OK;

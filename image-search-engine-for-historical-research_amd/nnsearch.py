@@ -166,12 +166,18 @@ def _build_gallery(train, norm_mode, device):
 
 def drop_cached_galleries():
     """Closes every cached gallery and gives the library's spare-buffer slots back too (mi_set_global_option "release_spares":
-    up to 16 GiB + ~200 MB that would otherwise stay with the process for the next gallery of the same sizes)."""
+    up to 16 GiB + ~200 MB that would otherwise stay with the process for the next gallery of the same sizes).  A gallery an
+    online chain is still built on (entry.online.Searcher: close() it first) is refused by the library and stays cached."""
     with _cache_lock:
         wait_for_saves()
-        for g in _cache.values():
-            g.close()
-        _cache.clear()
+        for key in list(_cache):
+            try:
+                _cache[key].close()
+            except RuntimeError as e:
+                if "online handle" not in str(e):
+                    raise
+                continue
+            del _cache[key]
         _lib.set_global_option("release_spares", 1)
 
 

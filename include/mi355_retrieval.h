@@ -375,8 +375,9 @@ int mi_get_global_option(const char* name, double* out_value);
  * callers were around then (answered + queued): the callers just answered are on their way back, and two half crowds taking
  * turns are half the throughput of one; a lone sequential caller never waits, nor does anyone after an idle period.  Every chain runs the verified
  * loop of the host entry points (sticky flags read, f32 scorer / dense float64 fallbacks), so the answers are those of
- * sequential mi_knn_search + mi_aqe_search calls bit for bit.  The galleries must outlive the handle and share device,
- * dimension and rows; other threads may keep using them (the chain takes their locks). */
+ * sequential mi_knn_search + mi_aqe_search calls bit for bit.  The galleries must outlive the handle (mi_gallery_destroy
+ * refuses a gallery an online handle is built on) and share device, dimension and rows; other threads may keep using them
+ * (the chain takes their locks). */
 typedef struct mi_online mi_online;
 int mi_online_create(mi_gallery* g_search, mi_gallery* g_rows, int32_t k, int32_t k_qe, double w, double eps,
                      int32_t max_batch /*1..1024, 128: the streaming kernel's limit*/, int32_t max_wait_us, mi_online** out);

@@ -56,6 +56,7 @@ def test_offline_then_online(feature_store, capsys):
     np.save("q.npy", qvecs[:, :2])
     assert online.main(["--datasets", "dsA,dsB", "--query-npy", "q.npy"]) == 0
     assert ".jpg" in capsys.readouterr().out
+    s.close()
     # the same query through the device chain (descriptor on the device -> search -> qge1 -> one D2H of K indices)
     import torch
     got_dev = s.query_device(torch.from_numpy(np.ascontiguousarray(qvecs[:, 3])).cuda())
@@ -91,8 +92,13 @@ def test_online_device_chain_vs_reference_qge1_golden(golden_dir, tmp_path, monk
         s64 = (vecs.astype(np.float64).T @ ref_qx).T
         assert oracle.check_topk_parity(got, s64, K, 1e-6) == []
         assert (got.T == ref_ranks).mean() > 0.99
-    finally:
+        # the galleries of a live chain are not dropped underneath it (the library refuses; they stay cached) ...
         nnsearch.drop_cached_galleries()
+        assert np.array_equal(s.query_device(torch.from_numpy(np.ascontiguousarray(qv.T)).cuda(), return_indices=True), got)
+    finally:
+        s.close()                                                     # ... and go once the chain is closed
+        nnsearch.drop_cached_galleries()
+    assert not nnsearch._cache
 
 
 @pytest.mark.parametrize("native", [True, False])
@@ -206,12 +212,96 @@ def test_online_chain_of_the_library_alone():
         assert msgs == [None] * 8
         idx = chain.query(bad.ctypes.data, 1, _lib.MI_HOST)
         assert set(idx[0]) <= set(range(4999, 5400)) and np.array_equal(idx[0], np.arange(4999, 4999 + K))
+        # the gallery cannot be destroyed under the handle (its worker would search freed memory with the next request)
+        with pytest.raises(RuntimeError, match="online handle"):
+            G.close()
+        assert np.array_equal(chain.query(q[2:3].ctypes.data, 1, _lib.MI_HOST)[0], want_i[2])
     finally:
         chain.close()
         chain.close()                                               # idempotent
         G.close()
     with pytest.raises(RuntimeError, match="closed"):
         _lib.OnlineChain.query(chain, q.ctypes.data, 1, _lib.MI_HOST)
+
+
+def test_online_chain_packs_whole_requests_and_drains_on_destroy():
+    """mi_online_*: a chain holds WHOLE requests up to max_batch rows (a request that does not fit waits for the next chain, its
+    rows stay together), device and host descriptors mix in one chain, handles come and go, and destroy answers what is queued."""
+    import threading
+    import torch
+    from isehr_amd import _lib
+    from isehr_amd.synth import synth_rows
+    n, d, K = 12000, 192, 7
+    G = _lib.Gallery.from_host(synth_rows(97, 0, n, d))
+    R = _lib.Gallery.from_host(synth_rows(97, 0, n, d), norm_mode=_lib.NORM_NONE)
+    q = synth_rows(98, 0, 36, d)
+    qd = torch.from_numpy(q).cuda()
+    torch.cuda.synchronize()
+    try:
+        for _ in range(3):                                          # create / destroy with nothing queued
+            _lib.OnlineChain(G, R, K, max_batch=8, max_wait_us=0).close()
+        chain = _lib.OnlineChain(G, R, K, k_qe=3, w=4.0, max_batch=8, max_wait_us=300)
+        want = np.concatenate([chain.query(q[i:i + 3].ctypes.data, 3, _lib.MI_HOST) for i in range(0, 36, 3)])
+        base = chain.stats()
+        assert base == {"chains": 12, "requests": 12}
+        got = np.full((36, K), -1, dtype=np.int64)
+        errs = []
+
+        def client(t):                                              # requests of 3 rows: at most two fit a chain of 8
+            try:
+                for rep in range(4):
+                    i = 3 * t
+                    if t % 2:
+                        got[i:i + 3] = chain.query(qd[i:i + 3].data_ptr(), 3, _lib.MI_DEVICE)
+                    else:
+                        got[i:i + 3] = chain.query(q[i:i + 3].ctypes.data, 3, _lib.MI_HOST)
+            except Exception as e:                                  # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=client, args=(t,)) for t in range(12)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(timeout=120)
+        assert not errs, errs[:1]
+        assert np.array_equal(got, want)
+        st = chain.stats()
+        assert st["requests"] - base["requests"] == 48 and (st["chains"] - base["chains"]) * 2 >= 48
+        chain.close()
+        # destroy while requests are waiting: every one of them is answered first.  The worker is held inside a chain whose only
+        # descriptor is still being produced (behind ~0.1 s of device sleep on its producer's stream); twelve requests queue
+        # behind it, then the handle is destroyed
+        c2 = _lib.OnlineChain(G, R, K, k_qe=3, w=4.0, max_batch=64, max_wait_us=300)
+        try:
+            out = np.full((13, K), -1, dtype=np.int64)
+            side = torch.cuda.Stream()
+            late = torch.zeros((1, d), device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(250_000_000)
+                late.copy_(qd[35:36], non_blocking=True)
+
+            def held():
+                out[12] = c2.query(late.data_ptr(), 1, _lib.MI_DEVICE, True, side.cuda_stream)[0]
+
+            def single(t):
+                out[t] = c2.query(q[3 * t:3 * t + 1].ctypes.data, 1, _lib.MI_HOST)[0]
+            ths = [threading.Thread(target=held)]
+            ths[0].start()
+            import time
+            time.sleep(0.005)                                       # the worker has taken the held request, alone
+            ths += [threading.Thread(target=single, args=(t,)) for t in range(12)]
+            for th in ths[1:]:
+                th.start()
+            time.sleep(0.02)                                        # all twelve are inside the call, queued behind the held chain
+            assert (out == -1).all() and c2.stats() == {"chains": 1, "requests": 1}
+        finally:
+            c2.close()                                              # mi_online_destroy: drains the queue, then stops the worker
+        for th in ths:
+            th.join(timeout=60)
+        assert np.array_equal(out[:12], want[0::3]) and np.array_equal(out[12], want[35])
+    finally:
+        G.close()
+        R.close()
 
 
 @pytest.mark.parametrize("mode,gpus", [("100", "0"), ("mAP", "0"), ("100", "0,0")])
