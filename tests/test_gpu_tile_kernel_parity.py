@@ -66,6 +66,33 @@ def test_tile_kernel_headline_shape_vs_oracle(lib, n, img):
         g.close()
 
 
+@pytest.mark.parametrize("img", ["f16", "bf16"])
+def test_ragged_batches_answer_like_the_full_batch(lib, img):
+    """129 .. 192 / 257 .. 448 / ... queries leave one to three of the last query tile's four 64-query columns empty (their
+    waves multiply zeros; a variant that let them sit such tiles out was measured and lost: profiles/r06aa_idle_columns_ab.txt).
+    The full batch against float64 ground truth, and every ragged prefix of it bit for bit the full batch's answers -- whatever
+    the number of query tiles, the padding, the kernel (one-tile nt launches, the streaming kernel's neighbours)."""
+    n = 100003
+    raw = _device_rows(lib, 33, n, D)
+    q = _device_rows(lib, 34, Q, D)
+    lib.set_global_option("image_dtype", 1 if img == "f16" else 0)
+    try:
+        g = lib.Gallery.from_device_ptr(raw.data_ptr(), n, D)
+    finally:
+        lib.set_global_option("image_dtype", 1)
+    try:
+        full_i, full_s = _search(g, q, K)                                 # 1024 queries: no padding anywhere
+        s = oracle.exact_scores_f64(raw.cpu().numpy(), q.cpu().numpy())
+        assert oracle.check_topk_parity(full_i, s, K, TAU) == []
+        for nq in (129, 150, 192, 193, 257, 300, 320, 321, 384, 448, 449, 513, 600, 769, 832, 1000):
+            g.status(reset=True)
+            idx, sc = _search(g, q[:nq].contiguous(), K)
+            assert g.flags() == 0 and g.status()["overflow_batches"] == 0, nq
+            assert np.array_equal(idx, full_i[:nq]) and np.array_equal(sc, full_s[:nq]), nq
+    finally:
+        g.close()
+
+
 def test_laboratory_switches_are_not_in_the_product(lib):
     """Round 5: the diagnostic / A-B instantiations of the tile kernel (stages switched off, other issue orders, DMA cache
     policies, the paired-XCD walk, the first structure) are compiled into scripts/kbench.hip's own program only
