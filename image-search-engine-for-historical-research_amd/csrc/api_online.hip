@@ -249,7 +249,14 @@ int mi_online_query(mi_online* o, const float* desc, int32_t nq, int memspace, i
     o->events.push_back(r.ev);
   };
   if (memspace == MI_DEVICE && pending) {
-    HIPC(hipSetDevice(o->device));
+    // the event belongs to the handle's device; the calling thread keeps the device it had
+    int prev = o->device;
+    (void)hipGetDevice(&prev);
+    struct Restore {
+      int dev, want;
+      ~Restore() { if (dev != want) (void)hipSetDevice(dev); }
+    } restore{prev, o->device};
+    if (prev != o->device) HIPC(hipSetDevice(o->device));
     {
       std::lock_guard<std::mutex> lk(o->mu);
       if (!o->events.empty()) {
