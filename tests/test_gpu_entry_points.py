@@ -288,7 +288,10 @@ def test_online_chain_packs_whole_requests_and_drains_on_destroy():
             ths = [threading.Thread(target=held)]
             ths[0].start()
             import time
-            time.sleep(0.005)                                       # the worker has taken the held request, alone
+            for _ in range(400):                                    # until the worker has taken the held request, alone
+                if c2.stats()["requests"] == 1:
+                    break
+                time.sleep(0.0005)
             ths += [threading.Thread(target=single, args=(t,)) for t in range(12)]
             for th in ths[1:]:
                 th.start()
